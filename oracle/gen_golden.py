@@ -1,0 +1,120 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates ``tests/golden/*.npz`` by executing the reference's own
+source files (``oracle/refload.py``) in the build container:
+
+    python -m oracle.gen_golden          # needs /root/reference; writes tests/golden/
+
+Inputs and weights are *not* stored: they are regenerated from frozen ``np.random.RandomState``
+streams keyed by state_dict key (``graph_weather_amd.utils.deterministic_fill_``), so the fixtures
+stay small.  Stored: full forecaster outputs for the 10 degree / B=2 plumbing config (BASELINE.json
+configs[0]) and a 5 degree / B=1 case, sub-sampled encoder / processor intermediates, the
+NormalizedMSELoss value, one GraphProcessor block on a random COO graph, a bare MLP, and checksums
+of the graph arrays the run used.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features  # noqa: E402
+from oracle.refload import load_reference  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _graph_checksums(model):
+    out = {}
+    for name, g in (("enc", model.encoder.graph), ("lat", model.encoder.latent_graph), ("dec", model.decoder.graph)):
+        ei = g.edge_index.numpy().astype(np.int64)
+        w = np.arange(1, ei.shape[1] + 1, dtype=np.int64)
+        out[name + "_num_edges"] = np.int64(ei.shape[1])
+        out[name + "_index_checksum"] = np.int64(((ei[0] * 31 + ei[1] * 17) * w % 1000003).sum())
+        out[name + "_attr_sum"] = np.float64(g.edge_attr.double().sum().item())
+    return out
+
+
+def forecaster_case(ns, step: float, batch: int, tag: str):
+    lat_lons = regular_lat_lons(step)
+    model = ns.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    model.eval()
+    feats = seeded_features(batch, len(lat_lons), 102, seed=42)
+    with torch.no_grad():
+        x, ei, ea = model.encoder(feats)
+        xp = model.processor(x, ei, ea)
+        y = model.decoder(xp, feats[..., :78])
+        y2 = model(feats)
+    assert torch.equal(y, y2)
+    rs = np.random.RandomState(7)
+    target = torch.from_numpy(rs.random_sample(tuple(y.shape)).astype(np.float32))
+    var = torch.from_numpy((rs.random_sample(78) + 0.5).astype(np.float32))
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):  # the reference loss prints 4 shapes per call
+        loss = ns.NormalizedMSELoss(feature_variance=var.tolist(), lat_lons=lat_lons)(y, target)
+        loss_n = ns.NormalizedMSELoss(feature_variance=var.tolist(), lat_lons=lat_lons, normalize=True)(y, target)
+    data = {
+        "step": np.float64(step), "batch": np.int64(batch),
+        "out": y.numpy(),
+        "enc_x_rows": x[::37].numpy(), "proc_x_rows": xp[::37].numpy(),
+        "lat_edge_attr_rows": ea[::997].numpy(),
+        "loss": np.float64(loss.item()), "loss_normalized": np.float64(loss_n.item()),
+        "lat_edge_index_replicated_max": np.int64(ei.max().item()),
+    }
+    data.update(_graph_checksums(model))
+    np.savez_compressed(os.path.join(OUT, f"forecaster_{tag}.npz"), **data)
+    print(tag, "out", tuple(y.shape), "loss", loss.item(), "absmax delta", (y - feats[..., :78]).abs().max().item())
+
+
+def block_case(ns):
+    """One GraphProcessor block on a random COO graph (the shape of
+    tests/models/test_gradient_checkpointing.py:62-86: arbitrary edge_index, not h3)."""
+    rs = np.random.RandomState(123)
+    n, e = 500, 3000
+    gp = ns.GraphProcessor(mp_iterations=2, in_dim_node=256, in_dim_edge=256, hidden_dim_node=256,
+                           hidden_dim_edge=256, hidden_layers_node=2, hidden_layers_edge=2, norm_type="LayerNorm")
+    deterministic_fill_(gp, seed=3)
+    gp.eval()
+    x = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
+    ea = torch.from_numpy(rs.standard_normal((e, 256)).astype(np.float32))
+    ei = torch.from_numpy(rs.randint(0, n, size=(2, e)).astype(np.int64))
+    with torch.no_grad():
+        xo, eo = gp(x, ei, ea)
+    np.savez_compressed(os.path.join(OUT, "graph_processor_random.npz"), x_out=xo.numpy(), e_out_rows=eo[::5].numpy(),
+                        edge_index=ei.numpy())
+    print("block", tuple(xo.shape), tuple(eo.shape))
+
+
+def mlp_case(ns):
+    rs = np.random.RandomState(5)
+    for tag, (i, o, h, norm) in {"node_enc": (102, 256, 256, "LayerNorm"), "edge_enc": (2, 256, 256, "LayerNorm"),
+                                 "node_dec": (256, 78, 128, None)}.items():
+        m = ns.MLP(i, o, h, 2, norm)
+        deterministic_fill_(m, seed=11)
+        m.eval()
+        x = torch.from_numpy(rs.standard_normal((300, i)).astype(np.float32))
+        with torch.no_grad():
+            y = m(x)
+        np.savez_compressed(os.path.join(OUT, f"mlp_{tag}.npz"), x=x.numpy(), y=y.numpy())
+        print("mlp", tag, tuple(y.shape))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = load_reference()
+    torch.set_num_threads(8)
+    mlp_case(ns)
+    block_case(ns)
+    forecaster_case(ns, 10.0, 2, "10deg_b2")
+    forecaster_case(ns, 5.0, 1, "5deg_b1")
+
+
+if __name__ == "__main__":
+    main()
