@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""bench.py - forward forecasts/s of GraphWeatherForecaster on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one forward pass of the hot path over one batch of synthetic input that is already resident in HBM.
+Workload at every N = BASELINE.json configs[1] per GPU: 1 degree grid (64 800 nodes), 102 -> 78 features,
+batch 2, fp32 arithmetic (fp32-in / fp32-accumulate MFMA), random-init weights.  Batch elements are independent,
+so N GPUs run N independent shards with no data-path collective (weak scaling); value = all forecasts / max time.
+
+Prints ONE JSON line with the driver contract fields plus
+  "roofline":     dominant kernel (decoder edge update) - algorithmic FLOPs per launch / HIP-event duration vs the
+                  fp32 matrix peak of gfx950 (157.3 TFLOP/s), and
+  "cpu_baseline": the CPU oracle (port of the reference forward, replicated-graph semantics) on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 acc
+EDGE_MLP_FLOPS = 2 * (768 * 256 + 256 * 256 + 256 * 256)  # per edge, SURVEY.md 8(d): mlp(768,256,256)
+
+
+def cpu_baseline(lat_lons, state, graphs, batch, budget_s=25.0):
+    """Oracle forward (what the reference executes: replicated graph, fp32, eval) on the host cores."""
+    from graph_weather_amd.utils import seeded_features
+    from oracle import reference_math as om
+
+    feats = seeded_features(batch, len(lat_lons), 102, seed=42)
+    g = graphs.as_oracle_dict()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        om.forecaster_forward(state, g, feats)  # warm-up
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int(budget_s // max(warm, 1e-3)) - 1))
+    times = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            om.forecaster_forward(state, g, feats)
+        times.append(time.perf_counter() - t0)
+    mean = sum(times) / len(times)
+    return {"value": batch / mean, "unit": "forecasts/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} timed forward(s) after 1 warm-up, 1 degree grid, batch {batch}, fp32, torch CPU oracle "
+                      f"(mean {mean:.2f} s, min {min(times):.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=float, default=1.0, help="grid spacing in degrees (1.0 = BASELINE configs[1])")
+    ap.add_argument("--batch", type=int, default=2, help="batch per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import graph_weather_amd as gw
+    from graph_weather_amd import ops
+    from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features
+
+    lat_lons = regular_lat_lons(args.grid)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    graphs = model.encoder.graphs
+    model = model.to(dev).eval()
+    feats = seeded_features(args.batch, len(lat_lons), 102, seed=42 + rank).to(dev)  # resident in HBM before timing
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(feats)
+        ops.TIMER = ops.KernelTimer(["decoder_edge", "processor_edge", "encoder_edge"])
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(feats)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    assert torch.isfinite(y).all()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        e_dec = graphs.dec_plan.num_edges
+        dec_ms = timer.mean_ms("decoder_edge")
+        flops = EDGE_MLP_FLOPS * e_dec * args.batch
+        achieved = flops / (dec_ms * 1e-3) / 1e12
+        out = {
+            "metric": "forward forecasts/sec (1° grid, 102→78 feat)", "value": world * args.batch * args.steps / elapsed,
+            "unit": "forecasts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"GraphWeatherForecaster {args.grid:g}deg grid ({len(lat_lons)} nodes), 102->78 feat, "
+                                   f"batch={args.batch} per GPU, fp32, mesh res 2 (5882 nodes), random-init weights",
+                       "global_batch": world * args.batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
+            "roofline": {"bound": "mfma", "kernel": "chain_kernel<EDGE> (decoder edge update)", "achieved": achieved,
+                         "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
+                         "traffic": None, "launch_ms": dec_ms, "algorithmic_flops_per_launch": flops,
+                         "other_kernels_ms": {"processor_edge": timer.mean_ms("processor_edge"),
+                                              "encoder_edge": timer.mean_ms("encoder_edge")}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lat_lons, cpu_state, graphs, args.batch)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

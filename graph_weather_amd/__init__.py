@@ -1,0 +1,21 @@
+"""graph_weather_amd - MI355X (gfx950) native implementation of the GraphWeatherForecaster hot path.
+
+Mirrors the import surface of the reference for that path (``graph_weather/__init__.py:9``,
+``graph_weather/models/__init__.py:13-15``): ``GraphWeatherForecaster``, ``Encoder``, ``Processor``, ``Decoder``,
+``GraphProcessor``, ``MLP``, ``NormalizedMSELoss``.
+"""
+from .forecast import GraphWeatherForecaster, GraphWeatherForecasterConfig  # noqa: F401
+from .layers import (  # noqa: F401
+    MLP,
+    AssimilatorDecoder,
+    Decoder,
+    EdgeProcessor,
+    Encoder,
+    GraphProcessor,
+    NodeProcessor,
+    Processor,
+    build_graph_processor_block,
+)
+from .losses import NormalizedMSELoss  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,91 @@
+"""ctypes binding of ``libgw_amd.so`` (C ABI declared in ``include/gw_amd.h``).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, a
+``RuntimeError`` is raised - the product path never computes on the CPU or through torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
+
+EXPORTS = [
+    "gw_version", "gw_last_error", "gw_packed_floats", "gw_pack_linear", "gw_padded_n", "gw_pad_vector",
+    "gw_mlp_forward", "gw_edge_update_forward", "gw_node_update_forward", "gw_normalized_mse_forward",
+]
+
+
+class GwOperand(Structure):
+    _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("rows_per_batch", c_int32), ("ld", c_int32), ("k", c_int32)]
+
+
+class GwMlpWeights(Structure):
+    _fields_ = [("w1", c_void_p * 3), ("b1", c_void_p), ("w_mid", c_void_p), ("b_mid", c_void_p), ("w_out", c_void_p),
+                ("b_out", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("hidden", c_int32),
+                ("n_mid", c_int32), ("n_out", c_int32)]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libgw_amd.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    deps = srcs + [os.path.join(os.path.dirname(_HERE), "include", "gw_amd.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "graph_weather_amd: %s is missing - the HIP extension must be built (python -c 'import __graft_entry__ as g; "
+            "g.build()'); there is no CPU/torch fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.gw_version.restype = c_int
+    L.gw_last_error.restype = c_char_p
+    L.gw_packed_floats.restype = c_size_t
+    L.gw_packed_floats.argtypes = [c_int, c_int, c_int]
+    L.gw_pack_linear.restype = c_int
+    L.gw_pack_linear.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.gw_padded_n.restype = c_int
+    L.gw_padded_n.argtypes = [c_int]
+    L.gw_pad_vector.restype = c_int
+    L.gw_pad_vector.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+    L.gw_mlp_forward.restype = c_int
+    L.gw_mlp_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwMlpWeights), POINTER(GwOperand),
+                                 c_void_p, c_int32, c_void_p]
+    L.gw_edge_update_forward.restype = c_int
+    L.gw_edge_update_forward.argtypes = [c_int32, c_int32, c_void_p, c_void_p, POINTER(GwOperand), POINTER(GwOperand),
+                                         POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_void_p, c_int32, c_void_p]
+    L.gw_node_update_forward.restype = c_int
+    L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights),
+                                         c_void_p, c_int32, c_void_p]
+    L.gw_normalized_mse_forward.restype = c_int
+    L.gw_normalized_mse_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                            c_void_p, c_void_p]
+    if L.gw_version() != 1:
+        raise RuntimeError("graph_weather_amd: libgw_amd.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().gw_last_error().decode(errors="replace")
+        raise RuntimeError("graph_weather_amd: %s failed (%d): %s" % (what, rc, msg))

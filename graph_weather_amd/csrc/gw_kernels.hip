@@ -1,0 +1,651 @@
+// gw_kernels.hip - CDNA4 (gfx950) kernels for the graph_weather message-passing hot path.
+//
+// Design:  every MLP of the model is evaluated in the *transposed* form
+//       H_out[feature][column] = W[feature][k] * H_in[k][column]
+// with `column` = one edge / node, 32 columns per 64-lane wave.  With v_mfma_f32_32x32x2_f32 the weight
+// matrix is the A operand (A[i = lane&31][k = lane>>5]) and the activations are the B operand
+// (B[k = lane>>5][j = lane&31]).  The accumulator layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+// holds, for column j, exactly the features a lane must supply as B operand of the next layer if the K
+// dimension is walked in the order k(s, h) = 8*(s>>2) + 4*h + (s&3) - so a 3-layer MLP + LayerNorm + residual
+// runs register-resident, no transposes, no LDS traffic for activations.  LDS carries only the packed weight
+// stream (shared by the 4 waves of a workgroup, filled by global_load_lds DMA, double buffered).
+// fp32 in / fp32 accumulate MFMA == an fmaf chain, so the result is fp32-exact up to summation order.
+//
+// Reference statements implemented: graph_net_block.py:45-61 (MLP), :131-137 (EdgeProcessor), :184-193
+// (NodeProcessor incl. scatter_sum :188), losses.py:66-94 (NormalizedMSELoss).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gw_amd.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;          // 4 waves, one per SIMD
+constexpr int kColsPerWave = 32;
+constexpr int kColsPerWG = 128;
+constexpr int kChunkSteps = 16;        // K-steps (2 k's each) per LDS buffer
+constexpr int kLdsBufFloats = kChunkSteps * 2 * 256;  // 16 steps x 8 tiles x 32 rows x 2 k = 32 KiB
+constexpr int kLdsBytes = 2 * kLdsBufFloats * 4;       // double buffered: 64 KiB
+
+enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
+
+struct ChainArgs {
+  int n_cols;          // total columns (batch * cols_per_batch)
+  int cols_per_batch;
+  // layer-1 operands
+  const float* seg_ptr[3];
+  const int* seg_idx[3];
+  int seg_rows_pb[3];
+  int seg_ld[3];
+  int seg_k[3];
+  // weights
+  const float* w1[3];
+  const float* b1;
+  const float* w_mid;
+  const float* b_mid;
+  const float* w_out;
+  const float* b_out;
+  const float* gamma;
+  const float* beta;
+  int n_mid;
+  // residual
+  const float* res_ptr;
+  const int* res_idx;
+  int res_rows_pb;
+  int res_ld;
+  // outputs
+  float* out;
+  int out_ld;
+  int out_cols;
+  float* agg;
+  const int* agg_idx;
+  int agg_rows_pb;
+};
+
+#define GW_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const GW_AS1 f32x4*)p; }
+__device__ __forceinline__ float ldg1(const float* p) { return *(const GW_AS1 float*)p; }
+__device__ __forceinline__ int ldgi(const int* p) { return *(const GW_AS1 int*)p; }
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *(GW_AS1 f32x4*)p = v; }
+__device__ __forceinline__ void stg1(float* p, float v) { *(GW_AS1 float*)p = v; }
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// Each wave DMAs its share of `nfloats` (multiple of 256) from the packed weight stream into an LDS buffer.
+__device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
+  const int npieces = nfloats >> 8;
+  for (int p = wave; p < npieces; p += 4) glds16(g + (size_t)p * 256 + lane * 4, ldsbuf + p * 256);
+}
+
+// in[16c .. 16c+15] <- row[k(s,h)] for the K-steps of chunk c (full 16-byte aligned rows)
+template <int NSTEPS>
+__device__ __forceinline__ void load_operand_slice(float (&in)[NSTEPS], const float* __restrict__ row, int c, int h) {
+#pragma unroll
+  for (int i = 4 * c; i < 4 * c + 4; ++i) {
+    if (4 * i + 3 < NSTEPS) {
+      const f32x4 v = ldg4(row + 8 * i + 4 * h);
+      in[4 * i + 0] = v.x;
+      in[4 * i + 1] = v.y;
+      in[4 * i + 2] = v.z;
+      in[4 * i + 3] = v.w;
+    }
+  }
+}
+
+// One K-pass of a layer: acc[t] += W[32t.., k] * in[k], K = 2*NSTEPS, NT row tiles of 32 features.
+// Protocol: the first chunk of this pass has already been issued into buffer `parity`.
+// With RELOAD, the 16 operand registers a chunk has consumed are refilled (one chunk later) with the same
+// k-slice of the NEXT layer-1 operand (rows are full 256-float rows), so the gather of operand i+1 streams in
+// underneath the MFMAs of operand i at no extra register cost; the slice consumed by the last chunk is
+// refilled during chunk 0 of the next pass (`tail_row`).
+template <int NSTEPS, int NT, bool RELOAD>
+__device__ __forceinline__ void mma_pass(f32x16 (&acc)[NT], float (&in)[NSTEPS], const float* __restrict__ gw,
+                                         const float* __restrict__ next_gw, int next_floats, float* lds, int& parity,
+                                         int lane, int wave, const float* __restrict__ tail_row, bool do_tail,
+                                         const float* __restrict__ next_row, bool do_next, int h) {
+  constexpr int NT4 = (NT + 3) / 4;
+  constexpr int STEPF = NT4 * 256;
+  constexpr int NCH = (NSTEPS + kChunkSteps - 1) / kChunkSteps;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int nsteps_c = (NSTEPS - c * kChunkSteps) < kChunkSteps ? (NSTEPS - c * kChunkSteps) : kChunkSteps;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk c has landed for every wave; nobody still reads the other buffer
+    float* other = lds + (parity ^ 1) * kLdsBufFloats;
+    if (c + 1 < NCH) {
+      const int nn = (NSTEPS - (c + 1) * kChunkSteps) < kChunkSteps ? (NSTEPS - (c + 1) * kChunkSteps) : kChunkSteps;
+      issue_chunk(gw + (size_t)(c + 1) * kChunkSteps * STEPF, nn * STEPF, other, lane, wave);
+    } else if (next_gw != nullptr) {
+      issue_chunk(next_gw, next_floats, other, lane, wave);
+    }
+    if (RELOAD) {
+      // Operand registers are refilled one chunk behind their consumption, right after the barrier, so the
+      // gathers have a whole chunk of MFMAs (~8k cycles) to land before the next vmcnt(0).
+      if (c == 0) {
+        if (do_tail) load_operand_slice<NSTEPS>(in, tail_row, NCH - 1, h);   // this operand's last 16 registers
+      } else {
+        if (do_next) load_operand_slice<NSTEPS>(in, next_row, c - 1, h);     // next operand, slice consumed last chunk
+      }
+    }
+    const float* buf = lds + parity * kLdsBufFloats + lane * 4;
+    f32x4 a_cur[NT4];
+#pragma unroll
+    for (int q = 0; q < NT4; ++q) a_cur[q] = *(const f32x4*)(buf + q * 256);
+#pragma unroll
+    for (int s = 0; s < kChunkSteps; ++s) {
+      if (s < nsteps_c) {
+        f32x4 a_nxt[NT4];
+        if (s + 1 < nsteps_c) {
+#pragma unroll
+          for (int q = 0; q < NT4; ++q) a_nxt[q] = *(const f32x4*)(buf + (s + 1) * STEPF + q * 256);
+        }
+        const float b = in[c * kChunkSteps + s];
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of step s+1 ahead of the MFMAs of step s
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps_c) {
+#pragma unroll
+          for (int q = 0; q < NT4; ++q) a_cur[q] = a_nxt[q];
+        }
+      }
+    }
+    parity ^= 1;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* __restrict__ bias, int h) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = ldg4(bias + 32 * t + 8 * g + 4 * h);
+      acc[t][4 * g + 0] = v.x;
+      acc[t][4 * g + 1] = v.y;
+      acc[t][4 * g + 2] = v.z;
+      acc[t][4 * g + 3] = v.w;
+    }
+}
+
+// in[s] <- row[k(s,h)], k(s,h) = 8*(s>>2) + 4*h + (s&3)
+template <int KSTEPS, bool FULL>
+__device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* __restrict__ row, int kvalid, int h) {
+#pragma unroll
+  for (int i = 0; i < KSTEPS / 4; ++i) {
+    if (FULL) {
+      const f32x4 v = ldg4(row + 8 * i + 4 * h);
+      in[4 * i + 0] = v.x;
+      in[4 * i + 1] = v.y;
+      in[4 * i + 2] = v.z;
+      in[4 * i + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 8 * i + 4 * h + r;
+        in[4 * i + r] = (k < kvalid) ? ldg1(row + k) : 0.f;
+      }
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_to_in(float (&in)[NT * 16], const f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[16 * t + r] = fmaxf(acc[t][r], 0.f);
+}
+
+__device__ __forceinline__ const float* operand_row(const float* ptr, const int* idx, int rows_pb, int ld, int b, int k) {
+  const int r = idx ? ldgi(idx + k) : k;
+  return ptr + ((size_t)b * (size_t)rows_pb + (size_t)r) * (size_t)ld;
+}
+
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI>
+__global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HS = HT * 16;                  // K-steps of a hidden layer
+  constexpr int HSTEPF = ((HT + 3) / 4) * 256;  // floats per step, hidden-row layers
+  constexpr int OSTEPF = ((OT + 3) / 4) * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  const int c_raw = blockIdx.x * kColsPerWG + wave * kColsPerWave + j;
+  const bool valid = c_raw < a.n_cols;
+  const int c = valid ? c_raw : a.n_cols - 1;
+  const int b = c / a.cols_per_batch;
+  const int k = c - b * a.cols_per_batch;
+
+  // ---- weight-stream schedule (wave uniform) ----
+  bool on[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) on[i] = (i < NSEG) && (a.seg_k[i] > 0);
+  const float* after_l1 = a.n_mid > 0 ? a.w_mid : a.w_out;
+  const int after_l1_floats = a.n_mid > 0 ? kChunkSteps * HSTEPF : kChunkSteps * OSTEPF;
+  constexpr int K1FIRST = (K1S < kChunkSteps ? K1S : kChunkSteps) * HSTEPF;
+  int parity = 0;
+  {
+    const float* first = on[0] ? a.w1[0] : (on[1] ? a.w1[1] : (on[2] ? a.w1[2] : after_l1));
+    const int first_floats = (on[0] || on[1] || on[2]) ? K1FIRST : after_l1_floats;
+    issue_chunk(first, first_floats, lds, lane, wave);
+  }
+
+  // ---- layer 1 ----
+  f32x16 acc[HT];
+  init_bias<HT>(acc, a.b1, h);
+  {
+    const float* row[3] = {nullptr, nullptr, nullptr};
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i)
+      if (on[i]) row[i] = operand_row(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], b, k);
+    float x[K1S];
+    {
+      const int f = on[0] ? 0 : (on[1] ? 1 : 2);
+      if (on[0] || on[1] || on[2]) load_operand<K1S, K1FULL>(x, row[f], a.seg_k[f], h);
+    }
+    constexpr bool RL = K1FULL && (NSEG > 1);
+    bool tail_pending = false;  // the current operand's last register slice still has to be gathered
+    if (on[0]) {
+      const float* nx = on[1] ? a.w1[1] : (on[2] ? a.w1[2] : after_l1);
+      const int nf = (on[1] || on[2]) ? K1FIRST : after_l1_floats;
+      const bool more = on[1] || on[2];
+      mma_pass<K1S, HT, RL>(acc, x, a.w1[0], nx, nf, lds, parity, lane, wave, nullptr, false, on[1] ? row[1] : row[2], more, h);
+      tail_pending = more;
+    }
+    if (NSEG > 1 && on[1]) {
+      const float* nx = on[2] ? a.w1[2] : after_l1;
+      const int nf = on[2] ? K1FIRST : after_l1_floats;
+      mma_pass<K1S, HT, RL>(acc, x, a.w1[1], nx, nf, lds, parity, lane, wave, row[1], tail_pending, row[2], on[2], h);
+      tail_pending = on[2];
+    }
+    if (NSEG > 2 && on[2])
+      mma_pass<K1S, HT, RL>(acc, x, a.w1[2], after_l1, after_l1_floats, lds, parity, lane, wave, row[2], tail_pending, nullptr, false, h);
+  }
+
+  // ---- middle layers (hidden -> hidden) ----
+  float hin[HS];
+#pragma unroll 1
+  for (int l = 0; l < a.n_mid; ++l) {
+    relu_to_in<HT>(hin, acc);
+    init_bias<HT>(acc, a.b_mid + l * (HT * 32), h);
+    const bool last = (l + 1 == a.n_mid);
+    const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
+    const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
+    mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+  }
+
+  // ---- output layer ----
+  relu_to_in<HT>(hin, acc);
+  f32x16 o[OT];
+  init_bias<OT>(o, a.b_out, h);
+  mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+
+  // ---- LayerNorm over the OT*32 features of each column (eps 1e-5, biased variance) ----
+  if (a.gamma != nullptr) {
+    constexpr float inv_n = 1.0f / (OT * 32);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += o[t][r];
+    s += __shfl_xor(s, 32);
+    const float mean = s * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = o[t][r] - mean;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q * inv_n + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 gm = ldg4(a.gamma + 32 * t + 8 * g + 4 * h);
+        const f32x4 bt = ldg4(a.beta + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][4 * g + r] = (o[t][4 * g + r] - mean) * rstd * gm[r] + bt[r];
+      }
+  }
+
+  // ---- residual ----
+  if (a.res_ptr != nullptr) {
+    const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * t + 8 * g + 4 * h;
+        if (EPI == EPI_DEC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) o[t][4 * g + r] += ldg1(rrow + f0 + r);
+        } else {
+          const f32x4 v = ldg4(rrow + f0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[t][4 * g + r] += v[r];
+        }
+      }
+  }
+
+  // ---- store ----
+  if (a.out != nullptr && valid) {
+    float* orow = a.out + (size_t)c * (size_t)a.out_ld;
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f0 = 32 * t + 8 * g + 4 * h;
+        if (EPI == EPI_DEC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[t][4 * g + r]);
+        } else {
+          f32x4 v;
+          v.x = o[t][4 * g + 0];
+          v.y = o[t][4 * g + 1];
+          v.z = o[t][4 * g + 2];
+          v.w = o[t][4 * g + 3];
+          stg4(orow + f0, v);
+        }
+      }
+  }
+
+  // ---- segment sum over destination-sorted columns: shuffle scan + one atomicAdd per segment tail ----
+  if (EPI == EPI_EDGE) {
+    const int gd = valid ? (b * a.agg_rows_pb + ldgi(a.agg_idx + k)) : (-1 - j);
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int gu = __shfl_up(gd, off, 32);
+      const bool take = (j >= off) && (gu == gd);
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float u = __shfl_up(o[t][r], off, 32);
+          o[t][r] += take ? u : 0.f;
+        }
+    }
+    const int gn = __shfl_down(gd, 1, 32);
+    const bool tail = valid && (j == 31 || gn != gd);
+    if (tail) {
+      float* arow = a.agg + (size_t)gd * (size_t)(OT * 32);
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+          __hip_atomic_fetch_add((GW_AS1 float*)(arow + f), o[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+  }
+}
+
+// ---- weight packing: nn.Linear [n_out, k_total] slice -> MFMA A-operand stream -------------------------
+// out[s][q4][lane][q] = W[32*(4*q4+q) + (lane&31)][k_lo + 8*(s>>2) + 4*(lane>>5) + (s&3)]  (0 outside)
+__global__ void pack_linear_kernel(const float* __restrict__ w, int n_out, int k_total, int k_lo, int kseg, int nt4,
+                                   int nsteps, float* __restrict__ out) {
+  const size_t total = (size_t)nsteps * nt4 * 256;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    const int q4 = (int)((i >> 8) % nt4);
+    const int s = (int)((i >> 8) / nt4);
+    const int f = 32 * (4 * q4 + q) + (lane & 31);
+    const int kk = 8 * (s >> 2) + 4 * (lane >> 5) + (s & 3);
+    out[i] = (f < n_out && kk < kseg) ? w[(size_t)f * k_total + k_lo + kk] : 0.f;
+  }
+}
+
+__global__ void pad_vector_kernel(const float* __restrict__ v, int n, int npad, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) out[i] = i < n ? v[i] : 0.f;
+}
+
+// ---- NormalizedMSELoss (losses.py:66-94) ----------------------------------------------------------------
+__global__ void nmse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                            const float* __restrict__ inv_var, const float* __restrict__ lat_w, int num_lon,
+                            int nodes, int channels, size_t total, float scale, float* __restrict__ loss) {
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / channels;
+    const int ch = (int)(i - row * channels);
+    const int n = (int)(row % nodes);
+    float d = pred[i] - target[i];
+    d = d * d;
+    if (inv_var) d *= inv_var[ch];
+    acc += d * lat_w[n / num_lon];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += part[i];
+    __hip_atomic_fetch_add(loss, s * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return GW_E_LAUNCH;
+  }
+  return GW_OK;
+}
+
+template <typename K>
+int launch_chain(K kernel, const ChainArgs& a, void* stream) {
+  static bool attr_done = false;  // per template instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    attr_done = true;
+  }
+  const int grid = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
+  return check_launch("chain_kernel launch");
+}
+
+void fill_weights(ChainArgs& a, const gw_mlp_weights* w) {
+  for (int i = 0; i < 3; ++i) a.w1[i] = w->w1[i];
+  a.b1 = w->b1;
+  a.w_mid = w->w_mid;
+  a.b_mid = w->b_mid;
+  a.w_out = w->w_out;
+  a.b_out = w->b_out;
+  a.gamma = w->ln_gamma;
+  a.beta = w->ln_beta;
+  a.n_mid = w->n_mid;
+}
+
+void fill_operand(ChainArgs& a, int i, const gw_operand* op) {
+  a.seg_ptr[i] = op->ptr;
+  a.seg_idx[i] = op->index;
+  a.seg_rows_pb[i] = op->rows_per_batch;
+  a.seg_ld[i] = op->ld;
+  a.seg_k[i] = op->k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gw_version(void) { return GW_ABI_VERSION; }
+const char* gw_last_error(void) { return g_err; }
+
+size_t gw_packed_floats(int n_out, int k_lo, int k_hi) {
+  const int kseg = k_hi - k_lo;
+  const int nsteps = ((kseg + 7) / 8) * 4;
+  const int nt = (n_out + 31) / 32;
+  const int nt4 = (nt + 3) / 4;
+  return (size_t)nsteps * nt4 * 256;
+}
+
+int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, float* out, void* stream) {
+  if (!w || !out || n_out <= 0 || k_lo < 0 || k_hi <= k_lo || k_hi > k_total) return fail(GW_E_BADARG, "gw_pack_linear: bad arguments");
+  const int kseg = k_hi - k_lo;
+  const int nsteps = ((kseg + 7) / 8) * 4;
+  const int nt4 = (((n_out + 31) / 32) + 3) / 4;
+  const size_t total = (size_t)nsteps * nt4 * 256;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n_out, k_total, k_lo, kseg, nt4, nsteps, out);
+  return check_launch("pack_linear_kernel launch");
+}
+
+int gw_padded_n(int n) { return ((n + 31) / 32) * 32; }
+
+int gw_pad_vector(const float* v, int n, float* out, void* stream) {
+  if (!v || !out || n <= 0) return fail(GW_E_BADARG, "gw_pad_vector: bad arguments");
+  const int npad = gw_padded_n(n);
+  hipLaunchKernelGGL(pad_vector_kernel, dim3((npad + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, n, npad, out);
+  return check_launch("pad_vector_kernel launch");
+}
+
+int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
+                   const gw_operand* residual, float* out, int32_t out_ld, void* stream) {
+  if (!x || !w || !out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_mlp_forward: bad arguments");
+  if (n_rows == 0) return GW_OK;
+  if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: more than 2^31-1 rows");
+  if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out || (w->n_mid > 0 && (!w->w_mid || !w->b_mid)))
+    return fail(GW_E_BADARG, "gw_mlp_forward: missing weights / empty operand");
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = (int)n_rows;
+  a.cols_per_batch = rows_per_batch;
+  fill_operand(a, 0, x);
+  fill_weights(a, w);
+  if (residual) {
+    a.res_ptr = residual->ptr;
+    a.res_idx = residual->index;
+    a.res_rows_pb = residual->rows_per_batch;
+    a.res_ld = residual->ld;
+  }
+  a.out = out;
+  a.out_ld = out_ld;
+  a.out_cols = w->n_out;
+  if (w->hidden == 256 && w->n_out == 256) {
+    if (residual && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
+    if (out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
+    if (x->k <= 8) return launch_chain(chain_kernel<4, false, 1, 8, 8, EPI_ROWS>, a, stream);
+    if (x->k <= 104) return launch_chain(chain_kernel<52, false, 1, 8, 8, EPI_ROWS>, a, stream);
+    if (x->k == 256 && x->ld % 4 == 0) return launch_chain(chain_kernel<128, true, 1, 8, 8, EPI_ROWS>, a, stream);
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=104 or ==256 for hidden 256");
+  }
+  if (w->hidden == 128 && w->n_out <= 96 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
+    return launch_chain(chain_kernel<128, true, 1, 4, 3, EPI_DEC>, a, stream);
+  }
+  return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: unsupported (hidden, n_out, k) combination");
+}
+
+int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
+                           const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
+                           const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst, void* stream) {
+  if (!src || !dst || !x_src || !x_dst || !e_in || !w || !agg || batch <= 0 || n_edges < 0 || n_dst <= 0)
+    return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
+  if (n_edges == 0) return GW_OK;
+  if ((int64_t)batch * n_edges >= (int64_t)1 << 31 || (int64_t)batch * n_dst >= (int64_t)1 << 31)
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: batch*edges exceeds int32");
+  if (w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || !w->ln_beta)
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: only hidden=256, out=256, LayerNorm is implemented");
+  const gw_operand* ops[3] = {x_src, x_dst, e_in};
+  for (int i = 0; i < 3; ++i) {
+    if (ops[i]->k != 0 && (ops[i]->k != 256 || ops[i]->ld % 4 != 0 || !ops[i]->ptr || !w->w1[i]))
+      return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
+  }
+  if (e_in->k != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_in must be present (residual)");
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = batch * n_edges;
+  a.cols_per_batch = n_edges;
+  fill_operand(a, 0, x_src);
+  a.seg_idx[0] = src;
+  fill_operand(a, 1, x_dst);
+  a.seg_idx[1] = dst;
+  fill_operand(a, 2, e_in);
+  fill_weights(a, w);
+  a.res_ptr = e_in->ptr;
+  a.res_idx = e_in->index;
+  a.res_rows_pb = e_in->rows_per_batch;
+  a.res_ld = e_in->ld;
+  a.out = e_out;
+  a.out_ld = 256;
+  a.out_cols = 256;
+  a.agg = agg;
+  a.agg_idx = dst;
+  a.agg_rows_pb = n_dst;
+  return launch_chain(chain_kernel<128, true, 3, 8, 8, EPI_EDGE>, a, stream);
+}
+
+int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
+                           const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream) {
+  if (!x || !agg || !w || !x_out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_forward: bad arguments");
+  if (n_rows == 0) return GW_OK;
+  if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: more than 2^31-1 rows");
+  if (w->hidden != 256 || w->n_out != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: only hidden=256, out=256");
+  if (agg->k != 256 || agg->ld % 4 != 0 || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide");
+  if (x->k != 0 && (x->k != 256 || x->ld % 4 != 0 || !w->w1[0])) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide or zeros");
+  if (out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: out_ld must be a multiple of 4");
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = (int)n_rows;
+  a.cols_per_batch = rows_per_batch;
+  fill_operand(a, 0, x);
+  fill_operand(a, 1, agg);
+  fill_weights(a, w);
+  if (x->k != 0) {
+    a.res_ptr = x->ptr;
+    a.res_idx = x->index;
+    a.res_rows_pb = x->rows_per_batch;
+    a.res_ld = x->ld;
+  }
+  a.out = x_out;
+  a.out_ld = out_ld;
+  a.out_cols = 256;
+  return launch_chain(chain_kernel<128, true, 2, 8, 8, EPI_ROWS>, a, stream);
+}
+
+int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,
+                              int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, float* loss_out,
+                              void* stream) {
+  if (!pred || !target || !lat_weights || !loss_out || num_unique_lat <= 0 || batch <= 0 || nodes <= 0 || channels <= 0)
+    return fail(GW_E_BADARG, "gw_normalized_mse_forward: bad arguments");
+  const int num_lon = nodes / num_unique_lat;
+  if (num_lon <= 0 || (nodes + num_lon - 1) / num_lon > num_unique_lat)
+    return fail(GW_E_BADARG, "gw_normalized_mse_forward: nodes must equal num_unique_lat * num_lon");
+  const size_t total = (size_t)batch * nodes * channels;
+  const float scale = 1.0f / ((float)channels * (float)batch * (float)nodes);
+  int grid = (int)((total + 1023) / 1024);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(nmse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, inv_var, lat_weights, num_lon, nodes,
+                     channels, total, scale, loss_out);
+  return check_launch("nmse_kernel launch");
+}
+
+}  // extern "C"

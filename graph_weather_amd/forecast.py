@@ -1,0 +1,138 @@
+"""``GraphWeatherForecaster`` - the drop-in model API of the hot path (reference ``graph_weather/models/forecast.py``).
+
+Same constructor arguments, attributes (``encoder`` / ``processor`` / ``decoder``, ``grid_shape``, ``node_to_grid``),
+``state_dict`` keys and ``forward(features[B, G, feature_dim+aux_dim], t=0) -> [B, G, output_dim]`` contract as
+forecast.py:61-247; the arithmetic runs in the HIP kernels of libgw_amd.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .graphs import build_forecast_graphs
+from .layers import Decoder, Encoder, Processor
+
+try:  # forecast.py:8,61 - hub mixin gives save_pretrained / from_pretrained / push_to_hub
+    from huggingface_hub import PyTorchModelHubMixin
+except Exception:  # pragma: no cover
+    class PyTorchModelHubMixin:  # type: ignore
+        pass
+
+
+@dataclass
+class GraphWeatherForecasterConfig:
+    """forecast.py:14-58."""
+
+    lat_lons: list
+    resolution: int = 2
+    feature_dim: int = 78
+    aux_dim: int = 24
+    output_dim: Optional[int] = None
+    node_dim: int = 256
+    edge_dim: int = 256
+    num_blocks: int = 9
+    hidden_dim_processor_node: int = 256
+    hidden_dim_processor_edge: int = 256
+    hidden_layers_processor_node: int = 2
+    hidden_layers_processor_edge: int = 2
+    hidden_dim_decoder: int = 128
+    hidden_layers_decoder: int = 2
+    norm_type: str = "LayerNorm"
+    use_checkpointing: bool = False
+    constraint_type: str = "none"
+    use_thermalizer: bool = False
+
+    def build(self) -> "GraphWeatherForecaster":
+        return GraphWeatherForecaster(**self.__dict__)
+
+
+class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
+    """forecast.py:61-247 (constraint layer and thermalizer are optional extras outside the hot path)."""
+
+    def __init__(self, lat_lons: list, resolution: int = 2, feature_dim: int = 78, aux_dim: int = 24,
+                 output_dim: Optional[int] = None, node_dim: int = 256, edge_dim: int = 256, num_blocks: int = 9,
+                 hidden_dim_processor_node: int = 256, hidden_dim_processor_edge: int = 256,
+                 hidden_layers_processor_node: int = 2, hidden_layers_processor_edge: int = 2,
+                 hidden_dim_decoder: int = 128, hidden_layers_decoder: int = 2, norm_type: str = "LayerNorm",
+                 use_checkpointing: bool = False, constraint_type: str = "none", use_thermalizer: bool = False):
+        super().__init__()
+        if constraint_type != "none":
+            raise NotImplementedError("PhysicalConstraintLayer (default 'none', forecast.py:82) is outside the hot path")
+        self.feature_dim = feature_dim
+        self.constraint_type = constraint_type
+        self.use_thermalizer = use_thermalizer
+        if output_dim is None:
+            output_dim = self.feature_dim
+        self.output_dim = output_dim
+        lat_lons = [tuple(ll) for ll in lat_lons]
+        unique_lats = sorted(set(lat for lat, _ in lat_lons))
+        unique_lons = sorted(set(lon for _, lon in lat_lons))
+        self.grid_shape = (len(unique_lats), len(unique_lons))
+        self.original_lat_lons = list(lat_lons)
+        self._create_grid_mapping(unique_lats, unique_lons)
+        graphs = build_forecast_graphs(lat_lons, resolution)  # built once, shared by encoder and decoder
+        self.encoder = Encoder(lat_lons=lat_lons, resolution=resolution, input_dim=feature_dim + aux_dim,
+                               output_dim=node_dim, output_edge_dim=edge_dim,
+                               hidden_dim_processor_edge=hidden_dim_processor_edge,
+                               hidden_layers_processor_node=hidden_layers_processor_node,
+                               hidden_dim_processor_node=hidden_dim_processor_node,
+                               hidden_layers_processor_edge=hidden_layers_processor_edge, mlp_norm_type=norm_type,
+                               use_checkpointing=use_checkpointing, _graphs=graphs)
+        self.processor = Processor(input_dim=node_dim, edge_dim=edge_dim, num_blocks=num_blocks,
+                                   hidden_dim_processor_edge=hidden_dim_processor_edge,
+                                   hidden_layers_processor_node=hidden_layers_processor_node,
+                                   hidden_dim_processor_node=hidden_dim_processor_node,
+                                   hidden_layers_processor_edge=hidden_layers_processor_edge, mlp_norm_type=norm_type,
+                                   use_thermalizer=use_thermalizer)
+        self.decoder = Decoder(lat_lons=lat_lons, resolution=resolution, input_dim=node_dim, output_dim=output_dim,
+                               output_edge_dim=edge_dim, hidden_dim_processor_edge=hidden_dim_processor_edge,
+                               hidden_layers_processor_node=hidden_layers_processor_node,
+                               hidden_dim_processor_node=hidden_dim_processor_node,
+                               hidden_layers_processor_edge=hidden_layers_processor_edge, mlp_norm_type=norm_type,
+                               hidden_dim_decoder=hidden_dim_decoder, hidden_layers_decoder=hidden_layers_decoder,
+                               use_checkpointing=use_checkpointing, _graphs=graphs)
+
+    def _create_grid_mapping(self, unique_lats, unique_lons):
+        """forecast.py:178-192 (vectorised; identical (row, col) pairs)."""
+        lo_lat, hi_lat = min(unique_lats), max(unique_lats)
+        lo_lon, hi_lon = min(unique_lons), max(unique_lons)
+        nlat, nlon = len(unique_lats), len(unique_lons)
+        self.node_to_grid = []
+        for lat, lon in self.original_lat_lons:
+            row = int((lat - lo_lat) / (hi_lat - lo_lat) * (nlat - 1)) if hi_lat > lo_lat else 0
+            col = int((lon - lo_lon) / (hi_lon - lo_lon) * (nlon - 1)) if hi_lon > lo_lon else 0
+            self.node_to_grid.append((row, col))
+
+    def graph_to_grid(self, graph_tensor):
+        """forecast.py:194-205: [B, N, C] -> [B, C, H, W]."""
+        batch_size, num_nodes, features = graph_tensor.shape
+        grid = torch.zeros(batch_size, features, *self.grid_shape)
+        for node_idx, (row, col) in enumerate(self.node_to_grid):
+            grid[..., row, col] = graph_tensor[..., node_idx, :]
+        return grid
+
+    def grid_to_graph(self, grid_tensor):
+        """forecast.py:207-213: [B, C, H, W] -> [B, N, C]."""
+        batch_size, features, H, W = grid_tensor.shape
+        graph = torch.zeros(batch_size, H * W, features)
+        for node_idx, (row, col) in enumerate(self.node_to_grid):
+            graph[..., node_idx, :] = grid_tensor[..., row, col]
+        return graph
+
+    def forward(self, features: torch.Tensor, t: int = 0) -> torch.Tensor:
+        """forecast.py:215-247 with constraint_type == "none".  Fused path: data stays in the native layouts
+        (dst-sorted shared graph, cached batch-independent embeddings) between encoder, processor and decoder."""
+        if not features.is_cuda:
+            raise RuntimeError("graph_weather_amd: features must be on a HIP device - there is no CPU path")
+        if features.dtype != torch.float32:
+            raise RuntimeError("graph_weather_amd: features must be float32")
+        features = features.contiguous()
+        B = int(features.shape[0])
+        x = self.encoder.encode(features)
+        _, lat_plan = self.encoder._plans(features.device)
+        e_lat = self.encoder.latent_edge_embedding(lat_plan)
+        x, _ = self.processor.graph_processor.run_plan(x, lat_plan, e_lat, True, B, False)
+        G = self.encoder.num_latlons
+        return self.decoder.decode(x, B, residual=features.reshape(B * G, features.shape[2]))

@@ -1,0 +1,406 @@
+"""Host-side mirror of the reference's module tree for the forecaster hot path.
+
+Same class names, constructor arguments, attribute names and ``state_dict`` keys as
+``graph_weather/models/layers/{graph_net_block,encoder,processor,decoder,assimilator_decoder}.py`` so reference
+checkpoints load with ``strict=True`` - but ``forward`` enqueues the hand-written HIP kernels of
+``libgw_amd.so`` (through ``graph_weather_amd.ops``) instead of ATen / torch_scatter / PyG ops.
+
+Batching uses *shared-graph* semantics everywhere (one edge list for all batch elements; node tables
+``[B, N, D]``): output-equivalent to the reference's replicated graph (its own efficient_batching tests,
+``tests/models/layers/test_efficient_batching.py:53,91,145``) without building B copies of the graph,
+re-encoding the batch-independent edge features B times, or running node MLPs on rows that are then dropped.
+
+Forward only in this round (inference / forecasts-per-second path); tensors must be fp32 on a HIP device.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .graphs import ForecastGraphs, GraphPlan, build_forecast_graphs
+from .ops import Operand, PackedMLP
+
+_NORMS = ["LayerNorm", "GraphNorm", "InstanceNorm", "BatchNorm", "MessageNorm"]
+
+
+def _version_key(params) -> tuple:
+    return tuple((p.data_ptr(), p._version, p.device) for p in params)
+
+
+class MLP(nn.Module):
+    """``MLP`` - graph_net_block.py:17-77.  ``model`` is the same nn.Sequential layout (Linear/ReLU.../[LayerNorm])."""
+
+    def __init__(self, in_dim: int, out_dim: int = 128, hidden_dim: int = 128, hidden_layers: int = 2,
+                 norm_type: Optional[str] = "LayerNorm", use_checkpointing: bool = False):
+        super().__init__()
+        self.use_checkpointing = use_checkpointing  # forward-only kernels save nothing: flag kept for API parity
+        layers: List[nn.Module] = [nn.Linear(in_dim, hidden_dim), nn.ReLU()]
+        for _ in range(hidden_layers - 1):
+            layers += [nn.Linear(hidden_dim, hidden_dim), nn.ReLU()]
+        layers.append(nn.Linear(hidden_dim, out_dim))
+        if norm_type is not None:
+            assert norm_type in _NORMS
+            norm_layer = getattr(nn, norm_type)  # only LayerNorm exists in torch.nn, as in the reference
+            layers.append(norm_layer(out_dim))
+        self.model = nn.Sequential(*layers)
+        self.in_dim, self.out_dim, self.hidden_dim = in_dim, out_dim, hidden_dim
+        self._packed: Optional[PackedMLP] = None
+        self._packed_key = None
+        self._splits: Tuple[Tuple[int, int], ...] = ((0, in_dim),)
+
+    def set_input_splits(self, splits) -> None:
+        """Column slices of layer 1 fed by separate operands (``cat`` order of the reference)."""
+        self._splits = tuple(splits)
+        self._packed = None
+
+    def _linears(self):
+        return [m for m in self.model if isinstance(m, nn.Linear)]
+
+    def packed(self) -> PackedMLP:
+        lin = self._linears()
+        norm = self.model[-1] if isinstance(self.model[-1], nn.LayerNorm) else None
+        params = [p for m in lin for p in (m.weight, m.bias)] + ([norm.weight, norm.bias] if norm is not None else [])
+        key = _version_key(params)
+        if self._packed is None or key != self._packed_key:
+            if not lin[0].weight.is_cuda:
+                raise RuntimeError("graph_weather_amd: module parameters must be on a HIP device (no CPU path exists)")
+            if norm is not None and abs(norm.eps - 1e-5) > 0:
+                raise RuntimeError("graph_weather_amd: LayerNorm eps must be 1e-5")
+            self._packed = PackedMLP([m.weight for m in lin], [m.bias for m in lin],
+                                     (norm.weight, norm.bias) if norm is not None else None, self._splits)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """graph_net_block.py:63-77."""
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        n = int(x2.shape[0])
+        y = ops.mlp_forward(self.packed(), Operand(x2, n, self.in_dim), n, n)
+        return y.reshape(*lead, self.out_dim)
+
+
+class EdgeProcessor(nn.Module):
+    """``EdgeProcessor`` - graph_net_block.py:87-137 (parameter container; arithmetic in gw_edge_update_forward)."""
+
+    def __init__(self, in_dim_node=128, in_dim_edge=128, hidden_dim=128, hidden_layers=2, norm_type="LayerNorm"):
+        super().__init__()
+        self.edge_mlp = MLP(2 * in_dim_node + in_dim_edge, in_dim_edge, hidden_dim, hidden_layers, norm_type)
+        self.edge_mlp.set_input_splits(((0, in_dim_node), (in_dim_node, 2 * in_dim_node),
+                                        (2 * in_dim_node, 2 * in_dim_node + in_dim_edge)))
+
+
+class NodeProcessor(nn.Module):
+    """``NodeProcessor`` - graph_net_block.py:140-193."""
+
+    def __init__(self, in_dim_node=128, in_dim_edge=128, hidden_dim=128, hidden_layers=2, norm_type="LayerNorm"):
+        super().__init__()
+        self.node_mlp = MLP(in_dim_node + in_dim_edge, in_dim_node, hidden_dim, hidden_layers, norm_type)
+        self.node_mlp.set_input_splits(((0, in_dim_node), (in_dim_node, in_dim_node + in_dim_edge)))
+
+
+class GraphNetBlock(nn.Module):
+    """Stands where the reference puts PyG ``MetaLayer`` (graph_net_block.py:221-228): attributes
+    ``edge_model`` / ``node_model`` give the same state_dict keys."""
+
+    def __init__(self, edge_model: EdgeProcessor, node_model: NodeProcessor):
+        super().__init__()
+        self.edge_model = edge_model
+        self.node_model = node_model
+
+    def run(self, batch: int, plan: GraphPlan, x_src: Operand, x_dst: Operand, x_node: Operand, e_in: Operand,
+            want_edges: bool, device, tag: Optional[str] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows."""
+        n_dst, n_edges = plan.n_dst, plan.num_edges
+        agg = torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
+        e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
+        ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src, x_dst, e_in, n_dst,
+                                agg, e_out, tag=tag)
+        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node,
+                                        Operand(agg, n_dst, 256))
+        return x_new, e_out
+
+
+def build_graph_processor_block(in_dim_node=128, in_dim_edge=128, hidden_dim_node=128, hidden_dim_edge=128,
+                                hidden_layers_node=2, hidden_layers_edge=2, norm_type="LayerNorm") -> nn.Module:
+    """graph_net_block.py:196-228."""
+    return GraphNetBlock(
+        edge_model=EdgeProcessor(in_dim_node, in_dim_edge, hidden_dim_edge, hidden_layers_edge, norm_type),
+        node_model=NodeProcessor(in_dim_node, in_dim_edge, hidden_dim_node, hidden_layers_node, norm_type),
+    )
+
+
+def _check_native_dims(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge, norm_type):
+    if not (in_dim_node == in_dim_edge == hidden_dim_node == hidden_dim_edge == 256) or norm_type != "LayerNorm":
+        raise NotImplementedError(
+            "graph_weather_amd: the HIP message-passing kernels are built for node/edge/hidden width 256 with "
+            "LayerNorm (the reference defaults, forecast.py:64-84); other widths are not implemented yet")
+
+
+class GraphProcessor(nn.Module):
+    """``GraphProcessor`` - graph_net_block.py:231-301."""
+
+    def __init__(self, mp_iterations=15, in_dim_node=128, in_dim_edge=128, hidden_dim_node=128, hidden_dim_edge=128,
+                 hidden_layers_node=2, hidden_layers_edge=2, norm_type="LayerNorm", use_checkpointing=False):
+        super().__init__()
+        self.use_checkpointing = use_checkpointing
+        self._dims = (in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge, norm_type)
+        self.blocks = nn.ModuleList()
+        for _ in range(mp_iterations):
+            self.blocks.append(build_graph_processor_block(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge,
+                                                           hidden_layers_node, hidden_layers_edge, norm_type))
+        self._plan_cache = None
+
+    # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
+    def run_plan(self, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: bool, batch: int,
+                 want_edges: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        _check_native_dims(*self._dims)
+        n, n_edges = plan.n_dst, plan.num_edges
+        e_cur, shared = e, e_shared
+        for i, blk in enumerate(self.blocks):
+            last = i == len(self.blocks) - 1
+            xop = Operand(x, n, 256)
+            x, e_new = blk.run(batch, plan, xop, xop, xop, Operand(e_cur, 0 if shared else n_edges, 256),
+                               want_edges or not last, x.device, tag="processor_edge")
+            if e_new is not None:
+                e_cur, shared = e_new, False
+        return x, (e_cur if want_edges else None)
+
+    def _plan_for(self, edge_index: torch.Tensor, num_nodes: int) -> GraphPlan:
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, num_nodes)
+        if self._plan_cache is not None and self._plan_cache[0] == key:
+            return self._plan_cache[1]
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise RuntimeError("edge_index must be [2, E] in COO format")
+        if edge_index.numel() and (int(edge_index.min()) < 0 or int(edge_index.max()) >= num_nodes):
+            raise IndexError("edge_index refers to nodes outside x")
+        dst_sorted, perm = torch.sort(edge_index[1], stable=True)
+        plan = GraphPlan(num_nodes, num_nodes, edge_index[0][perm].to(torch.int32).contiguous(),
+                         dst_sorted.to(torch.int32).contiguous(), perm, None)
+        self._plan_cache = (key, plan)
+        return plan
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """graph_net_block.py:279-301 for an arbitrary COO graph (the reference's random-graph test,
+        tests/models/test_gradient_checkpointing.py:62-86): edges are dst-sorted once per edge_index tensor."""
+        plan = self._plan_for(edge_index, int(x.shape[0]))
+        e_sorted = edge_attr.contiguous()[plan.perm].contiguous()
+        x_out, e_out = self.run_plan(x.contiguous(), plan, e_sorted, False, 1, True)
+        e_ref = torch.empty_like(e_out)
+        e_ref[plan.perm] = e_out
+        return x_out, e_ref
+
+
+class Encoder(nn.Module):
+    """``Encoder`` - encoder.py:36-268."""
+
+    def __init__(self, lat_lons: list, resolution: int = 2, input_dim: int = 78, output_dim: int = 256,
+                 output_edge_dim: int = 256, hidden_dim_processor_node=256, hidden_dim_processor_edge=256,
+                 hidden_layers_processor_node=2, hidden_layers_processor_edge=2, mlp_norm_type="LayerNorm",
+                 use_checkpointing: bool = False, efficient_batching: bool = False,
+                 _graphs: Optional[ForecastGraphs] = None):
+        super().__init__()
+        self.use_checkpointing = use_checkpointing
+        self.efficient_batching = efficient_batching
+        self.output_dim = output_dim
+        self.num_latlons = len(lat_lons)
+        self.graphs = _graphs if _graphs is not None else build_forecast_graphs(lat_lons, resolution)
+        self.num_h3 = self.graphs.num_mesh
+        # encoder.py:112-114 - zero-initialised learnable mesh-node inputs
+        self.h3_nodes = nn.Parameter(torch.zeros((self.num_h3, input_dim), dtype=torch.float))
+        self.node_encoder = MLP(input_dim, output_dim, hidden_dim_processor_node, hidden_layers_processor_node,
+                                mlp_norm_type, use_checkpointing)
+        self.edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, hidden_layers_processor_edge,
+                                mlp_norm_type, use_checkpointing)
+        self.latent_edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, hidden_layers_processor_edge,
+                                       mlp_norm_type, use_checkpointing)
+        self.graph_processor = GraphProcessor(1, output_dim, output_edge_dim, hidden_dim_processor_node,
+                                              hidden_dim_processor_edge, hidden_layers_processor_node,
+                                              hidden_layers_processor_edge, mlp_norm_type, use_checkpointing)
+        self._dev_plans = {}
+        self._cache = {}
+
+    # plans live outside state_dict (like encoder.graph / encoder.latent_graph, encoder.py:107,109)
+    def _plans(self, device):
+        key = str(device)
+        if key not in self._dev_plans:
+            self._dev_plans[key] = (self.graphs.enc_plan.to(device), self.graphs.lat_plan.to(device))
+        return self._dev_plans[key]
+
+    def _cached(self, name: str, params, fn):
+        key = _version_key(params)
+        hit = self._cache.get(name)
+        if hit is None or hit[0] != key:
+            self._cache[name] = (key, fn())
+        return self._cache[name][1]
+
+    def mesh_embedding(self) -> torch.Tensor:
+        """node_encoder(h3_nodes): batch independent (encoder.py:199-205 recomputes it for every sample)."""
+        ps = list(self.node_encoder.parameters()) + [self.h3_nodes]
+        return self._cached("mesh", ps, lambda: self.node_encoder(self.h3_nodes.detach()))
+
+    def encoder_edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
+        return self._cached("enc_e", list(self.edge_encoder.parameters()), lambda: self.edge_encoder(plan.edge_attr))
+
+    def latent_edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
+        """latent_edge_encoder(attr) once on [E_lat, 2] in dst-sorted order (encoder.py:235-241 repeats B times)."""
+        return self._cached("lat_e", list(self.latent_edge_encoder.parameters()),
+                            lambda: self.latent_edge_encoder(plan.edge_attr))
+
+    def encode(self, features: torch.Tensor) -> torch.Tensor:
+        """encoder.py:199-223 -> mesh node features [(B*M), D] (batch-major, reversed-rank mesh order)."""
+        if features.dim() != 3 or features.shape[1] != self.num_latlons:
+            raise RuntimeError("features must be [B, %d, input_dim]" % self.num_latlons)
+        B, G, F = (int(s) for s in features.shape)
+        feats = features.contiguous().reshape(B * G, F)
+        enc_plan, _ = self._plans(features.device)
+        pm = self.node_encoder.packed()
+        xg = ops.mlp_forward(pm, Operand(feats, G, F), B * G, G)  # grid rows only
+        xm = self.mesh_embedding()
+        e = self.encoder_edge_embedding(enc_plan)
+        blk = self.graph_processor.blocks[0]
+        _check_native_dims(*self.graph_processor._dims)
+        xm_op = Operand(xm, 0, 256)
+        x, _ = blk.run(B, enc_plan, Operand(xg, G, 256), xm_op, xm_op, Operand(e, 0, 256), False, features.device,
+                       tag="encoder_edge")
+        return x
+
+    def forward(self, features: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """encoder.py:153-242.  Returns reference-order tensors: replicated graph by default, the single shared
+        graph with ``efficient_batching`` (encoder.py:190-196)."""
+        B = int(features.shape[0])
+        x = self.encode(features)
+        _, lat_plan = self._plans(features.device)
+        e_sorted = self.latent_edge_embedding(lat_plan)
+        e_ref = torch.empty_like(e_sorted)
+        e_ref[lat_plan.perm] = e_sorted
+        ei = self.graphs.lat_edge_index.to(features.device)
+        if self.efficient_batching:
+            return x, ei, e_ref
+        M = self.num_h3
+        ei_rep = torch.cat([ei + i * M for i in range(B)], dim=1)  # max(edge_index)+1 == M (self loops), encoder.py:229
+        return x, ei_rep, e_ref.repeat(B, 1)
+
+
+class Processor(nn.Module):
+    """``Processor`` - processor.py:17-128 (thermalizer not part of the hot path)."""
+
+    def __init__(self, input_dim: int = 256, edge_dim: int = 256, num_blocks: int = 9, hidden_dim_processor_node: int = 256,
+                 hidden_dim_processor_edge: int = 256, hidden_layers_processor_node: int = 2,
+                 hidden_layers_processor_edge: int = 2, mlp_norm_type: str = "LayerNorm", use_thermalizer: bool = False,
+                 use_checkpointing: bool = False):
+        super().__init__()
+        if use_thermalizer:
+            raise NotImplementedError("the thermalizer (reference default off, forecast.py:83) is outside the hot path")
+        self.input_dim = input_dim
+        self.use_thermalizer = use_thermalizer
+        self.checkpoint_segments = 0
+        self.graph_processor = GraphProcessor(num_blocks, input_dim, edge_dim, hidden_dim_processor_node,
+                                              hidden_dim_processor_edge, hidden_layers_processor_node,
+                                              hidden_layers_processor_edge, mlp_norm_type, use_checkpointing)
+
+    def set_checkpoint_segments(self, checkpoint_segments: int):
+        """processor.py:70-81 (forward-only kernels keep no activations; value is recorded for API parity)."""
+        self.checkpoint_segments = checkpoint_segments
+
+    def forward(self, x: torch.Tensor, edge_index, edge_attr, t: int = 0, batch_size: int = None,
+                efficient_batching: bool = False) -> torch.Tensor:
+        """processor.py:83-128."""
+        if efficient_batching and batch_size is not None and batch_size > 1:
+            n = int(x.shape[0]) // batch_size
+            plan = self.graph_processor._plan_for(edge_index, n)
+            e_sorted = edge_attr.contiguous()[plan.perm].contiguous()
+            out, _ = self.graph_processor.run_plan(x.contiguous(), plan, e_sorted, True, batch_size, False)
+            return out
+        plan = self.graph_processor._plan_for(edge_index, int(x.shape[0]))
+        e_sorted = edge_attr.contiguous()[plan.perm].contiguous()
+        out, _ = self.graph_processor.run_plan(x.contiguous(), plan, e_sorted, False, 1, False)
+        return out
+
+
+class AssimilatorDecoder(nn.Module):
+    """``AssimilatorDecoder`` - assimilator_decoder.py:26-200."""
+
+    def __init__(self, lat_lons: list, resolution: int = 2, input_dim: int = 256, output_dim: int = 78,
+                 output_edge_dim: int = 256, hidden_dim_processor_node: int = 256, hidden_dim_processor_edge: int = 256,
+                 hidden_layers_processor_node: int = 2, hidden_layers_processor_edge: int = 2,
+                 mlp_norm_type: str = "LayerNorm", hidden_dim_decoder: int = 128, hidden_layers_decoder: int = 2,
+                 use_checkpointing: bool = False, efficient_batching: bool = False,
+                 _graphs: Optional[ForecastGraphs] = None):
+        super().__init__()
+        self.use_checkpointing = use_checkpointing
+        self.efficient_batching = efficient_batching
+        self.num_latlons = len(lat_lons)
+        self.graphs = _graphs if _graphs is not None else build_forecast_graphs(lat_lons, resolution)
+        self.num_h3 = self.graphs.num_mesh
+        self.output_dim = output_dim
+        # assimilator_decoder.py:108-110: hidden_layers of the edge encoder is the literal 2
+        self.edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, 2, mlp_norm_type, use_checkpointing)
+        self.graph_processor = GraphProcessor(mp_iterations=1, in_dim_node=input_dim, in_dim_edge=output_edge_dim,
+                                              hidden_dim_node=hidden_dim_processor_node,
+                                              hidden_dim_edge=hidden_dim_processor_edge,
+                                              hidden_layers_node=hidden_layers_processor_node,
+                                              hidden_layers_edge=hidden_layers_processor_edge, norm_type=mlp_norm_type,
+                                              use_checkpointing=use_checkpointing)
+        self.node_decoder = MLP(input_dim, output_dim, hidden_dim_decoder, hidden_layers_decoder, None, use_checkpointing)
+        self._dev_plans = {}
+        self._cache = {}
+
+    def _plan(self, device) -> GraphPlan:
+        key = str(device)
+        if key not in self._dev_plans:
+            self._dev_plans[key] = self.graphs.dec_plan.to(device)
+        return self._dev_plans[key]
+
+    def edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
+        key = _version_key(list(self.edge_encoder.parameters()))
+        hit = self._cache.get("dec_e")
+        if hit is None or hit[0] != key:
+            self._cache["dec_e"] = (key, self.edge_encoder(plan.edge_attr))
+        return self._cache["dec_e"][1]
+
+    def decode(self, processor_features: torch.Tensor, batch_size: int,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """assimilator_decoder.py:173-200 (+ decoder.py:93 when ``residual`` [B*G, ld] is given)."""
+        B, G, M = batch_size, self.num_latlons, self.num_h3
+        if processor_features.shape[0] != B * M:
+            raise RuntimeError("processor_features must have batch*num_h3 rows")
+        dev = processor_features.device
+        plan = self._plan(dev)
+        e = self.edge_embedding(plan)
+        blk = self.graph_processor.blocks[0]
+        _check_native_dims(*self.graph_processor._dims)
+        # lat/lon rows are zeros (assimilator_decoder.py:84,190-192): x_dst = 0, node input [0 | agg], residual 0
+        xg, _ = blk.run(B, plan, Operand(processor_features.contiguous(), M, 256), ops.ZERO, ops.ZERO, Operand(e, 0, 256),
+                        False, dev, tag="decoder_edge")
+        res = None
+        if residual is not None:
+            res = Operand(residual, G, self.output_dim)
+        y = ops.mlp_forward(self.node_decoder.packed(), Operand(xg, G, 256), B * G, G, residual=res)
+        return y.reshape(B, G, self.output_dim)
+
+    def forward(self, processor_features: torch.Tensor, batch_size: int) -> torch.Tensor:
+        return self.decode(processor_features, batch_size)
+
+
+class Decoder(AssimilatorDecoder):
+    """``Decoder`` - decoder.py:22-94."""
+
+    def forward(self, processor_features: torch.Tensor, start_features: torch.Tensor, t: int = 0) -> torch.Tensor:
+        B = int(start_features.shape[0])
+        sf = start_features
+        if sf.dim() != 3 or sf.shape[1] != self.num_latlons or sf.shape[2] != self.output_dim:
+            raise RuntimeError("start_features must be [B, %d, %d]" % (self.num_latlons, self.output_dim))
+        # fused residual: read start_features in place when it is a leading-channel view of a contiguous tensor
+        base = None
+        if sf.stride(2) == 1 and sf.stride(0) == sf.shape[1] * sf.stride(1) and sf.stride(1) >= sf.shape[2]:
+            try:
+                base = torch.as_strided(sf, (B * sf.shape[1], sf.stride(1)), (sf.stride(1), 1))
+            except RuntimeError:
+                base = None
+        if base is None:
+            base = sf.contiguous().reshape(B * sf.shape[1], sf.shape[2])
+        return self.decode(processor_features, B, residual=base)

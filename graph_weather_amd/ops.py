@@ -1,0 +1,207 @@
+"""Tensor-level wrappers over the C ABI (``include/gw_amd.h``).  PyTorch is used only to own device memory
+and to name the current HIP stream; every arithmetic operation of the hot path happens inside libgw_amd.so."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GwMlpWeights, GwOperand
+
+
+class KernelTimer:
+    """Optional HIP-event bracket around tagged C-ABI calls (used by bench.py for the live roofline figure).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self, tags):
+        self.tags = set(tags)
+        self.events = {t: [] for t in self.tags}
+
+    def start(self, tag):
+        if tag not in self.tags:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def stop(self, tag, ev):
+        if ev is not None:
+            ev[1].record()
+            self.events[tag].append(ev)
+
+    def mean_ms(self, tag) -> float:
+        evs = self.events[tag]
+        return sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError(f"graph_weather_amd: {name} must live on a HIP device (no CPU path exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"graph_weather_amd: {name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"graph_weather_amd: {name} must be contiguous")
+
+
+@dataclass
+class Operand:
+    """A row table feeding an MLP input slice.  ``tensor`` is [rows, ld]; ``rows_per_batch`` = 0 means the table
+    is shared by all batch elements; ``index`` (int32) maps a column to a row within its batch element."""
+
+    tensor: Optional[torch.Tensor]
+    rows_per_batch: int
+    k: int
+    index: Optional[torch.Tensor] = None
+
+    def c(self) -> GwOperand:
+        if self.k == 0 or self.tensor is None:
+            return GwOperand(None, None, 0, 0, 0)
+        _require(self.tensor, "operand")
+        if self.index is not None:
+            _require(self.index, "operand index", torch.int32)
+        return GwOperand(self.tensor.data_ptr(), None if self.index is None else self.index.data_ptr(),
+                         int(self.rows_per_batch), int(self.tensor.stride(0)), int(self.k))
+
+
+ZERO = Operand(None, 0, 0)
+
+
+class PackedMLP:
+    """Device-resident packed form of one reference ``MLP`` (graph_net_block.py:45-61)."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+                 ln: Optional[Tuple[torch.Tensor, torch.Tensor]], splits: Sequence[Tuple[int, int]]):
+        L = _lib.lib()
+        n_lin = len(weights)
+        if n_lin < 2:
+            raise RuntimeError("graph_weather_amd: MLP needs at least one hidden layer")
+        dev = weights[0].device
+        self.hidden = int(weights[0].shape[0])
+        self.n_out = int(weights[-1].shape[0])
+        self.n_mid = n_lin - 2
+        self.in_dim = int(weights[0].shape[1])
+        for w in weights[1:-1]:
+            if tuple(w.shape) != (self.hidden, self.hidden):
+                raise RuntimeError("graph_weather_amd: hidden layers must be square")
+        st = torch.cuda.current_stream(dev).cuda_stream
+
+        def pack(w, k_lo, k_hi):
+            w = w.detach().contiguous().float()
+            n = L.gw_packed_floats(int(w.shape[0]), k_lo, k_hi)
+            out = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(L.gw_pack_linear(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), k_lo, k_hi, out.data_ptr(), st),
+                       "gw_pack_linear")
+            return out
+
+        def pad(v):
+            v = v.detach().contiguous().float()
+            out = torch.empty(L.gw_padded_n(int(v.shape[0])), dtype=torch.float32, device=dev)
+            _lib.check(L.gw_pad_vector(v.data_ptr(), int(v.shape[0]), out.data_ptr(), st), "gw_pad_vector")
+            return out
+
+        self.w1 = [pack(weights[0], lo, hi) for lo, hi in splits]
+        self.b1 = pad(biases[0])
+        if self.n_mid:
+            self.w_mid = torch.cat([pack(w, 0, self.hidden) for w in weights[1:-1]])
+            self.b_mid = torch.cat([pad(b) for b in biases[1:-1]])
+        else:
+            self.w_mid = self.b_mid = None
+        self.w_out = pack(weights[-1], 0, self.hidden)
+        self.b_out = pad(biases[-1])
+        self.gamma = pad(ln[0]) if ln is not None else None
+        self.beta = pad(ln[1]) if ln is not None else None
+
+    def c(self, active: Sequence[bool] = (True, True, True)) -> GwMlpWeights:
+        w = GwMlpWeights()
+        for i in range(3):
+            w.w1[i] = self.w1[i].data_ptr() if i < len(self.w1) and active[i] else None
+        w.b1 = self.b1.data_ptr()
+        w.w_mid = self.w_mid.data_ptr() if self.w_mid is not None else None
+        w.b_mid = self.b_mid.data_ptr() if self.b_mid is not None else None
+        w.w_out = self.w_out.data_ptr()
+        w.b_out = self.b_out.data_ptr()
+        w.ln_gamma = self.gamma.data_ptr() if self.gamma is not None else None
+        w.ln_beta = self.beta.data_ptr() if self.beta is not None else None
+        w.hidden, w.n_mid, w.n_out = self.hidden, self.n_mid, self.n_out
+        return w
+
+
+def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, residual: Optional[Operand] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """graph_net_block.py:63-77 on ``n_rows`` rows (+ optional residual add)."""
+    dev = x.tensor.device
+    if out is None:
+        out = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=dev)
+    _require(out, "out")
+    xc = x.c()
+    wc = pm.c()
+    rc = residual.c() if residual is not None else None
+    if rc is not None:
+        rc.k = pm.n_out
+    _lib.check(_lib.lib().gw_mlp_forward(n_rows, max(1, rows_per_batch), xc, wc, rc, out.data_ptr(), int(out.stride(0)),
+                                         _stream(out)), "gw_mlp_forward")
+    return out
+
+
+def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
+                        e_in: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
+                        tag: Optional[str] = None) -> None:
+    """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed."""
+    _require(src, "src", torch.int32)
+    _require(dst, "dst", torch.int32)
+    _require(agg, "agg")
+    if e_out is not None:
+        _require(e_out, "e_out")
+    n_edges = int(src.shape[0])
+    wc = pm.c((x_src.k > 0, x_dst.k > 0, e_in.k > 0))
+    ev = TIMER.start(tag) if TIMER is not None else None
+    _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), x_src.c(), x_dst.c(), e_in.c(),
+                                                 wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(), n_dst,
+                                                 _stream(agg)), "gw_edge_update_forward")
+    if ev is not None:
+        TIMER.stop(tag, ev)
+
+
+def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, agg: Operand,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """graph_net_block.py:189-191 (NodeProcessor after aggregation)."""
+    dev = agg.tensor.device
+    if out is None:
+        out = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=dev)
+    _require(out, "out")
+    wc = pm.c((x.k > 0, True, False))
+    _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), agg.c(), wc, out.data_ptr(), int(out.stride(0)),
+                                                 _stream(out)), "gw_node_update_forward")
+    return out
+
+
+def normalized_mse_forward(pred: torch.Tensor, target: torch.Tensor, lat_weights: torch.Tensor,
+                           inv_var: Optional[torch.Tensor]) -> torch.Tensor:
+    """losses.py:66-94."""
+    _require(pred, "pred")
+    _require(target, "target")
+    _require(lat_weights, "lat_weights")
+    if pred.shape != target.shape or pred.dim() < 3:
+        raise RuntimeError("graph_weather_amd: pred/target must both be [B, nodes..., C]")
+    b = int(pred.shape[0])
+    c = int(pred.shape[-1])
+    nodes = pred.numel() // (b * c)
+    if inv_var is not None:
+        _require(inv_var, "inv_var")
+        if inv_var.numel() != c:
+            raise RuntimeError("graph_weather_amd: feature_variance must have one entry per channel")
+    loss = torch.zeros((), dtype=torch.float32, device=pred.device)
+    _lib.check(_lib.lib().gw_normalized_mse_forward(pred.data_ptr(), target.data_ptr(),
+                                                    None if inv_var is None else inv_var.data_ptr(), lat_weights.data_ptr(),
+                                                    int(lat_weights.numel()), b, nodes, c, loss.data_ptr(), _stream(pred)),
+               "gw_normalized_mse_forward")
+    return loss

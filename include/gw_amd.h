@@ -1,0 +1,109 @@
+/*
+ * gw_amd.h - C ABI of libgw_amd.so: the MI355X (gfx950) implementation of the message-passing hot path of
+ * openclimatefix/graph_weather's GraphWeatherForecaster.
+ *
+ * The reference has no FFI: its boundary is the Python nn.Module API.  Each entry point below names the
+ * reference statements it replaces (paths relative to the reference tree).  All functions
+ *   - take plain device pointers + sizes + a hipStream_t passed as void* (no torch types),
+ *   - never allocate, free or synchronise; they enqueue kernels on `stream` and return,
+ *   - return 0 on success, a negative GW_E_* code otherwise (message via gw_last_error()).
+ *
+ * Data layout: activations row-major fp32 [rows, ld]; "tables" are [batch, rows_per_batch, ld] stacked along
+ * rows (rows_per_batch == 0 means the table is shared by every batch element).  Edge lists are destination-
+ * sorted int32 arrays shared by all batch elements ("shared graph" semantics, the reference's own
+ * efficient_batching equivalence: tests/models/layers/test_efficient_batching.py:145).
+ *
+ * Weights are consumed in a packed MFMA-operand order produced by gw_pack_linear() from the reference's
+ * nn.Linear layout ([out_features, in_features] row-major).
+ */
+#ifndef GW_AMD_H
+#define GW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GW_OK 0
+#define GW_E_BADARG (-1)
+#define GW_E_UNSUPPORTED (-2)
+#define GW_E_LAUNCH (-3)
+
+#define GW_ABI_VERSION 1
+
+/* Library / ABI version and last error text (thread local). */
+int gw_version(void);
+const char* gw_last_error(void);
+
+/* ---- weight packing ------------------------------------------------------------------------------------
+ * Packed size in floats of the [k_lo, k_hi) column slice of an nn.Linear weight with `n_out` rows, padded to
+ * 32-row tiles / 8-column groups (graph_net_block.py:45-49 creates the Linear layers being packed). */
+size_t gw_packed_floats(int n_out, int k_lo, int k_hi);
+/* w: device pointer to [n_out, k_total] fp32 (nn.Linear.weight); out: gw_packed_floats() floats. */
+int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, float* out, void* stream);
+/* Zero-pad a vector (bias / LayerNorm gamma, beta) to a multiple of 32 floats. out has gw_padded_n(n). */
+int gw_padded_n(int n);
+int gw_pad_vector(const float* v, int n, float* out, void* stream);
+
+/* One input operand of a fused MLP ("segment" of the concatenated input). */
+typedef struct gw_operand {
+  const float* ptr;     /* table base                                                          */
+  const int32_t* index; /* per-column row index within a batch element, NULL = identity         */
+  int32_t rows_per_batch; /* rows of the table per batch element, 0 = table shared by the batch */
+  int32_t ld;           /* row stride in floats                                                 */
+  int32_t k;            /* valid input features taken from each row (0 = operand is all zeros:  */
+                        /* its weight slice is skipped, exact since 0*W == 0)                    */
+} gw_operand;
+
+/* A 3+ layer MLP in packed form: Linear(k_in,h) ReLU [Linear(h,h) ReLU]*n_mid Linear(h,n_out) [LayerNorm]. */
+typedef struct gw_mlp_weights {
+  const float* w1[3];  /* packed slices of layer-1 weight, one per operand (NULL if operand k == 0) */
+  const float* b1;     /* padded bias [h]                                                           */
+  const float* w_mid;  /* n_mid packed [h,h] matrices, contiguous                                   */
+  const float* b_mid;  /* n_mid padded biases                                                       */
+  const float* w_out;  /* packed [n_out, h]                                                         */
+  const float* b_out;  /* padded bias                                                               */
+  const float* ln_gamma; /* padded, NULL = no LayerNorm (eps = 1e-5, biased variance)               */
+  const float* ln_beta;
+  int32_t hidden;      /* 128 or 256 */
+  int32_t n_mid;       /* hidden_layers - 1 */
+  int32_t n_out;       /* 256, or <= 96 for the decoder head */
+} gw_mlp_weights;
+
+/* ---- MLP.forward (graph_net_block.py:63-77) applied to rows --------------------------------------------
+ * y[c, :] = MLP(x[c, :k]) (+ residual[c, :n_out]);   c in [0, n_rows).
+ * Used for Encoder.node_encoder (encoder.py:205), the three edge encoders (encoder.py:206-208,235-241,
+ * assimilator_decoder.py:175-177) and AssimilatorDecoder.node_decoder + the Decoder residual
+ * (assimilator_decoder.py:197, decoder.py:93).  Supported k: <= 8, <= 104, or exactly 256. */
+int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
+                   const gw_operand* residual /* may be NULL */, float* out, int32_t out_ld, void* stream);
+
+/* ---- EdgeProcessor.forward + scatter_sum (graph_net_block.py:131-137 and :188) --------------------------
+ * For every batch element b and edge e (dst-sorted):
+ *   e_new = LN(MLP(cat[x_src[b, src[e]], x_dst[b, dst[e]], e_in[b, e]])) + e_in[b, e]
+ *   agg[b, dst[e], :] += e_new                         (agg must be zero-filled by the caller)
+ * and, if e_out != NULL, e_out[b, e, :] = e_new.  Feature width is 256. */
+int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
+                           const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
+                           const gw_mlp_weights* w, float* e_out /* [batch*n_edges,256] or NULL */,
+                           float* agg /* [batch*n_dst,256] */, int32_t n_dst, void* stream);
+
+/* ---- NodeProcessor.forward after aggregation (graph_net_block.py:189-191) -------------------------------
+ *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x[b, j]
+ * x->k == 0 states that the node rows are zeros (the decoder's lat/lon rows, assimilator_decoder.py:84,190):
+ * the x-slice of layer 1 and the residual are skipped. */
+int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
+                           const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream);
+
+/* ---- NormalizedMSELoss.forward (losses.py:66-94, normalize on/off) ---------------------------------------
+ * loss = mean_{b,n}( w_lat[n / num_lon] * mean_c( (pred-target)^2 [/ var_c] ) ); *loss_out must be zeroed. */
+int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var /* NULL or [c] */,
+                              const float* lat_weights, int32_t num_unique_lat, int32_t batch, int32_t nodes,
+                              int32_t channels, float* loss_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GW_AMD_H */

@@ -1,0 +1,59 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/gw_amd.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from graph_weather_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "gw_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    path = _lib.build_library()
+    assert os.path.exists(path)
+    cdll = ctypes.CDLL(path)
+    declared = _declared_functions()
+    assert set(declared) == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(cdll, name), name
+    L = _lib.lib()
+    assert L.gw_version() == 1
+    assert L.gw_packed_floats(256, 0, 256) == 256 * 256
+    assert L.gw_packed_floats(78, 0, 128) == 64 * 1 * 256
+    assert L.gw_packed_floats(256, 0, 102) == 52 * 2 * 256
+    assert L.gw_padded_n(78) == 96
+
+
+def test_argument_validation_without_gpu():
+    L = _lib.lib()
+    assert L.gw_pack_linear(None, 256, 256, 0, 256, None, None) == -1
+    assert b"bad arguments" in L.gw_last_error()
+    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, 1, None) == -1
+
+
+def test_product_has_no_cpu_path():
+    import graph_weather_amd as gw
+    from graph_weather_amd.utils import regular_lat_lons
+
+    model = gw.GraphWeatherForecaster(regular_lat_lons(30.0))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(torch.zeros(1, 72, 102))
+    with pytest.raises(RuntimeError):
+        gw.MLP(8, 256, 256)(torch.zeros(4, 8))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "graph_weather_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
