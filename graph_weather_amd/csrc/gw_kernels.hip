@@ -567,9 +567,9 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst, void* stream) {
-  if (!src || !dst || !x_src || !x_dst || !e_in || !w || !agg || batch <= 0 || n_edges < 0 || n_dst <= 0)
-    return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
-  if (n_edges == 0) return GW_OK;
+  if (batch <= 0 || n_edges < 0 || n_dst <= 0) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
+  if (n_edges == 0) return GW_OK;  // nothing to add: agg stays as the caller zeroed it
+  if (!src || !dst || !x_src || !x_dst || !e_in || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if ((int64_t)batch * n_edges >= (int64_t)1 << 31 || (int64_t)batch * n_dst >= (int64_t)1 << 31)
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: batch*edges exceeds int32");
   if (w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || !w->ln_beta)

@@ -18,9 +18,10 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 timeout 600 python bench.py --steps ${BENCH_STEPS:-20} --warmup 3 > $OUT/bench.log 2>&1; echo "bench rc=$?" >> $OUT/bench.log; tail -n 3 $OUT/bench.log
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   rm -rf /tmp/prof && mkdir -p /tmp/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o gw -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_run.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_run.log 2>&1)
   echo "rocprof rc=$?" >> $OUT/rocprof_run.log
-  find /tmp/prof -name "*stats*" -exec cp {} $OUT/ \; 2>/dev/null
+  find /tmp/prof -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null
+  find /tmp/prof -name "*kernel_trace.csv" -exec cp {} $OUT/ \; 2>/dev/null
   find /tmp/prof -name "*kernel_stats*" | head -1 | xargs -r head -n 20
 fi
 ls -la $OUT
