@@ -17,12 +17,14 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_packed_floats", "gw_pack_linear", "gw_padded_n", "gw_pad_vector",
-    "gw_mlp_forward", "gw_edge_update_forward", "gw_node_update_forward", "gw_normalized_mse_forward",
+    "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_node_update_forward",
+    "gw_normalized_mse_forward",
 ]
 
 
 class GwOperand(Structure):
-    _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("rows_per_batch", c_int32), ("ld", c_int32), ("k", c_int32)]
+    _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("rows_per_batch", c_int32), ("ld", c_int32), ("k", c_int32),
+                ("projected", c_int32)]
 
 
 class GwMlpWeights(Structure):
@@ -72,10 +74,14 @@ def lib():
                                  c_void_p, c_int32, c_void_p]
     L.gw_edge_update_forward.restype = c_int
     L.gw_edge_update_forward.argtypes = [c_int32, c_int32, c_void_p, c_void_p, POINTER(GwOperand), POINTER(GwOperand),
-                                         POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_void_p, c_int32, c_void_p]
+                                         POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_void_p,
+                                         c_int32, c_void_p]
     L.gw_node_update_forward.restype = c_int
-    L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights),
-                                         c_void_p, c_int32, c_void_p]
+    L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
+                                         POINTER(GwMlpWeights), c_void_p, c_int32, c_void_p]
+    L.gw_project_forward.restype = c_int
+    L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
+                                     c_int32, c_void_p]
     L.gw_normalized_mse_forward.restype = c_int
     L.gw_normalized_mse_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                             c_void_p, c_void_p]

@@ -44,6 +44,10 @@ struct ChainArgs {
   int seg_rows_pb[3];
   int seg_ld[3];
   int seg_k[3];
+  int seg_proj[3];     // operand is already multiplied by its layer-1 weight slice: rows are [hidden] wide
+  // single-layer projection mode: blockIdx.y selects the weight slice / output table
+  const float* proj_w[4];
+  float* proj_out[4];
   // weights
   const float* w1[3];
   const float* b1;
@@ -166,6 +170,13 @@ __device__ __forceinline__ void mma_pass(f32x16 (&acc)[NT], float (&in)[NSTEPS],
 
 template <int NT>
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* __restrict__ bias, int h) {
+  if (bias == nullptr) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -175,6 +186,21 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* __rest
       acc[t][4 * g + 1] = v.y;
       acc[t][4 * g + 2] = v.z;
       acc[t][4 * g + 3] = v.w;
+    }
+}
+
+// acc += P[row] for an operand that is already projected through its layer-1 weight slice (accumulator layout)
+template <int NT>
+__device__ __forceinline__ void add_projected(f32x16 (&acc)[NT], const float* __restrict__ row, int h) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = ldg4(row + 32 * t + 8 * g + 4 * h);
+      acc[t][4 * g + 0] += v.x;
+      acc[t][4 * g + 1] += v.y;
+      acc[t][4 * g + 2] += v.z;
+      acc[t][4 * g + 3] += v.w;
     }
 }
 
@@ -212,7 +238,7 @@ __device__ __forceinline__ const float* operand_row(const float* ptr, const int*
   return ptr + ((size_t)b * (size_t)rows_pb + (size_t)r) * (size_t)ld;
 }
 
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI>
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE = false>
 __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HS = HT * 16;                  // K-steps of a hidden layer
@@ -229,71 +255,86 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
   const int k = c - b * a.cols_per_batch;
 
   // ---- weight-stream schedule (wave uniform) ----
-  bool on[3];
+  // on[i]: operand i takes part in an MFMA pass (raw rows);  prj[i]: operand i is pre-projected (gather-add only)
+  bool on[3], prj[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) on[i] = (i < NSEG) && (a.seg_k[i] > 0);
-  const float* after_l1 = a.n_mid > 0 ? a.w_mid : a.w_out;
-  const int after_l1_floats = a.n_mid > 0 ? kChunkSteps * HSTEPF : kChunkSteps * OSTEPF;
+  for (int i = 0; i < 3; ++i) {
+    on[i] = (i < NSEG) && (a.seg_k[i] > 0) && (a.seg_proj[i] == 0);
+    prj[i] = (i < NSEG) && (a.seg_k[i] > 0) && (a.seg_proj[i] != 0);
+  }
+  const float* w1[3] = {a.w1[0], a.w1[1], a.w1[2]};
+  if (SINGLE) w1[0] = a.proj_w[blockIdx.y];
+  const float* after_l1 = SINGLE ? nullptr : (a.n_mid > 0 ? a.w_mid : a.w_out);
+  const int after_l1_floats = SINGLE ? 0 : (a.n_mid > 0 ? kChunkSteps * HSTEPF : kChunkSteps * OSTEPF);
   constexpr int K1FIRST = (K1S < kChunkSteps ? K1S : kChunkSteps) * HSTEPF;
   int parity = 0;
   {
-    const float* first = on[0] ? a.w1[0] : (on[1] ? a.w1[1] : (on[2] ? a.w1[2] : after_l1));
+    const float* first = on[0] ? w1[0] : (on[1] ? w1[1] : (on[2] ? w1[2] : after_l1));
     const int first_floats = (on[0] || on[1] || on[2]) ? K1FIRST : after_l1_floats;
     issue_chunk(first, first_floats, lds, lane, wave);
   }
 
   // ---- layer 1 ----
   f32x16 acc[HT];
-  init_bias<HT>(acc, a.b1, h);
   {
     const float* row[3] = {nullptr, nullptr, nullptr};
 #pragma unroll
     for (int i = 0; i < NSEG; ++i)
-      if (on[i]) row[i] = operand_row(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], b, k);
+      if (on[i] || prj[i]) row[i] = operand_row(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], b, k);
     float x[K1S];
     {
       const int f = on[0] ? 0 : (on[1] ? 1 : 2);
       if (on[0] || on[1] || on[2]) load_operand<K1S, K1FULL>(x, row[f], a.seg_k[f], h);
     }
+    init_bias<HT>(acc, a.b1, h);
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i)
+      if (prj[i]) add_projected<HT>(acc, row[i], h);
     constexpr bool RL = K1FULL && (NSEG > 1);
     bool tail_pending = false;  // the current operand's last register slice still has to be gathered
     if (on[0]) {
-      const float* nx = on[1] ? a.w1[1] : (on[2] ? a.w1[2] : after_l1);
+      const float* nx = on[1] ? w1[1] : (on[2] ? w1[2] : after_l1);
       const int nf = (on[1] || on[2]) ? K1FIRST : after_l1_floats;
       const bool more = on[1] || on[2];
-      mma_pass<K1S, HT, RL>(acc, x, a.w1[0], nx, nf, lds, parity, lane, wave, nullptr, false, on[1] ? row[1] : row[2], more, h);
+      mma_pass<K1S, HT, RL>(acc, x, w1[0], nx, nf, lds, parity, lane, wave, nullptr, false, on[1] ? row[1] : row[2], more, h);
       tail_pending = more;
     }
     if (NSEG > 1 && on[1]) {
-      const float* nx = on[2] ? a.w1[2] : after_l1;
+      const float* nx = on[2] ? w1[2] : after_l1;
       const int nf = on[2] ? K1FIRST : after_l1_floats;
-      mma_pass<K1S, HT, RL>(acc, x, a.w1[1], nx, nf, lds, parity, lane, wave, row[1], tail_pending, row[2], on[2], h);
+      mma_pass<K1S, HT, RL>(acc, x, w1[1], nx, nf, lds, parity, lane, wave, row[1], tail_pending, row[2], on[2], h);
       tail_pending = on[2];
     }
     if (NSEG > 2 && on[2])
-      mma_pass<K1S, HT, RL>(acc, x, a.w1[2], after_l1, after_l1_floats, lds, parity, lane, wave, row[2], tail_pending, nullptr, false, h);
+      mma_pass<K1S, HT, RL>(acc, x, w1[2], after_l1, after_l1_floats, lds, parity, lane, wave, row[2], tail_pending, nullptr, false, h);
   }
 
-  // ---- middle layers (hidden -> hidden) ----
-  float hin[HS];
-#pragma unroll 1
-  for (int l = 0; l < a.n_mid; ++l) {
-    relu_to_in<HT>(hin, acc);
-    init_bias<HT>(acc, a.b_mid + l * (HT * 32), h);
-    const bool last = (l + 1 == a.n_mid);
-    const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
-    const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
-    mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
-  }
-
-  // ---- output layer ----
-  relu_to_in<HT>(hin, acc);
   f32x16 o[OT];
-  init_bias<OT>(o, a.b_out, h);
-  mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+  if constexpr (SINGLE) {
+    static_assert(!SINGLE || HT == OT, "single-layer mode stores the layer-1 accumulator");
+#pragma unroll
+    for (int t = 0; t < OT; ++t) o[t] = acc[t < HT ? t : 0];
+  } else {
+    // ---- middle layers (hidden -> hidden) ----
+    float hin[HS];
+#pragma unroll 1
+    for (int l = 0; l < a.n_mid; ++l) {
+      relu_to_in<HT>(hin, acc);
+      init_bias<HT>(acc, a.b_mid + l * (HT * 32), h);
+      const bool last = (l + 1 == a.n_mid);
+      const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
+      const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
+      mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+    }
+
+    // ---- output layer ----
+    relu_to_in<HT>(hin, acc);
+    init_bias<OT>(o, a.b_out, h);
+    mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+  }
 
   // ---- LayerNorm over the OT*32 features of each column (eps 1e-5, biased variance) ----
-  if (a.gamma != nullptr) {
+  if (!SINGLE && a.gamma != nullptr) {
     constexpr float inv_n = 1.0f / (OT * 32);
     float s = 0.f;
 #pragma unroll
@@ -324,7 +365,7 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
   }
 
   // ---- residual ----
-  if (a.res_ptr != nullptr) {
+  if (!SINGLE && a.res_ptr != nullptr) {
     const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
 #pragma unroll
     for (int t = 0; t < OT; ++t)
@@ -344,8 +385,9 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
   }
 
   // ---- store ----
-  if (a.out != nullptr && valid) {
-    float* orow = a.out + (size_t)c * (size_t)a.out_ld;
+  float* outp = SINGLE ? a.proj_out[blockIdx.y] : a.out;
+  if (outp != nullptr && valid) {
+    float* orow = outp + (size_t)c * (size_t)a.out_ld;
 #pragma unroll
     for (int t = 0; t < OT; ++t)
 #pragma unroll
@@ -461,14 +503,14 @@ int check_launch(const char* what) {
 }
 
 template <typename K>
-int launch_chain(K kernel, const ChainArgs& a, void* stream) {
+int launch_chain(K kernel, const ChainArgs& a, void* stream, int grid_y = 1) {
   static bool attr_done = false;  // per template instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_done = true;
   }
   const int grid = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
   return check_launch("chain_kernel launch");
 }
 
@@ -490,7 +532,17 @@ void fill_operand(ChainArgs& a, int i, const gw_operand* op) {
   a.seg_rows_pb[i] = op->rows_per_batch;
   a.seg_ld[i] = op->ld;
   a.seg_k[i] = op->k;
+  a.seg_proj[i] = op->projected;
 }
+
+void fill_residual(ChainArgs& a, const gw_operand* op) {
+  a.res_ptr = op->ptr;
+  a.res_idx = op->index;
+  a.res_rows_pb = op->rows_per_batch;
+  a.res_ld = op->ld;
+}
+
+bool bad256(const gw_operand* op) { return op->k != 256 || op->ld % 4 != 0 || !op->ptr; }
 
 }  // namespace
 
@@ -566,20 +618,22 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
 
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
-                           const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst, void* stream) {
+                           const gw_operand* e_res, const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst,
+                           void* stream) {
   if (batch <= 0 || n_edges < 0 || n_dst <= 0) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if (n_edges == 0) return GW_OK;  // nothing to add: agg stays as the caller zeroed it
-  if (!src || !dst || !x_src || !x_dst || !e_in || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
+  if (!src || !dst || !x_src || !x_dst || !e_in || !e_res || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if ((int64_t)batch * n_edges >= (int64_t)1 << 31 || (int64_t)batch * n_dst >= (int64_t)1 << 31)
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: batch*edges exceeds int32");
-  if (w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || !w->ln_beta)
+  if (w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || !w->ln_beta || !w->b1 || !w->w_out || !w->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: only hidden=256, out=256, LayerNorm is implemented");
   const gw_operand* ops[3] = {x_src, x_dst, e_in};
   for (int i = 0; i < 3; ++i) {
-    if (ops[i]->k != 0 && (ops[i]->k != 256 || ops[i]->ld % 4 != 0 || !ops[i]->ptr || !w->w1[i]))
+    if (ops[i]->k == 0) continue;
+    if (bad256(ops[i]) || (!ops[i]->projected && !w->w1[i]))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
-  if (e_in->k != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_in must be present (residual)");
+  if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;
@@ -590,10 +644,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.seg_idx[1] = dst;
   fill_operand(a, 2, e_in);
   fill_weights(a, w);
-  a.res_ptr = e_in->ptr;
-  a.res_idx = e_in->index;
-  a.res_rows_pb = e_in->rows_per_batch;
-  a.res_ld = e_in->ld;
+  fill_residual(a, e_res);
   a.out = e_out;
   a.out_ld = 256;
   a.out_cols = 256;
@@ -603,14 +654,16 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   return launch_chain(chain_kernel<128, true, 3, 8, 8, EPI_EDGE>, a, stream);
 }
 
-int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
-                           const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream) {
+int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
+                           const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream) {
   if (!x || !agg || !w || !x_out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: more than 2^31-1 rows");
-  if (w->hidden != 256 || w->n_out != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: only hidden=256, out=256");
-  if (agg->k != 256 || agg->ld % 4 != 0 || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide");
-  if (x->k != 0 && (x->k != 256 || x->ld % 4 != 0 || !w->w1[0])) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide or zeros");
+  if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out)
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: only hidden=256, out=256");
+  if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide (raw)");
+  if (x->k != 0 && (bad256(x) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide or zeros");
+  if (x_res && x_res->k != 0 && bad256(x_res)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x_res must be 256 wide");
   if (out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: out_ld must be a multiple of 4");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -619,16 +672,33 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   fill_operand(a, 0, x);
   fill_operand(a, 1, agg);
   fill_weights(a, w);
-  if (x->k != 0) {
-    a.res_ptr = x->ptr;
-    a.res_idx = x->index;
-    a.res_rows_pb = x->rows_per_batch;
-    a.res_ld = x->ld;
-  }
+  if (x_res && x_res->k != 0) fill_residual(a, x_res);
   a.out = x_out;
   a.out_ld = out_ld;
   a.out_cols = 256;
   return launch_chain(chain_kernel<128, true, 2, 8, 8, EPI_ROWS>, a, stream);
+}
+
+int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
+                       const float* const* w_slices, float* const* outs, int32_t out_ld, void* stream) {
+  if (!x || !w_slices || !outs || n_rows < 0 || rows_per_batch <= 0 || n_slices <= 0 || n_slices > 4)
+    return fail(GW_E_BADARG, "gw_project_forward: bad arguments (1..4 slices)");
+  if (n_rows == 0) return GW_OK;
+  if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_project_forward: more than 2^31-1 rows");
+  if (bad256(x) || x->projected || out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_project_forward: x must be a raw 256-wide table");
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = (int)n_rows;
+  a.cols_per_batch = rows_per_batch;
+  fill_operand(a, 0, x);
+  for (int i = 0; i < n_slices; ++i) {
+    if (!w_slices[i] || !outs[i]) return fail(GW_E_BADARG, "gw_project_forward: null slice / output");
+    a.proj_w[i] = w_slices[i];
+    a.proj_out[i] = outs[i];
+  }
+  a.out_ld = out_ld;
+  a.out_cols = 256;
+  return launch_chain(chain_kernel<128, true, 1, 8, 8, EPI_ROWS, true>, a, stream, n_slices);
 }
 
 int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,

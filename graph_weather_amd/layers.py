@@ -111,17 +111,22 @@ class GraphNetBlock(nn.Module):
         self.edge_model = edge_model
         self.node_model = node_model
 
-    def run(self, batch: int, plan: GraphPlan, x_src: Operand, x_dst: Operand, x_node: Operand, e_in: Operand,
-            want_edges: bool, device, tag: Optional[str] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows."""
+    def run(self, batch: int, plan: GraphPlan, x_src: Operand, x_dst: Operand, e_in: Operand, e_res: Operand,
+            x_node: Operand, x_node_res: Operand, want_edges: bool, device,
+            tag: Optional[str] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
+        Operands may be raw rows, rows pre-projected through their layer-1 weight slice, or zeros."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
         agg = torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
         e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
-        ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src, x_dst, e_in, n_dst,
-                                agg, e_out, tag=tag)
-        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node,
+        ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src, x_dst, e_in, e_res,
+                                n_dst, agg, e_out, tag=tag)
+        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node, x_node_res,
                                         Operand(agg, n_dst, 256))
         return x_new, e_out
+
+    def params_key(self) -> tuple:
+        return _version_key(list(self.parameters()))
 
 
 def build_graph_processor_block(in_dim_node=128, in_dim_edge=128, hidden_dim_node=128, hidden_dim_edge=128,
@@ -153,18 +158,33 @@ class GraphProcessor(nn.Module):
             self.blocks.append(build_graph_processor_block(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge,
                                                            hidden_layers_node, hidden_layers_edge, norm_type))
         self._plan_cache = None
+        self._e0_cache = None
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
     def run_plan(self, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: bool, batch: int,
                  want_edges: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """Layer 1 of every edge MLP is split (cat[x_s, x_d, e].W1^T = x_s.Ws^T + x_d.Wd^T + e.We^T): the node
+        products are computed once per node (shared by its ~7 incident edges) and gathered per edge; when the
+        incoming edge features are batch independent (first block after the encoder) their product is cached."""
         _check_native_dims(*self._dims)
         n, n_edges = plan.n_dst, plan.num_edges
         e_cur, shared = e, e_shared
         for i, blk in enumerate(self.blocks):
             last = i == len(self.blocks) - 1
+            pm_e = blk.edge_model.edge_mlp.packed()
             xop = Operand(x, n, 256)
-            x, e_new = blk.run(batch, plan, xop, xop, xop, Operand(e_cur, 0 if shared else n_edges, 256),
-                               want_edges or not last, x.device, tag="processor_edge")
+            ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], xop, batch * n, n)
+            if shared:
+                key = (e_cur.data_ptr(), e_cur._version, blk.params_key())
+                if self._e0_cache is None or self._e0_cache[0] != key:
+                    pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
+                    self._e0_cache = (key, pe)
+                e_in = Operand(self._e0_cache[1], 0, 256, projected=True)
+            else:
+                e_in = Operand(e_cur, n_edges, 256)
+            x, e_new = blk.run(batch, plan, Operand(ps, n, 256, projected=True), Operand(pd, n, 256, projected=True), e_in,
+                               Operand(e_cur, 0 if shared else n_edges, 256), xop, xop, want_edges or not last, x.device,
+                               tag="processor_edge")
             if e_new is not None:
                 e_cur, shared = e_new, False
         return x, (e_cur if want_edges else None)
@@ -263,10 +283,27 @@ class Encoder(nn.Module):
         e = self.encoder_edge_embedding(enc_plan)
         blk = self.graph_processor.blocks[0]
         _check_native_dims(*self.graph_processor._dims)
-        xm_op = Operand(xm, 0, 256)
-        x, _ = blk.run(B, enc_plan, Operand(xg, G, 256), xm_op, xm_op, Operand(e, 0, 256), False, features.device,
-                       tag="encoder_edge")
+        pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
+        x, _ = blk.run(B, enc_plan, Operand(xg, G, 256), Operand(pd_xm, 0, 256, projected=True),
+                       Operand(pe, 0, 256, projected=True), Operand(e, 0, 256), Operand(px_xm, 0, 256, projected=True),
+                       Operand(xm, 0, 256), False, features.device, tag="encoder_edge")
         return x
+
+    def _static_projections(self, blk, xm: torch.Tensor, e: torch.Tensor):
+        """Batch-independent layer-1 products of the encoder block (mesh rows are the same for every sample,
+        encoder.py:199-204): Wd.xm (edge MLP), We.e (edge MLP), Wx.xm (node MLP) - cached per weight version."""
+        ps = list(self.parameters())
+
+        def make():
+            pm_e = blk.edge_model.edge_mlp.packed()
+            pm_n = blk.node_model.node_mlp.packed()
+            M, G = int(xm.shape[0]), int(e.shape[0])
+            pd_xm = ops.project_forward([pm_e.w1[1]], Operand(xm, M, 256), M, M)[0]
+            pe = ops.project_forward([pm_e.w1[2]], Operand(e, G, 256), G, G)[0]
+            px_xm = ops.project_forward([pm_n.w1[0]], Operand(xm, M, 256), M, M)[0]
+            return pd_xm, pe, px_xm
+
+        return self._cached("enc_proj", ps, make)
 
     def forward(self, features: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """encoder.py:153-242.  Returns reference-order tensors: replicated graph by default, the single shared
@@ -373,9 +410,19 @@ class AssimilatorDecoder(nn.Module):
         e = self.edge_embedding(plan)
         blk = self.graph_processor.blocks[0]
         _check_native_dims(*self.graph_processor._dims)
-        # lat/lon rows are zeros (assimilator_decoder.py:84,190-192): x_dst = 0, node input [0 | agg], residual 0
-        xg, _ = blk.run(B, plan, Operand(processor_features.contiguous(), M, 256), ops.ZERO, ops.ZERO, Operand(e, 0, 256),
-                        False, dev, tag="decoder_edge")
+        # lat/lon rows are zeros (assimilator_decoder.py:84,190-192): x_dst = 0, node input [0 | agg], residual 0.
+        # Layer 1 of the edge MLP is then relu(Ws.x[src] + (We.e + b)): a gather-add of a per-mesh-node product and a
+        # cached batch-independent per-edge product - no matrix work per edge in layer 1.
+        pm_e = blk.edge_model.edge_mlp.packed()
+        ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M)[0]
+        key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
+        hit = self._cache.get("dec_pe")
+        if hit is None or hit[0] != key:
+            n_e = plan.num_edges
+            self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
+        pe = self._cache["dec_pe"][1]
+        xg, _ = blk.run(B, plan, Operand(ps, M, 256, projected=True), ops.ZERO, Operand(pe, 0, 256, projected=True),
+                        Operand(e, 0, 256), ops.ZERO, ops.ZERO, False, dev, tag="decoder_edge")
         res = None
         if residual is not None:
             res = Operand(residual, G, self.output_dim)

@@ -61,15 +61,16 @@ class Operand:
     rows_per_batch: int
     k: int
     index: Optional[torch.Tensor] = None
+    projected: bool = False  # rows are X . W1_slice^T (see project_forward): gather-added, no MFMA pass
 
     def c(self) -> GwOperand:
         if self.k == 0 or self.tensor is None:
-            return GwOperand(None, None, 0, 0, 0)
+            return GwOperand(None, None, 0, 0, 0, 0)
         _require(self.tensor, "operand")
         if self.index is not None:
             _require(self.index, "operand index", torch.int32)
         return GwOperand(self.tensor.data_ptr(), None if self.index is None else self.index.data_ptr(),
-                         int(self.rows_per_batch), int(self.tensor.stride(0)), int(self.k))
+                         int(self.rows_per_batch), int(self.tensor.stride(0)), int(self.k), 1 if self.projected else 0)
 
 
 ZERO = Operand(None, 0, 0)
@@ -152,8 +153,23 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
     return out
 
 
+def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, rows_per_batch: int) -> List[torch.Tensor]:
+    """out_s = x . W_s^T for up to four packed [256, 256] layer-1 slices in one launch (layer-1 split of
+    graph_net_block.py:131-134 / :189: products over node tables are shared by all incident edges)."""
+    import ctypes
+
+    dev = x.tensor.device
+    n = len(w_slices)
+    outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=dev) for _ in range(n)]
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w_slices])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, _stream(outs[0])),
+               "gw_project_forward")
+    return outs
+
+
 def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
-                        e_in: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
+                        e_in: Operand, e_res: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
                         tag: Optional[str] = None) -> None:
     """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed."""
     _require(src, "src", torch.int32)
@@ -162,25 +178,25 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
     if e_out is not None:
         _require(e_out, "e_out")
     n_edges = int(src.shape[0])
-    wc = pm.c((x_src.k > 0, x_dst.k > 0, e_in.k > 0))
+    wc = pm.c((x_src.k > 0 and not x_src.projected, x_dst.k > 0 and not x_dst.projected, e_in.k > 0 and not e_in.projected))
     ev = TIMER.start(tag) if TIMER is not None else None
     _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), x_src.c(), x_dst.c(), e_in.c(),
-                                                 wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(), n_dst,
-                                                 _stream(agg)), "gw_edge_update_forward")
+                                                 e_res.c(), wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(),
+                                                 n_dst, _stream(agg)), "gw_edge_update_forward")
     if ev is not None:
         TIMER.stop(tag, ev)
 
 
-def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, agg: Operand,
+def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, x_res: Operand, agg: Operand,
                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """graph_net_block.py:189-191 (NodeProcessor after aggregation)."""
     dev = agg.tensor.device
     if out is None:
         out = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=dev)
     _require(out, "out")
-    wc = pm.c((x.k > 0, True, False))
-    _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), agg.c(), wc, out.data_ptr(), int(out.stride(0)),
-                                                 _stream(out)), "gw_node_update_forward")
+    wc = pm.c((x.k > 0 and not x.projected, True, False))
+    _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), x_res.c(), agg.c(), wc, out.data_ptr(),
+                                                 int(out.stride(0)), _stream(out)), "gw_node_update_forward")
     return out
 
 

@@ -55,6 +55,8 @@ typedef struct gw_operand {
   int32_t ld;           /* row stride in floats                                                 */
   int32_t k;            /* valid input features taken from each row (0 = operand is all zeros:  */
                         /* its weight slice is skipped, exact since 0*W == 0)                    */
+  int32_t projected;    /* 1 = rows already hold X . W1_slice^T (from gw_project_forward): they */
+                        /* are gather-added into the layer-1 accumulator, no MFMA pass           */
 } gw_operand;
 
 /* A 3+ layer MLP in packed form: Linear(k_in,h) ReLU [Linear(h,h) ReLU]*n_mid Linear(h,n_out) [LayerNorm]. */
@@ -80,22 +82,32 @@ typedef struct gw_mlp_weights {
 int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
                    const gw_operand* residual /* may be NULL */, float* out, int32_t out_ld, void* stream);
 
+/* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
+ * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7
+ * edges incident to a node, and the ones over batch-independent tables are cacheable.)
+ * out_s[c, :] = x[c, :256] . W_s^T for s < n_slices (<= 4); W_s = packed [256, 256] slices from gw_pack_linear. */
+int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
+                       const float* const* w_slices, float* const* outs, int32_t out_ld, void* stream);
+
 /* ---- EdgeProcessor.forward + scatter_sum (graph_net_block.py:131-137 and :188) --------------------------
  * For every batch element b and edge e (dst-sorted):
- *   e_new = LN(MLP(cat[x_src[b, src[e]], x_dst[b, dst[e]], e_in[b, e]])) + e_in[b, e]
+ *   e_new = LN(MLP(cat[x_src[b, src[e]], x_dst[b, dst[e]], e_in[b, e]])) + e_res[b, e]
  *   agg[b, dst[e], :] += e_new                         (agg must be zero-filled by the caller)
- * and, if e_out != NULL, e_out[b, e, :] = e_new.  Feature width is 256. */
+ * and, if e_out != NULL, e_out[b, e, :] = e_new.  Feature width is 256.  Each of x_src / x_dst / e_in may be
+ * raw rows, pre-projected rows (operand.projected) or zeros (k == 0); e_res is always the raw edge feature row
+ * (the residual of graph_net_block.py:135). */
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
-                           const gw_mlp_weights* w, float* e_out /* [batch*n_edges,256] or NULL */,
-                           float* agg /* [batch*n_dst,256] */, int32_t n_dst, void* stream);
+                           const gw_operand* e_res, const gw_mlp_weights* w,
+                           float* e_out /* [batch*n_edges,256] or NULL */, float* agg /* [batch*n_dst,256] */,
+                           int32_t n_dst, void* stream);
 
 /* ---- NodeProcessor.forward after aggregation (graph_net_block.py:189-191) -------------------------------
- *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x[b, j]
- * x->k == 0 states that the node rows are zeros (the decoder's lat/lon rows, assimilator_decoder.py:84,190):
- * the x-slice of layer 1 and the residual are skipped. */
-int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
-                           const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream);
+ *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x_res[b, j]
+ * x may be raw, pre-projected or zeros (k == 0: the decoder's lat/lon rows are zeros, assimilator_decoder.py:84,
+ * 190 - the x-slice of layer 1 is skipped); x_res = raw node rows for the residual (NULL or k == 0: none). */
+int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
+                           const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream);
 
 /* ---- NormalizedMSELoss.forward (losses.py:66-94, normalize on/off) ---------------------------------------
  * loss = mean_{b,n}( w_lat[n / num_lon] * mean_c( (pred-target)^2 [/ var_c] ) ); *loss_out must be zeroed. */

@@ -37,7 +37,8 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.gw_pack_linear(None, 256, 256, 0, 256, None, None) == -1
     assert b"bad arguments" in L.gw_last_error()
-    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, 1, None) == -1
+    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, None, 1, None) == -1
+    assert L.gw_project_forward(10, 10, None, 1, None, None, 256, None) == -1
 
 
 def test_product_has_no_cpu_path():
