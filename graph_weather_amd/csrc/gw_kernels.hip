@@ -2,13 +2,15 @@
 //
 // Design:  every MLP of the model is evaluated in the *transposed* form
 //       H_out[feature][column] = W[feature][k] * H_in[k][column]
-// with `column` = one edge / node, 32 columns per 64-lane wave.  With v_mfma_f32_32x32x2_f32 the weight
-// matrix is the A operand (A[i = lane&31][k = lane>>5]) and the activations are the B operand
-// (B[k = lane>>5][j = lane&31]).  The accumulator layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-// holds, for column j, exactly the features a lane must supply as B operand of the next layer if the K
-// dimension is walked in the order k(s, h) = 8*(s>>2) + 4*h + (s&3) - so a 3-layer MLP + LayerNorm + residual
-// runs register-resident, no transposes, no LDS traffic for activations.  LDS carries only the packed weight
-// stream (shared by the 4 waves of a workgroup, filled by global_load_lds DMA, double buffered).
+// with `column` = one edge / node, 16 columns per 64-lane wave.  With v_mfma_f32_16x16x4_f32 the weight matrix
+// is the A operand (A[i = lane&15][k = lane>>4]) and the activations are the B operand (B[k = lane>>4][j = lane&15]).
+// The accumulator layout (col = lane&15, row = 4*(lane>>4) + r) holds, for column j, exactly the features a lane
+// must supply as B operand of the next layer if the K dimension is walked in the order
+//       k(s, q) = 16*(s>>2) + 4*q + (s&3)        (s = K-step, q = lane>>4)
+// so a 3-layer MLP + LayerNorm + residual runs register-resident: no transposes, no LDS traffic for activations.
+// LDS carries only the packed weight stream (shared by the 4 waves of a workgroup, filled by global_load_lds DMA,
+// double buffered).  A wave needs < 256 registers, so two independent 64-column workgroups share a CU and one's
+// gathers / LayerNorm / segment-sum epilogue overlap the other's MFMAs.
 // fp32 in / fp32 accumulate MFMA == an fmaf chain, so the result is fp32-exact up to summation order.
 //
 // Reference statements implemented: graph_net_block.py:45-61 (MLP), :131-137 (EdgeProcessor), :184-193
@@ -23,15 +25,14 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;          // 4 waves, one per SIMD
-constexpr int kColsPerWave = 32;
-constexpr int kColsPerWG = 128;
-constexpr int kChunkSteps = 16;        // K-steps (2 k's each) per LDS buffer
-constexpr int kLdsBufFloats = kChunkSteps * 2 * 256;  // 16 steps x 8 tiles x 32 rows x 2 k = 32 KiB
-constexpr int kLdsBytes = 2 * kLdsBufFloats * 4;       // double buffered: 64 KiB
+constexpr int kThreads = 256;         // 4 waves per workgroup; two workgroups per CU (2 waves per SIMD)
+constexpr int kColsPerWave = 16;
+constexpr int kColsPerWG = 64;
+constexpr int kChunkSteps = 8;        // K-steps (4 k's each) per LDS buffer: K = 32 per chunk
+constexpr int kLdsBufFloats = kChunkSteps * 4 * 256;  // 8 steps x 16 tiles x 16 rows x 4 k = 32 KiB
+constexpr int kLdsBytes = 2 * kLdsBufFloats * 4;       // double buffered: 64 KiB per workgroup
 
 enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
 
@@ -90,13 +91,13 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfl
   for (int p = wave; p < npieces; p += 4) glds16(g + (size_t)p * 256 + lane * 4, ldsbuf + p * 256);
 }
 
-// in[16c .. 16c+15] <- row[k(s,h)] for the K-steps of chunk c (full 16-byte aligned rows)
+// in[8c .. 8c+7] <- row[k(s,q)] for the K-steps of chunk c (full 16-byte aligned rows)
 template <int NSTEPS>
-__device__ __forceinline__ void load_operand_slice(float (&in)[NSTEPS], const float* __restrict__ row, int c, int h) {
+__device__ __forceinline__ void load_operand_slice(float (&in)[NSTEPS], const float* __restrict__ row, int c, int q) {
 #pragma unroll
-  for (int i = 4 * c; i < 4 * c + 4; ++i) {
+  for (int i = 2 * c; i < 2 * c + 2; ++i) {
     if (4 * i + 3 < NSTEPS) {
-      const f32x4 v = ldg4(row + 8 * i + 4 * h);
+      const f32x4 v = ldg4(row + 16 * i + 4 * q);
       in[4 * i + 0] = v.x;
       in[4 * i + 1] = v.y;
       in[4 * i + 2] = v.z;
@@ -105,17 +106,17 @@ __device__ __forceinline__ void load_operand_slice(float (&in)[NSTEPS], const fl
   }
 }
 
-// One K-pass of a layer: acc[t] += W[32t.., k] * in[k], K = 2*NSTEPS, NT row tiles of 32 features.
+// One K-pass of a layer: acc[t] += W[16t.., k] * in[k], K = 4*NSTEPS, NT row tiles of 16 features.
 // Protocol: the first chunk of this pass has already been issued into buffer `parity`.
-// With RELOAD, the 16 operand registers a chunk has consumed are refilled (one chunk later) with the same
+// With RELOAD, the 8 operand registers a chunk has consumed are refilled (one chunk later) with the same
 // k-slice of the NEXT layer-1 operand (rows are full 256-float rows), so the gather of operand i+1 streams in
 // underneath the MFMAs of operand i at no extra register cost; the slice consumed by the last chunk is
 // refilled during chunk 0 of the next pass (`tail_row`).
 template <int NSTEPS, int NT, bool RELOAD>
-__device__ __forceinline__ void mma_pass(f32x16 (&acc)[NT], float (&in)[NSTEPS], const float* __restrict__ gw,
+__device__ __forceinline__ void mma_pass(f32x4 (&acc)[NT], float (&in)[NSTEPS], const float* __restrict__ gw,
                                          const float* __restrict__ next_gw, int next_floats, float* lds, int& parity,
                                          int lane, int wave, const float* __restrict__ tail_row, bool do_tail,
-                                         const float* __restrict__ next_row, bool do_next, int h) {
+                                         const float* __restrict__ next_row, bool do_next, int q) {
   constexpr int NT4 = (NT + 3) / 4;
   constexpr int STEPF = NT4 * 256;
   constexpr int NCH = (NSTEPS + kChunkSteps - 1) / kChunkSteps;
@@ -133,34 +134,34 @@ __device__ __forceinline__ void mma_pass(f32x16 (&acc)[NT], float (&in)[NSTEPS],
     }
     if (RELOAD) {
       // Operand registers are refilled one chunk behind their consumption, right after the barrier, so the
-      // gathers have a whole chunk of MFMAs (~8k cycles) to land before the next vmcnt(0).
+      // gathers have a whole chunk of MFMAs to land before the next vmcnt(0).
       if (c == 0) {
-        if (do_tail) load_operand_slice<NSTEPS>(in, tail_row, NCH - 1, h);   // this operand's last 16 registers
+        if (do_tail) load_operand_slice<NSTEPS>(in, tail_row, NCH - 1, q);   // this operand's last 8 registers
       } else {
-        if (do_next) load_operand_slice<NSTEPS>(in, next_row, c - 1, h);     // next operand, slice consumed last chunk
+        if (do_next) load_operand_slice<NSTEPS>(in, next_row, c - 1, q);     // next operand, slice consumed last chunk
       }
     }
     const float* buf = lds + parity * kLdsBufFloats + lane * 4;
     f32x4 a_cur[NT4];
 #pragma unroll
-    for (int q = 0; q < NT4; ++q) a_cur[q] = *(const f32x4*)(buf + q * 256);
+    for (int b4 = 0; b4 < NT4; ++b4) a_cur[b4] = *(const f32x4*)(buf + b4 * 256);
 #pragma unroll
     for (int s = 0; s < kChunkSteps; ++s) {
       if (s < nsteps_c) {
         f32x4 a_nxt[NT4];
         if (s + 1 < nsteps_c) {
 #pragma unroll
-          for (int q = 0; q < NT4; ++q) a_nxt[q] = *(const f32x4*)(buf + (s + 1) * STEPF + q * 256);
+          for (int b4 = 0; b4 < NT4; ++b4) a_nxt[b4] = *(const f32x4*)(buf + (s + 1) * STEPF + b4 * 256);
         }
         const float b = in[c * kChunkSteps + s];
         __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of step s+1 ahead of the MFMAs of step s
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nsteps_c) {
 #pragma unroll
-          for (int q = 0; q < NT4; ++q) a_cur[q] = a_nxt[q];
+          for (int b4 = 0; b4 < NT4; ++b4) a_cur[b4] = a_nxt[b4];
         }
       }
     }
@@ -169,48 +170,30 @@ __device__ __forceinline__ void mma_pass(f32x16 (&acc)[NT], float (&in)[NSTEPS],
 }
 
 template <int NT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* __restrict__ bias, int h) {
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* __restrict__ bias, int q) {
   if (bias == nullptr) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     return;
   }
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = ldg4(bias + 32 * t + 8 * g + 4 * h);
-      acc[t][4 * g + 0] = v.x;
-      acc[t][4 * g + 1] = v.y;
-      acc[t][4 * g + 2] = v.z;
-      acc[t][4 * g + 3] = v.w;
-    }
+  for (int t = 0; t < NT; ++t) acc[t] = ldg4(bias + 16 * t + 4 * q);
 }
 
 // acc += P[row] for an operand that is already projected through its layer-1 weight slice (accumulator layout)
 template <int NT>
-__device__ __forceinline__ void add_projected(f32x16 (&acc)[NT], const float* __restrict__ row, int h) {
+__device__ __forceinline__ void add_projected(f32x4 (&acc)[NT], const float* __restrict__ row, int q) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = ldg4(row + 32 * t + 8 * g + 4 * h);
-      acc[t][4 * g + 0] += v.x;
-      acc[t][4 * g + 1] += v.y;
-      acc[t][4 * g + 2] += v.z;
-      acc[t][4 * g + 3] += v.w;
-    }
+  for (int t = 0; t < NT; ++t) acc[t] += ldg4(row + 16 * t + 4 * q);
 }
 
-// in[s] <- row[k(s,h)], k(s,h) = 8*(s>>2) + 4*h + (s&3)
+// in[s] <- row[k(s,q)], k(s,q) = 16*(s>>2) + 4*q + (s&3)
 template <int KSTEPS, bool FULL>
-__device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* __restrict__ row, int kvalid, int h) {
+__device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* __restrict__ row, int kvalid, int q) {
 #pragma unroll
   for (int i = 0; i < KSTEPS / 4; ++i) {
     if (FULL) {
-      const f32x4 v = ldg4(row + 8 * i + 4 * h);
+      const f32x4 v = ldg4(row + 16 * i + 4 * q);
       in[4 * i + 0] = v.x;
       in[4 * i + 1] = v.y;
       in[4 * i + 2] = v.z;
@@ -218,7 +201,7 @@ __device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* _
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int k = 8 * i + 4 * h + r;
+        const int k = 16 * i + 4 * q + r;
         in[4 * i + r] = (k < kvalid) ? ldg1(row + k) : 0.f;
       }
     }
@@ -226,11 +209,11 @@ __device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* _
 }
 
 template <int NT>
-__device__ __forceinline__ void relu_to_in(float (&in)[NT * 16], const f32x16 (&acc)[NT]) {
+__device__ __forceinline__ void relu_to_in(float (&in)[NT * 4], const f32x4 (&acc)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) in[16 * t + r] = fmaxf(acc[t][r], 0.f);
+    for (int r = 0; r < 4; ++r) in[4 * t + r] = fmaxf(acc[t][r], 0.f);
 }
 
 __device__ __forceinline__ const float* operand_row(const float* ptr, const int* idx, int rows_pb, int ld, int b, int k) {
@@ -239,15 +222,15 @@ __device__ __forceinline__ const float* operand_row(const float* ptr, const int*
 }
 
 template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE = false>
-__global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int HS = HT * 16;                  // K-steps of a hidden layer
+  constexpr int HS = HT * 4;                   // K-steps of a hidden layer
   constexpr int HSTEPF = ((HT + 3) / 4) * 256;  // floats per step, hidden-row layers
   constexpr int OSTEPF = ((OT + 3) / 4) * 256;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31;
-  const int h = lane >> 5;
+  const int j = lane & 15;
+  const int q = lane >> 4;
   const int c_raw = blockIdx.x * kColsPerWG + wave * kColsPerWave + j;
   const bool valid = c_raw < a.n_cols;
   const int c = valid ? c_raw : a.n_cols - 1;
@@ -275,7 +258,7 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
   }
 
   // ---- layer 1 ----
-  f32x16 acc[HT];
+  f32x4 acc[HT];
   {
     const float* row[3] = {nullptr, nullptr, nullptr};
 #pragma unroll
@@ -284,32 +267,32 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
     float x[K1S];
     {
       const int f = on[0] ? 0 : (on[1] ? 1 : 2);
-      if (on[0] || on[1] || on[2]) load_operand<K1S, K1FULL>(x, row[f], a.seg_k[f], h);
+      if (on[0] || on[1] || on[2]) load_operand<K1S, K1FULL>(x, row[f], a.seg_k[f], q);
     }
-    init_bias<HT>(acc, a.b1, h);
+    init_bias<HT>(acc, a.b1, q);
 #pragma unroll
     for (int i = 0; i < NSEG; ++i)
-      if (prj[i]) add_projected<HT>(acc, row[i], h);
+      if (prj[i]) add_projected<HT>(acc, row[i], q);
     constexpr bool RL = K1FULL && (NSEG > 1);
     bool tail_pending = false;  // the current operand's last register slice still has to be gathered
     if (on[0]) {
       const float* nx = on[1] ? w1[1] : (on[2] ? w1[2] : after_l1);
       const int nf = (on[1] || on[2]) ? K1FIRST : after_l1_floats;
       const bool more = on[1] || on[2];
-      mma_pass<K1S, HT, RL>(acc, x, w1[0], nx, nf, lds, parity, lane, wave, nullptr, false, on[1] ? row[1] : row[2], more, h);
+      mma_pass<K1S, HT, RL>(acc, x, w1[0], nx, nf, lds, parity, lane, wave, nullptr, false, on[1] ? row[1] : row[2], more, q);
       tail_pending = more;
     }
     if (NSEG > 1 && on[1]) {
       const float* nx = on[2] ? w1[2] : after_l1;
       const int nf = on[2] ? K1FIRST : after_l1_floats;
-      mma_pass<K1S, HT, RL>(acc, x, w1[1], nx, nf, lds, parity, lane, wave, row[1], tail_pending, row[2], on[2], h);
+      mma_pass<K1S, HT, RL>(acc, x, w1[1], nx, nf, lds, parity, lane, wave, row[1], tail_pending, row[2], on[2], q);
       tail_pending = on[2];
     }
     if (NSEG > 2 && on[2])
-      mma_pass<K1S, HT, RL>(acc, x, w1[2], after_l1, after_l1_floats, lds, parity, lane, wave, row[2], tail_pending, nullptr, false, h);
+      mma_pass<K1S, HT, RL>(acc, x, w1[2], after_l1, after_l1_floats, lds, parity, lane, wave, row[2], tail_pending, nullptr, false, q);
   }
 
-  f32x16 o[OT];
+  f32x4 o[OT];
   if constexpr (SINGLE) {
     static_assert(!SINGLE || HT == OT, "single-layer mode stores the layer-1 accumulator");
 #pragma unroll
@@ -320,68 +303,62 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
 #pragma unroll 1
     for (int l = 0; l < a.n_mid; ++l) {
       relu_to_in<HT>(hin, acc);
-      init_bias<HT>(acc, a.b_mid + l * (HT * 32), h);
+      init_bias<HT>(acc, a.b_mid + l * (HT * 16), q);
       const bool last = (l + 1 == a.n_mid);
       const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
       const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
-      mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+      mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
     }
 
     // ---- output layer ----
     relu_to_in<HT>(hin, acc);
-    init_bias<OT>(o, a.b_out, h);
-    mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, h);
+    init_bias<OT>(o, a.b_out, q);
+    mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
   }
 
-  // ---- LayerNorm over the OT*32 features of each column (eps 1e-5, biased variance) ----
+  // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance) ----
   if (!SINGLE && a.gamma != nullptr) {
-    constexpr float inv_n = 1.0f / (OT * 32);
+    constexpr float inv_n = 1.0f / (OT * 16);
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += o[t][r];
+    for (int t = 0; t < OT; ++t) s += (o[t].x + o[t].y) + (o[t].z + o[t].w);
+    s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     const float mean = s * inv_n;
-    float q = 0.f;
+    float v = 0.f;
 #pragma unroll
     for (int t = 0; t < OT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 4; ++r) {
         const float d = o[t][r] - mean;
-        q += d * d;
+        v += d * d;
       }
-    q += __shfl_xor(q, 32);
-    const float rstd = 1.0f / sqrtf(q * inv_n + 1e-5f);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < OT; ++t) {
+      const f32x4 gm = ldg4(a.gamma + 16 * t + 4 * q);
+      const f32x4 bt = ldg4(a.beta + 16 * t + 4 * q);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 gm = ldg4(a.gamma + 32 * t + 8 * g + 4 * h);
-        const f32x4 bt = ldg4(a.beta + 32 * t + 8 * g + 4 * h);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[t][4 * g + r] = (o[t][4 * g + r] - mean) * rstd * gm[r] + bt[r];
-      }
+      for (int r = 0; r < 4; ++r) o[t][r] = (o[t][r] - mean) * rstd * gm[r] + bt[r];
+    }
   }
 
   // ---- residual ----
   if (!SINGLE && a.res_ptr != nullptr) {
     const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < OT; ++t) {
+      const int f0 = 16 * t + 4 * q;
+      if (EPI == EPI_DEC) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int f0 = 32 * t + 8 * g + 4 * h;
-        if (EPI == EPI_DEC) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (f0 + r < a.out_cols) o[t][4 * g + r] += ldg1(rrow + f0 + r);
-        } else {
-          const f32x4 v = ldg4(rrow + f0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[t][4 * g + r] += v[r];
-        }
+        for (int r = 0; r < 4; ++r)
+          if (f0 + r < a.out_cols) o[t][r] += ldg1(rrow + f0 + r);
+      } else {
+        o[t] += ldg4(rrow + f0);
       }
+    }
   }
 
   // ---- store ----
@@ -389,67 +366,58 @@ __global__ __launch_bounds__(kThreads, 1) void chain_kernel(const ChainArgs a) {
   if (outp != nullptr && valid) {
     float* orow = outp + (size_t)c * (size_t)a.out_ld;
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < OT; ++t) {
+      const int f0 = 16 * t + 4 * q;
+      if (EPI == EPI_DEC) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int f0 = 32 * t + 8 * g + 4 * h;
-        if (EPI == EPI_DEC) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[t][4 * g + r]);
-        } else {
-          f32x4 v;
-          v.x = o[t][4 * g + 0];
-          v.y = o[t][4 * g + 1];
-          v.z = o[t][4 * g + 2];
-          v.w = o[t][4 * g + 3];
-          stg4(orow + f0, v);
-        }
+        for (int r = 0; r < 4; ++r)
+          if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[t][r]);
+      } else {
+        stg4(orow + f0, o[t]);
       }
+    }
   }
 
   // ---- segment sum over destination-sorted columns: shuffle scan + one atomicAdd per segment tail ----
   if (EPI == EPI_EDGE) {
     const int gd = valid ? (b * a.agg_rows_pb + ldgi(a.agg_idx + k)) : (-1 - j);
 #pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const int gu = __shfl_up(gd, off, 32);
+    for (int off = 1; off < 16; off <<= 1) {
+      const int gu = __shfl_up(gd, off, 16);
       const bool take = (j >= off) && (gu == gd);
 #pragma unroll
       for (int t = 0; t < OT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float u = __shfl_up(o[t][r], off, 32);
+        for (int r = 0; r < 4; ++r) {
+          const float u = __shfl_up(o[t][r], off, 16);
           o[t][r] += take ? u : 0.f;
         }
     }
-    const int gn = __shfl_down(gd, 1, 32);
-    const bool tail = valid && (j == 31 || gn != gd);
+    const int gn = __shfl_down(gd, 1, 16);
+    const bool tail = valid && (j == 15 || gn != gd);
     if (tail) {
-      float* arow = a.agg + (size_t)gd * (size_t)(OT * 32);
+      float* arow = a.agg + (size_t)gd * (size_t)(OT * 16);
 #pragma unroll
       for (int t = 0; t < OT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-          __hip_atomic_fetch_add((GW_AS1 float*)(arow + f), o[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int r = 0; r < 4; ++r)
+          __hip_atomic_fetch_add((GW_AS1 float*)(arow + 16 * t + 4 * q + r), o[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
 // ---- weight packing: nn.Linear [n_out, k_total] slice -> MFMA A-operand stream -------------------------
-// out[s][q4][lane][q] = W[32*(4*q4+q) + (lane&31)][k_lo + 8*(s>>2) + 4*(lane>>5) + (s&3)]  (0 outside)
+// out[s][b4][lane][i] = W[16*(4*b4+i) + (lane&15)][k_lo + 16*(s>>2) + 4*(lane>>4) + (s&3)]  (0 outside)
 __global__ void pack_linear_kernel(const float* __restrict__ w, int n_out, int k_total, int k_lo, int kseg, int nt4,
                                    int nsteps, float* __restrict__ out) {
   const size_t total = (size_t)nsteps * nt4 * 256;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i & 3);
+    const int ti = (int)(i & 3);
     const int lane = (int)((i >> 2) & 63);
-    const int q4 = (int)((i >> 8) % nt4);
+    const int b4 = (int)((i >> 8) % nt4);
     const int s = (int)((i >> 8) / nt4);
-    const int f = 32 * (4 * q4 + q) + (lane & 31);
-    const int kk = 8 * (s >> 2) + 4 * (lane >> 5) + (s & 3);
+    const int f = 16 * (4 * b4 + ti) + (lane & 15);
+    const int kk = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
     out[i] = (f < n_out && kk < kseg) ? w[(size_t)f * k_total + k_lo + kk] : 0.f;
   }
 }
@@ -553,8 +521,8 @@ const char* gw_last_error(void) { return g_err; }
 
 size_t gw_packed_floats(int n_out, int k_lo, int k_hi) {
   const int kseg = k_hi - k_lo;
-  const int nsteps = ((kseg + 7) / 8) * 4;
-  const int nt = (n_out + 31) / 32;
+  const int nsteps = ((kseg + 15) / 16) * 4;
+  const int nt = (n_out + 15) / 16;
   const int nt4 = (nt + 3) / 4;
   return (size_t)nsteps * nt4 * 256;
 }
@@ -562,8 +530,8 @@ size_t gw_packed_floats(int n_out, int k_lo, int k_hi) {
 int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, float* out, void* stream) {
   if (!w || !out || n_out <= 0 || k_lo < 0 || k_hi <= k_lo || k_hi > k_total) return fail(GW_E_BADARG, "gw_pack_linear: bad arguments");
   const int kseg = k_hi - k_lo;
-  const int nsteps = ((kseg + 7) / 8) * 4;
-  const int nt4 = (((n_out + 31) / 32) + 3) / 4;
+  const int nsteps = ((kseg + 15) / 16) * 4;
+  const int nt4 = (((n_out + 15) / 16) + 3) / 4;
   const size_t total = (size_t)nsteps * nt4 * 256;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
@@ -605,13 +573,13 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   if (w->hidden == 256 && w->n_out == 256) {
     if (residual && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
     if (out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
-    if (x->k <= 8) return launch_chain(chain_kernel<4, false, 1, 8, 8, EPI_ROWS>, a, stream);
-    if (x->k <= 104) return launch_chain(chain_kernel<52, false, 1, 8, 8, EPI_ROWS>, a, stream);
-    if (x->k == 256 && x->ld % 4 == 0) return launch_chain(chain_kernel<128, true, 1, 8, 8, EPI_ROWS>, a, stream);
-    return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=104 or ==256 for hidden 256");
+    if (x->k <= 16) return launch_chain(chain_kernel<4, false, 1, 16, 16, EPI_ROWS>, a, stream);
+    if (x->k <= 112) return launch_chain(chain_kernel<28, false, 1, 16, 16, EPI_ROWS>, a, stream);
+    if (x->k == 256 && x->ld % 4 == 0) return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS>, a, stream);
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=112 or ==256 for hidden 256");
   }
-  if (w->hidden == 128 && w->n_out <= 96 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
-    return launch_chain(chain_kernel<128, true, 1, 4, 3, EPI_DEC>, a, stream);
+  if (w->hidden == 128 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
+    return launch_chain(chain_kernel<64, true, 1, 8, 5, EPI_DEC>, a, stream);
   }
   return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: unsupported (hidden, n_out, k) combination");
 }
@@ -651,7 +619,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg = agg;
   a.agg_idx = dst;
   a.agg_rows_pb = n_dst;
-  return launch_chain(chain_kernel<128, true, 3, 8, 8, EPI_EDGE>, a, stream);
+  return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream);
 }
 
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
@@ -676,7 +644,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.out = x_out;
   a.out_ld = out_ld;
   a.out_cols = 256;
-  return launch_chain(chain_kernel<128, true, 2, 8, 8, EPI_ROWS>, a, stream);
+  return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream);
 }
 
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
@@ -698,7 +666,7 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   }
   a.out_ld = out_ld;
   a.out_cols = 256;
-  return launch_chain(chain_kernel<128, true, 1, 8, 8, EPI_ROWS, true>, a, stream, n_slices);
+  return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices);
 }
 
 int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,

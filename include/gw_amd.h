@@ -39,7 +39,7 @@ const char* gw_last_error(void);
 
 /* ---- weight packing ------------------------------------------------------------------------------------
  * Packed size in floats of the [k_lo, k_hi) column slice of an nn.Linear weight with `n_out` rows, padded to
- * 32-row tiles / 8-column groups (graph_net_block.py:45-49 creates the Linear layers being packed). */
+ * 16-row tiles / 16-column groups (graph_net_block.py:45-49 creates the Linear layers being packed). */
 size_t gw_packed_floats(int n_out, int k_lo, int k_hi);
 /* w: device pointer to [n_out, k_total] fp32 (nn.Linear.weight); out: gw_packed_floats() floats. */
 int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, float* out, void* stream);
@@ -71,14 +71,14 @@ typedef struct gw_mlp_weights {
   const float* ln_beta;
   int32_t hidden;      /* 128 or 256 */
   int32_t n_mid;       /* hidden_layers - 1 */
-  int32_t n_out;       /* 256, or <= 96 for the decoder head */
+  int32_t n_out;       /* 256, or <= 80 for the decoder head */
 } gw_mlp_weights;
 
 /* ---- MLP.forward (graph_net_block.py:63-77) applied to rows --------------------------------------------
  * y[c, :] = MLP(x[c, :k]) (+ residual[c, :n_out]);   c in [0, n_rows).
  * Used for Encoder.node_encoder (encoder.py:205), the three edge encoders (encoder.py:206-208,235-241,
  * assimilator_decoder.py:175-177) and AssimilatorDecoder.node_decoder + the Decoder residual
- * (assimilator_decoder.py:197, decoder.py:93).  Supported k: <= 8, <= 104, or exactly 256. */
+ * (assimilator_decoder.py:197, decoder.py:93).  Supported k: <= 16, <= 112, or exactly 256. */
 int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
                    const gw_operand* residual /* may be NULL */, float* out, int32_t out_ld, void* stream);
 

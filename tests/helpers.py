@@ -42,44 +42,44 @@ def make_params(shapes, seed: int = 0) -> Dict[str, torch.Tensor]:
     return p
 
 
-def k_of(s: int, h: int) -> int:
-    """K walk order of the kernels: step s, lane half h -> input feature index."""
-    return 8 * (s >> 2) + 4 * h + (s & 3)
+def k_of(s: int, q: int) -> int:
+    """K walk order of the kernels: step s, lane quarter q -> input feature index."""
+    return 16 * (s >> 2) + 4 * q + (s & 3)
 
 
 def pack_linear_ref(w: np.ndarray, k_lo: int, k_hi: int) -> np.ndarray:
-    """numpy statement of gw_pack_linear's layout: out[s][q4][lane][q]."""
+    """numpy statement of gw_pack_linear's layout: out[s][b4][lane][i]."""
     n_out = w.shape[0]
     kseg = k_hi - k_lo
-    nsteps = ((kseg + 7) // 8) * 4
-    nt = (n_out + 31) // 32
+    nsteps = ((kseg + 15) // 16) * 4
+    nt = (n_out + 15) // 16
     nt4 = (nt + 3) // 4
     out = np.zeros((nsteps, nt4, 64, 4), dtype=np.float32)
     for s in range(nsteps):
         for lane in range(64):
-            kk = k_of(s, lane >> 5)
+            kk = k_of(s, lane >> 4)
             if kk >= kseg:
                 continue
-            for q4 in range(nt4):
-                for q in range(4):
-                    f = 32 * (4 * q4 + q) + (lane & 31)
+            for b4 in range(nt4):
+                for i in range(4):
+                    f = 16 * (4 * b4 + i) + (lane & 15)
                     if f < n_out:
-                        out[s, q4, lane, q] = w[f, k_lo + kk]
+                        out[s, b4, lane, i] = w[f, k_lo + kk]
     return out
 
 
-def mfma_32x32x2_emulate(a_lane: np.ndarray, b_lane: np.ndarray, acc: np.ndarray) -> np.ndarray:
-    """v_mfma_f32_32x32x2_f32 with the documented operand layouts (cdna_hip_programming.md section 3):
-    A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31], D col=lane&31, row=(r&3)+8*(r>>2)+4*(lane>>5).
-    a_lane, b_lane: [64]; acc: [16, 64] (register r, lane)."""
-    A = np.zeros((32, 2))
-    B = np.zeros((2, 32))
+def mfma_16x16x4_emulate(a_lane: np.ndarray, b_lane: np.ndarray, acc: np.ndarray) -> np.ndarray:
+    """v_mfma_f32_16x16x4_f32 with the documented operand layouts (cdna_hip_programming.md section 3):
+    A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D col=lane&15, row=4*(lane>>4)+r.
+    a_lane, b_lane: [64]; acc: [4, 64] (register r, lane)."""
+    A = np.zeros((16, 4))
+    B = np.zeros((4, 16))
     for lane in range(64):
-        A[lane & 31, lane >> 5] = a_lane[lane]
-        B[lane >> 5, lane & 31] = b_lane[lane]
+        A[lane & 15, lane >> 4] = a_lane[lane]
+        B[lane >> 4, lane & 15] = b_lane[lane]
     D = A @ B
     out = acc.copy()
     for lane in range(64):
-        for r in range(16):
-            out[r, lane] += D[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+        for r in range(4):
+            out[r, lane] += D[4 * (lane >> 4) + r, lane & 15]
     return out

@@ -28,8 +28,8 @@ def test_library_builds_loads_and_exports_header_symbols():
     L = _lib.lib()
     assert L.gw_version() == 1
     assert L.gw_packed_floats(256, 0, 256) == 256 * 256
-    assert L.gw_packed_floats(78, 0, 128) == 64 * 1 * 256
-    assert L.gw_packed_floats(256, 0, 102) == 52 * 2 * 256
+    assert L.gw_packed_floats(78, 0, 128) == 32 * 2 * 256
+    assert L.gw_packed_floats(256, 0, 102) == 28 * 4 * 256
     assert L.gw_padded_n(78) == 96
 
 
