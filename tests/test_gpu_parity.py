@@ -176,7 +176,7 @@ def test_efficient_batching_api_equals_replicated():
     x_r, ei_r, ea_r = enc(feats)
     enc.efficient_batching = True
     x_e, ei_e, ea_e = enc(feats)
-    assert torch.equal(x_r, x_e)
+    _close(x_r, x_e, rel=1e-6, what="encoder replicated vs shared API (atomics order only)")
     assert ei_r.shape[1] == 2 * ei_e.shape[1] and ea_r.shape[0] == 2 * ea_e.shape[0]
     proc = gw.Processor()
     deterministic_fill_(proc, seed=6)
