@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/gw_amd.h"
@@ -39,6 +40,7 @@ enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
 struct ChainArgs {
   int n_cols;          // total columns (batch * cols_per_batch)
   int cols_per_batch;
+  int stagger;         // start-up delay (x 8k cycles) of every second wave of workgroups, see chain_kernel
   // layer-1 operands
   const float* seg_ptr[3];
   const int* seg_idx[3];
@@ -237,6 +239,14 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   const int b = c / a.cols_per_batch;
   const int k = c - b * a.cols_per_batch;
 
+  // Two workgroups share a CU (2 waves per SIMD).  Dispatched together and doing identical work they would run
+  // in lockstep - both gathering, then both queueing on the matrix pipe - so neither hides the other's memory
+  // phase (measured: MFMA busy 57 %).  Delaying the second batch of 256 workgroups by about half a tile puts the
+  // pair on each CU in anti-phase: one gathers / normalises / scatters while the other owns the matrix pipe.
+  if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   // ---- weight-stream schedule (wave uniform) ----
   // on[i]: operand i takes part in an MFMA pass (raw rows);  prj[i]: operand i is pre-projected (gather-add only)
   bool on[3], prj[3];
@@ -293,6 +303,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   }
 
   f32x4 o[OT];
+  f32x4 rres[OT];  // residual rows (prefetched during the last pass)
   if constexpr (SINGLE) {
     static_assert(!SINGLE || HT == OT, "single-layer mode stores the layer-1 accumulator");
 #pragma unroll
@@ -313,6 +324,12 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     // ---- output layer ----
     relu_to_in<HT>(hin, acc);
     init_bias<OT>(o, a.b_out, q);
+    if (EPI != EPI_DEC && a.res_ptr != nullptr) {
+      // the layer-1 / hidden accumulators are dead now: fetch the residual rows underneath the last pass
+      const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
+#pragma unroll
+      for (int t = 0; t < OT; ++t) rres[t] = ldg4(rrow + 16 * t + 4 * q);
+    }
     mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
   }
 
@@ -347,17 +364,18 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 
   // ---- residual ----
   if (!SINGLE && a.res_ptr != nullptr) {
-    const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
+    if (EPI == EPI_DEC) {
+      const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
 #pragma unroll
-    for (int t = 0; t < OT; ++t) {
-      const int f0 = 16 * t + 4 * q;
-      if (EPI == EPI_DEC) {
+      for (int t = 0; t < OT; ++t) {
+        const int f0 = 16 * t + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (f0 + r < a.out_cols) o[t][r] += ldg1(rrow + f0 + r);
-      } else {
-        o[t] += ldg4(rrow + f0);
       }
+    } else {
+#pragma unroll
+      for (int t = 0; t < OT; ++t) o[t] += rres[t];
     }
   }
 
@@ -470,8 +488,23 @@ int check_launch(const char* what) {
   return GW_OK;
 }
 
+int g_stagger_override = -1;  // GW_STAGGER env (tuning): -1 = automatic
+
 template <typename K>
-int launch_chain(K kernel, const ChainArgs& a, void* stream, int grid_y = 1) {
+int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1) {
+  {
+    static bool env_read = false;
+    if (!env_read) {
+      const char* e = getenv("GW_STAGGER");
+      if (e) g_stagger_override = atoi(e);
+      env_read = true;
+    }
+    // number of 256-K passes this launch runs per tile -> about half a tile of delay (8k-cycle sleeps)
+    int passes = 1 + a.n_mid;
+    for (int i = 0; i < 3; ++i) passes += (a.seg_k[i] > 0 && !a.seg_proj[i]) ? 1 : 0;
+    a.stagger = g_stagger_override >= 0 ? g_stagger_override * passes : 2 * passes + 2;
+    if ((a.n_cols + kColsPerWG - 1) / kColsPerWG <= 256) a.stagger = 0;
+  }
   static bool attr_done = false;  // per template instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
