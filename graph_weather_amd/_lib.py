@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
 EXPORTS = [
-    "gw_version", "gw_last_error", "gw_packed_floats", "gw_pack_linear", "gw_padded_n", "gw_pad_vector",
+    "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_padded_n", "gw_pad_vector",
     "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_node_update_forward",
     "gw_normalized_mse_forward",
 ]
@@ -61,6 +61,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.gw_version.restype = c_int
     L.gw_last_error.restype = c_char_p
+    L.gw_debug_timestamps.restype = c_int
+    L.gw_debug_timestamps.argtypes = [c_void_p, c_int, c_int]
     L.gw_packed_floats.restype = c_size_t
     L.gw_packed_floats.argtypes = [c_int, c_int, c_int]
     L.gw_pack_linear.restype = c_int

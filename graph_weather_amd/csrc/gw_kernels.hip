@@ -40,6 +40,8 @@ enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
 struct ChainArgs {
   int n_cols;          // total columns (batch * cols_per_batch)
   int cols_per_batch;
+  unsigned long long* dbg;  // optional per-workgroup timestamp records (16 x u64 each), debug only
+  int dbg_cap;
   int stagger;         // start-up delay (x 8k cycles) of every second wave of workgroups, see chain_kernel
   // layer-1 operands
   const float* seg_ptr[3];
@@ -76,6 +78,13 @@ struct ChainArgs {
 };
 
 #define GW_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ unsigned long long gw_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define GW_STAMP(i) \
+  if (a.dbg != nullptr) { ts[i] = gw_clock(); }
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const GW_AS1 f32x4*)p; }
 __device__ __forceinline__ float ldg1(const float* p) { return *(const GW_AS1 float*)p; }
 __device__ __forceinline__ int ldgi(const int* p) { return *(const GW_AS1 int*)p; }
@@ -247,6 +256,9 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  GW_STAMP(0)
+
   // ---- weight-stream schedule (wave uniform) ----
   // on[i]: operand i takes part in an MFMA pass (raw rows);  prj[i]: operand i is pre-projected (gather-add only)
   bool on[3], prj[3];
@@ -283,6 +295,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
     for (int i = 0; i < NSEG; ++i)
       if (prj[i]) add_projected<HT>(acc, row[i], q);
+    GW_STAMP(1)
     constexpr bool RL = K1FULL && (NSEG > 1);
     bool tail_pending = false;  // the current operand's last register slice still has to be gathered
     if (on[0]) {
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
       mma_pass<K1S, HT, RL>(acc, x, w1[2], after_l1, after_l1_floats, lds, parity, lane, wave, row[2], tail_pending, nullptr, false, q);
   }
 
+  GW_STAMP(2)
   f32x4 o[OT];
   f32x4 rres[OT];  // residual rows (prefetched during the last pass)
   if constexpr (SINGLE) {
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
       mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
     }
 
+    GW_STAMP(3)
     // ---- output layer ----
     relu_to_in<HT>(hin, acc);
     init_bias<OT>(o, a.b_out, q);
@@ -333,6 +348,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
   }
 
+  GW_STAMP(4)
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance) ----
   if (!SINGLE && a.gamma != nullptr) {
     constexpr float inv_n = 1.0f / (OT * 16);
@@ -396,6 +412,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     }
   }
 
+  GW_STAMP(5)
   // ---- segment sum over destination-sorted columns: shuffle scan + one atomicAdd per segment tail ----
   if (EPI == EPI_EDGE) {
     const int gd = valid ? (b * a.agg_rows_pb + ldgi(a.agg_idx + k)) : (-1 - j);
@@ -420,6 +437,17 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           __hip_atomic_fetch_add((GW_AS1 float*)(arow + 16 * t + 4 * q + r), o[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (a.dbg != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = gw_clock();
+    if (threadIdx.x == 0 && (int)blockIdx.x < a.dbg_cap && blockIdx.y == 0) {
+      unsigned long long* rec = a.dbg + (size_t)blockIdx.x * 16;
+      for (int i = 0; i < 7; ++i) rec[i] = ts[i];
+      rec[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+      rec[9] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID
+      rec[10] = blockIdx.x;
     }
   }
 }
@@ -488,10 +516,17 @@ int check_launch(const char* what) {
   return GW_OK;
 }
 
-int g_stagger_override = -1;  // GW_STAGGER env (tuning): -1 = automatic
+int g_stagger_override = -1;
+unsigned long long* g_dbg = nullptr;
+int g_dbg_cap = 0;
+int g_dbg_kind = -1;  // which launch family to stamp: 0 mlp, 1 edge, 2 node, 3 project  // GW_STAGGER env (tuning): -1 = automatic
 
 template <typename K>
-int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1) {
+int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1, int kind = 0) {
+  if (g_dbg != nullptr && kind == g_dbg_kind) {
+    a.dbg = g_dbg;
+    a.dbg_cap = g_dbg_cap;
+  }
   {
     static bool env_read = false;
     if (!env_read) {
@@ -550,6 +585,13 @@ bool bad256(const gw_operand* op) { return op->k != 256 || op->ld % 4 != 0 || !o
 extern "C" {
 
 int gw_version(void) { return GW_ABI_VERSION; }
+
+int gw_debug_timestamps(void* buffer, int capacity_workgroups, int kind) {
+  g_dbg = (unsigned long long*)buffer;
+  g_dbg_cap = capacity_workgroups;
+  g_dbg_kind = kind;
+  return GW_OK;
+}
 const char* gw_last_error(void) { return g_err; }
 
 size_t gw_packed_floats(int n_out, int k_lo, int k_hi) {
@@ -652,7 +694,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg = agg;
   a.agg_idx = dst;
   a.agg_rows_pb = n_dst;
-  return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream);
+  return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream, 1, 1);
 }
 
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
@@ -677,7 +719,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.out = x_out;
   a.out_ld = out_ld;
   a.out_cols = 256;
-  return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream);
+  return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }
 
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
@@ -699,7 +741,7 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   }
   a.out_ld = out_ld;
   a.out_cols = 256;
-  return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices);
+  return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices, 3);
 }
 
 int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,

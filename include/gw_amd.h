@@ -36,6 +36,10 @@ extern "C" {
 /* Library / ABI version and last error text (thread local). */
 int gw_version(void);
 const char* gw_last_error(void);
+/* Debug/profiling aid (no reference counterpart): while `buffer` != NULL, launches of family `kind` (0 mlp, 1 edge
+ * update, 2 node update, 3 project) write 16 x uint64 per workgroup: s_memtime stamps of the kernel phases [0..6],
+ * HW_ID [8], XCC_ID [9], block index [10].  buffer: device memory, capacity_workgroups * 16 * 8 bytes. */
+int gw_debug_timestamps(void* buffer, int capacity_workgroups, int kind);
 
 /* ---- weight packing ------------------------------------------------------------------------------------
  * Packed size in floats of the [k_lo, k_hi) column slice of an nn.Linear weight with `n_out` rows, padded to

@@ -4,6 +4,7 @@
 TAG=$1; VAR=$2; shift 2
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1 || echo BUILD FAILED
 for v in "$@"; do
   env $VAR=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_${VAR}_$v.log 2>&1
   python - "$OUT/bench_${VAR}_$v.log" "$VAR=$v" <<'PY'
@@ -17,3 +18,4 @@ else:
     print(sys.argv[2], "FAILED"); print(open(sys.argv[1]).read()[-800:])
 PY
 done
+if [ -n "$TIMELINE" ]; then python scripts/gpu_timeline.py $OUT/timeline_dec.npy 1; fi
