@@ -180,6 +180,73 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[NT], float (&in)[NSTEPS], 
   }
 }
 
+// First pass after layer 1.  Its B operand is relu(layer-1 accumulator + gathered pre-projected operand rows),
+// and it is *produced slice by slice*: chunk c only needs hidden features 32c..32c+31, i.e. accumulator tiles 2c,
+// 2c+1 plus the matching 2 x 16-byte pieces of each projected row.  The pieces for slice c+1 are requested while
+// chunk c computes, so the per-edge gathers (1 KiB per operand and column) stream in underneath the MFMAs instead
+// of forming a serial prologue (measured: 38k of 209k cycles per tile in the decoder edge update).
+template <int HTI, int NT>
+__device__ __forceinline__ void mma_pass_produce(f32x4 (&acc)[NT], const f32x4 (&src)[HTI], f32x4 (&tmp)[3][2],
+                                                 const float* __restrict__ prow0, const float* __restrict__ prow1,
+                                                 const float* __restrict__ prow2, bool p0, bool p1, bool p2,
+                                                 const float* __restrict__ gw, const float* __restrict__ next_gw,
+                                                 int next_floats, float* lds, int& parity, int lane, int wave, int q) {
+  constexpr int NT4 = (NT + 3) / 4;
+  constexpr int STEPF = NT4 * 256;
+  constexpr int NCH = HTI / 2;  // 8 K-steps (two 16-feature tiles) per chunk
+  static_assert(HTI % 2 == 0 && kChunkSteps == 8, "slice = one chunk = two accumulator tiles");
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* other = lds + (parity ^ 1) * kLdsBufFloats;
+    if (c + 1 < NCH) {
+      issue_chunk(gw + (size_t)(c + 1) * kChunkSteps * STEPF, kChunkSteps * STEPF, other, lane, wave);
+    } else if (next_gw != nullptr) {
+      issue_chunk(next_gw, next_floats, other, lane, wave);
+    }
+    f32x4 v0 = src[2 * c], v1 = src[2 * c + 1];
+    if (p0) { v0 += tmp[0][0]; v1 += tmp[0][1]; }
+    if (p1) { v0 += tmp[1][0]; v1 += tmp[1][1]; }
+    if (p2) { v0 += tmp[2][0]; v1 += tmp[2][1]; }
+    float in8[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      in8[r] = fmaxf(v0[r], 0.f);
+      in8[4 + r] = fmaxf(v1[r], 0.f);
+    }
+    if (c + 1 < NCH) {
+      const int f0 = 16 * (2 * c + 2) + 4 * q;
+      if (p0) { tmp[0][0] = ldg4(prow0 + f0); tmp[0][1] = ldg4(prow0 + f0 + 16); }
+      if (p1) { tmp[1][0] = ldg4(prow1 + f0); tmp[1][1] = ldg4(prow1 + f0 + 16); }
+      if (p2) { tmp[2][0] = ldg4(prow2 + f0); tmp[2][1] = ldg4(prow2 + f0 + 16); }
+    }
+    const float* buf = lds + parity * kLdsBufFloats + lane * 4;
+    f32x4 a_cur[NT4];
+#pragma unroll
+    for (int b4 = 0; b4 < NT4; ++b4) a_cur[b4] = *(const f32x4*)(buf + b4 * 256);
+#pragma unroll
+    for (int s = 0; s < kChunkSteps; ++s) {
+      f32x4 a_nxt[NT4];
+      if (s + 1 < kChunkSteps) {
+#pragma unroll
+        for (int b4 = 0; b4 < NT4; ++b4) a_nxt[b4] = *(const f32x4*)(buf + (s + 1) * STEPF + b4 * 256);
+      }
+      const float b = in8[s];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < kChunkSteps) {
+#pragma unroll
+        for (int b4 = 0; b4 < NT4; ++b4) a_cur[b4] = a_nxt[b4];
+      }
+    }
+    parity ^= 1;
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* __restrict__ bias, int q) {
   if (bias == nullptr) {
@@ -281,6 +348,8 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 
   // ---- layer 1 ----
   f32x4 acc[HT];
+  f32x4 ptmp[3][2];
+  const float* prow[3] = {nullptr, nullptr, nullptr};
   {
     const float* row[3] = {nullptr, nullptr, nullptr};
 #pragma unroll
@@ -292,9 +361,17 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
       if (on[0] || on[1] || on[2]) load_operand<K1S, K1FULL>(x, row[f], a.seg_k[f], q);
     }
     init_bias<HT>(acc, a.b1, q);
+    if (!SINGLE) {
+      // first 32-feature slice of every pre-projected operand (the rest streams in during the first hidden pass)
 #pragma unroll
-    for (int i = 0; i < NSEG; ++i)
-      if (prj[i]) add_projected<HT>(acc, row[i], q);
+      for (int i = 0; i < NSEG; ++i) {
+        prow[i] = row[i];
+        if (prj[i]) {
+          ptmp[i][0] = ldg4(row[i] + 4 * q);
+          ptmp[i][1] = ldg4(row[i] + 16 + 4 * q);
+        }
+      }
+    }
     GW_STAMP(1)
     constexpr bool RL = K1FULL && (NSEG > 1);
     bool tail_pending = false;  // the current operand's last register slice still has to be gathered
@@ -323,29 +400,40 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
     for (int t = 0; t < OT; ++t) o[t] = acc[t < HT ? t : 0];
   } else {
-    // ---- middle layers (hidden -> hidden) ----
-    float hin[HS];
+    {
+      // ---- first middle layer (n_mid >= 1 is checked on the host): input produced slice by slice from the layer-1 accumulator ----
+      f32x4 acc2[HT];
+      init_bias<HT>(acc2, a.b_mid, q);
+      {
+        const bool last = (a.n_mid == 1);
+        const float* nx = last ? a.w_out : a.w_mid + (size_t)HS * HSTEPF;
+        const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
+        mma_pass_produce<HT, HT>(acc2, acc, ptmp, prow[0], prow[1], prow[2], prj[0], prj[1], prj[2], a.w_mid, nx, nf, lds,
+                                 parity, lane, wave, q);
+      }
+      // ---- further middle layers (hidden -> hidden) ----
+      float hin[HS];
 #pragma unroll 1
-    for (int l = 0; l < a.n_mid; ++l) {
-      relu_to_in<HT>(hin, acc);
-      init_bias<HT>(acc, a.b_mid + l * (HT * 16), q);
-      const bool last = (l + 1 == a.n_mid);
-      const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
-      const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
-      mma_pass<HS, HT, false>(acc, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
-    }
-
-    GW_STAMP(3)
-    // ---- output layer ----
-    relu_to_in<HT>(hin, acc);
-    init_bias<OT>(o, a.b_out, q);
-    if (EPI != EPI_DEC && a.res_ptr != nullptr) {
-      // the layer-1 / hidden accumulators are dead now: fetch the residual rows underneath the last pass
-      const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
+      for (int l = 1; l < a.n_mid; ++l) {
+        relu_to_in<HT>(hin, acc2);
+        init_bias<HT>(acc2, a.b_mid + l * (HT * 16), q);
+        const bool last = (l + 1 == a.n_mid);
+        const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
+        const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
+        mma_pass<HS, HT, false>(acc2, hin, a.w_mid + (size_t)l * HS * HSTEPF, nx, nf, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
+      }
+      GW_STAMP(3)
+      // ---- output layer ----
+      relu_to_in<HT>(hin, acc2);
+      init_bias<OT>(o, a.b_out, q);
+      if (EPI != EPI_DEC && a.res_ptr != nullptr) {
+        // fetch the residual rows underneath the last pass
+        const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
 #pragma unroll
-      for (int t = 0; t < OT; ++t) rres[t] = ldg4(rrow + 16 * t + 4 * q);
+        for (int t = 0; t < OT; ++t) rres[t] = ldg4(rrow + 16 * t + 4 * q);
+      }
+      mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
     }
-    mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
   }
 
   GW_STAMP(4)
@@ -550,6 +638,8 @@ int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1, int kind 
   return check_launch("chain_kernel launch");
 }
 
+bool bad_layers(const gw_mlp_weights* w) { return w->n_mid < 1 || !w->w_mid || !w->b_mid; }
+
 void fill_weights(ChainArgs& a, const gw_mlp_weights* w) {
   for (int i = 0; i < 3; ++i) a.w1[i] = w->w1[i];
   a.b1 = w->b1;
@@ -628,8 +718,9 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   if (!x || !w || !out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_mlp_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: more than 2^31-1 rows");
-  if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out || (w->n_mid > 0 && (!w->w_mid || !w->b_mid)))
+  if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out)
     return fail(GW_E_BADARG, "gw_mlp_forward: missing weights / empty operand");
+  if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: at least 2 hidden layers (n_mid >= 1) are required");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = (int)n_rows;
@@ -670,6 +761,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: batch*edges exceeds int32");
   if (w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || !w->ln_beta || !w->b1 || !w->w_out || !w->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: only hidden=256, out=256, LayerNorm is implemented");
+  if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: at least 2 hidden layers (n_mid >= 1) are required");
   const gw_operand* ops[3] = {x_src, x_dst, e_in};
   for (int i = 0; i < 3; ++i) {
     if (ops[i]->k == 0) continue;
@@ -704,6 +796,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: more than 2^31-1 rows");
   if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: only hidden=256, out=256");
+  if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: at least 2 hidden layers (n_mid >= 1) are required");
   if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide (raw)");
   if (x->k != 0 && (bad256(x) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide or zeros");
   if (x_res && x_res->k != 0 && bad256(x_res)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x_res must be 256 wide");
