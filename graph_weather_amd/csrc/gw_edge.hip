@@ -1,0 +1,572 @@
+// gw_edge.hip - the edge-update kernel of the hot path, specialised for what the forecaster actually launches.
+//
+// EdgeProcessor.forward + scatter_sum (reference graph_net_block.py:131-137 and :188) for destination-sorted edges:
+//     e' = LN(W_out . relu(W_mid . relu(b1 + [W_raw . raw] + sum_p P_p[row_p]) + b_mid) + b_out) + e_res
+//     agg[dst] += e'
+// After the layer-1 split every launch of the forecaster has AT MOST ONE operand that still
+// needs a matrix pass in layer 1 (the per-sample edge features in processor blocks 1..8, the grid-node features in
+// the encoder); the others are per-node / per-edge products that are only gathered and added.  Compared with the
+// general chain_kernel this kernel
+//   * keeps the gathered rows of the projected operands in a two-chunk-deep register ring, requested two weight
+//     chunks ahead and left in flight across the chunk barrier (s_waitcnt vmcnt(N) instead of vmcnt(0)),
+//   * needs no layer-1 accumulator at all when nothing is raw (decoder, first processor block),
+//   * stages e' through LDS (the weight buffers are free by then) so that the rows of e_out are written with one
+//     fully coalesced 1 KiB store per row and the segment sum runs with one thread per feature: interior
+//     destination runs of a tile become plain coalesced stores, only the first and last run of a tile use
+//     (row-coalesced) atomics.
+// Same register-resident transposed-MLP scheme and weight stream as chain_kernel (gw_kernels.hip).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "gw_device.hpp"
+#include "gw_internal.hpp"
+
+using namespace gw;
+
+namespace {
+
+constexpr int kStageLd = 260;                                  // floats per staged row: 65 x 16 B -> conflict-free b128 writes
+constexpr int kStageFloats = kColsPerWG * kStageLd;            // 64 rows
+constexpr int kEdgeLdsBytes = (kStageFloats + kColsPerWG) * 4;  // staging (overlays the 64 KiB weight buffers) + 64 dst ids
+static_assert(kStageFloats * 4 >= kLdsBytes, "staging area must cover the weight double buffer");
+constexpr int kChunkFloats = kChunkSteps * 1024;               // one weight chunk: 8 K-steps x 256 rows x 4 k = 32 KiB
+constexpr int kChunksPerLayer = 64 / kChunkSteps;              // K = 256
+
+struct EdgeArgs {
+  int n_cols;  // batch * n_edges
+  int n_edges;
+  int n_dst;
+  int stagger;
+  unsigned long long* dbg;
+  int dbg_cap;
+  const int* src;
+  const int* dst;
+  // raw operand (RAW kernels): full 256-float rows, multiplied by w_raw on the matrix cores
+  const float* raw_ptr;
+  int raw_rows_pb;
+  int raw_ld;
+  int raw_kind;  // 0: row = src[k], 1: dst[k], 2: k
+  const float* w_raw;
+  // projected operands: rows already hold X . W1_slice^T, gathered and added
+  const float* p_ptr[3];
+  int p_rows_pb[3];
+  int p_ld[3];
+  int p_kind[3];
+  // weights
+  const float* b1;
+  const float* w_mid;
+  const float* b_mid;
+  int n_mid;
+  const float* w_out;
+  const float* b_out;
+  const float* gamma;
+  const float* beta;
+  // residual e rows (indexed by edge), outputs
+  const float* res_ptr;
+  int res_rows_pb;
+  int res_ld;
+  float* e_out;
+  float* agg;
+};
+
+// One weight chunk: acc[t] += W[16t.., k(s)] * in[s] for the 8 K-steps of the chunk (16 row tiles).
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[16], const float (&in8)[8], const float* buf_lane) {
+  f32x4 a_cur[4];
+#pragma unroll
+  for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = *(const f32x4*)(buf_lane + b4 * 256);
+#pragma unroll
+  for (int s = 0; s < kChunkSteps; ++s) {
+    f32x4 a_nxt[4];
+    if (s + 1 < kChunkSteps) {
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) a_nxt[b4] = *(const f32x4*)(buf_lane + (s + 1) * 1024 + b4 * 256);
+    }
+    const float b = in8[s];
+    __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of step s+1 ahead of the MFMAs of step s
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < kChunkSteps) {
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = a_nxt[b4];
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- loads hipcc must not count -------------------------------------------------------------------------------
+// global_load_lds is a FLAT-class instruction: while one is pending in hipcc's model, every s_waitcnt it generates
+// for a VMEM result is vmcnt(0) - which would drain the weight DMA of the NEXT chunk each time a gathered register is
+// first used.  The loads whose results are consumed inside the chunk loops are therefore issued from asm statements
+// (invisible to that bookkeeping) and completed by explicit counted waits that name their destination registers
+// ("+v"), so no consumer can be scheduled above the wait (cdna_hip_programming.md 5.7, form ii).
+template <int OFF>
+__device__ __forceinline__ f32x4 hld4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "i"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ int hldi(const int* p) {
+  int v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_regs(int& a, int& b) {
+  asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b) : [n] "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_regs(f32x4 (&r)[1][2]) {
+  asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(r[0][0]), "+v"(r[0][1]) : [n] "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_regs(f32x4 (&r)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]) : [n] "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_regs(f32x4 (&r)[3][2]) {
+  asm volatile("s_waitcnt vmcnt(%[n])"
+               : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[2][0]), "+v"(r[2][1])
+               : [n] "n"(N)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_regs(f32x4 (&r)[4][2]) {
+  asm volatile("s_waitcnt vmcnt(%[n])"
+               : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[2][0]), "+v"(r[2][1]), "+v"(r[3][0]),
+                 "+v"(r[3][1])
+               : [n] "n"(N)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_regs(f32x4 (&r)[16]) {
+  asm volatile("s_waitcnt vmcnt(%[n])"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                 "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+               : [n] "n"(N)
+               : "memory");
+}
+// 16 x 16 B of one 256-float row (accumulator layout: tile t at +16t floats; p already includes the 4q lane offset)
+__device__ __forceinline__ void hld_row(f32x4 (&r)[16], const float* p) {
+  r[0] = hld4<0>(p);     r[1] = hld4<64>(p);    r[2] = hld4<128>(p);   r[3] = hld4<192>(p);
+  r[4] = hld4<256>(p);   r[5] = hld4<320>(p);   r[6] = hld4<384>(p);   r[7] = hld4<448>(p);
+  r[8] = hld4<512>(p);   r[9] = hld4<576>(p);   r[10] = hld4<640>(p);  r[11] = hld4<704>(p);
+  r[12] = hld4<768>(p);  r[13] = hld4<832>(p);  r[14] = hld4<896>(p);  r[15] = hld4<960>(p);
+}
+
+// Workgroup barrier for the LDS weight ring.  __syncthreads() carries a workgroup-scope release fence, which hipcc
+// lowers to s_waitcnt vmcnt(0): that would drain the gathers this kernel deliberately keeps in flight.  Here only
+// LDS traffic has to be ordered: this wave's LDS reads are complete (lgkmcnt(0)) and its share of the weight DMA
+// has landed (the caller's counted wait) before it arrives.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Each wave DMAs its 8 KiB share of one 32 KiB weight chunk into an LDS buffer: exactly 8 x global_load_lds (1 KiB
+// each), no branches - the vmcnt(N) bookkeeping of the kernel counts on that.
+__device__ __forceinline__ void issue_chunk32k(const float* __restrict__ g, float* ldsbuf, int lane, int wave) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = wave + 4 * i;
+    glds16(g + (size_t)p * 256 + lane * 4, ldsbuf + p * 256);
+  }
+}
+
+template <bool RAW, int NPROJ>
+__global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const int tile_c0 = blockIdx.x * kColsPerWG;
+  const int c_raw = tile_c0 + wave * kColsPerWave + j;
+  const bool valid = c_raw < a.n_cols;
+  const int c = valid ? c_raw : a.n_cols - 1;
+  const int b = c / a.n_edges;
+  const int k = c - b * a.n_edges;
+
+  // anti-phase start of the second batch of workgroups (see chain_kernel)
+  if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  GW_STAMP(0)
+
+  // ---- indices, then the first weight chunk; weight stream = [w_raw] w_mid x n_mid, w_out, chunk i in buffer i & 1 ----
+  int s_idx = hldi(a.src + k);
+  int d_idx = hldi(a.dst + k);
+  issue_chunk32k(RAW ? a.w_raw : a.w_mid, lds, lane, wave);
+  int ci = 0;  // chunk counter of this tile (wave uniform)
+  wait_regs<8>(s_idx, d_idx);  // the 8 DMA pieces stay in flight
+
+  const float* prow[NPROJ];
+#pragma unroll
+  for (int p = 0; p < NPROJ; ++p) {
+    const int r = a.p_kind[p] == 0 ? s_idx : (a.p_kind[p] == 1 ? d_idx : k);
+    prow[p] = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
+  }
+  const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)k) * (size_t)a.res_ld + 4 * q;
+
+  // ring[c & 1][p][h]: features 32c + 16h + 4q .. +3 of projected operand p (the B-operand slice of produce chunk c).
+  // When nothing is raw the layer-1 bias is one more ring member (same address for all columns: L1 broadcast).
+  constexpr int NR = RAW ? NPROJ : NPROJ + 1;
+  const float* brow = a.b1 + 4 * q;
+  f32x4 ring[2][NR][2];
+#define GW_REQUEST_SLICE(slot, slice)                                          \
+  {                                                                            \
+    _Pragma("unroll") for (int p = 0; p < NPROJ; ++p) {                        \
+      ring[slot][p][0] = hld4<128 * (slice)>(prow[p]);                         \
+      ring[slot][p][1] = hld4<128 * (slice) + 64>(prow[p]);                    \
+    }                                                                          \
+    if (!RAW) {                                                                \
+      ring[slot][NR - 1][0] = hld4<128 * (slice)>(brow);                       \
+      ring[slot][NR - 1][1] = hld4<128 * (slice) + 64>(brow);                  \
+    }                                                                          \
+  }
+
+  f32x4 acc[16];   // layer-1 accumulator (RAW only)
+  f32x4 acc2[16];  // first hidden layer accumulator
+  if (RAW) {
+    const int r = a.raw_kind == 0 ? s_idx : (a.raw_kind == 1 ? d_idx : k);
+    const float* xrow = a.raw_ptr + ((size_t)b * (size_t)a.raw_rows_pb + (size_t)r) * (size_t)a.raw_ld + 4 * q;
+    f32x4 xv[16];
+    hld_row(xv, xrow);
+    hld_row(acc, brow);
+    GW_REQUEST_SLICE(0, 0)
+    GW_REQUEST_SLICE(1, 1)
+    wait_regs<4 * NR>(xv);   // x and the bias rows landed (and chunk 0 of the weights, issued before them);
+    wait_regs<4 * NR>(acc);  // the two ring slices stay in flight
+    GW_STAMP(1)
+    float x[64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      x[4 * i + 0] = xv[i].x;
+      x[4 * i + 1] = xv[i].y;
+      x[4 * i + 2] = xv[i].z;
+      x[4 * i + 3] = xv[i].w;
+    }
+#pragma unroll
+    for (int cc = 0; cc < kChunksPerLayer; ++cc) {
+      if (cc > 0) wait_vm<0>();
+      lds_barrier();
+      const float* nxt = (cc + 1 < kChunksPerLayer) ? a.w_raw + (size_t)(cc + 1) * kChunkFloats : a.w_mid;
+      issue_chunk32k(nxt, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
+      if (cc == kChunksPerLayer - 1) hld_row(acc2, a.b_mid + 4 * q);  // next layer's bias, under the last chunk
+      float in8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) in8[i] = x[8 * cc + i];
+      mma_chunk(acc, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
+      ++ci;
+    }
+    wait_regs<0>(acc2);
+  } else {
+    // issue order matters for the counted waits: bias rows first, the two ring slices last
+    hld_row(acc2, a.b_mid + 4 * q);
+    GW_REQUEST_SLICE(0, 0)
+    GW_REQUEST_SLICE(1, 1)
+    wait_regs<4 * NR>(acc2);
+    GW_STAMP(1)
+  }
+  GW_STAMP(2)
+
+  // ---- first hidden layer: B operand produced slice by slice = relu(layer-1 accumulator + gathered rows) ----
+#pragma unroll
+  for (int cc = 0; cc < kChunksPerLayer; ++cc) {
+    // In flight across the barrier: the ring slice requested during the previous chunk (issued after that chunk's
+    // weight DMA), i.e. slice cc+1.  Everything older - this chunk's weights and slice cc - has landed.
+    if (cc == 0) {
+      if (RAW) wait_regs<0>(ring[0]); else wait_regs<2 * NR>(ring[0]);
+    } else if (cc <= kChunksPerLayer - 2) {
+      wait_regs<2 * NR>(ring[cc & 1]);
+    } else {
+      wait_regs<0>(ring[cc & 1]);
+    }
+    lds_barrier();
+    {
+      const bool last = (cc + 1 == kChunksPerLayer);
+      const float* nxt = !last ? a.w_mid + (size_t)(cc + 1) * kChunkFloats
+                               : (a.n_mid > 1 ? a.w_mid + (size_t)kChunksPerLayer * kChunkFloats : a.w_out);
+      issue_chunk32k(nxt, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
+    }
+    f32x4 v0, v1;
+    if (RAW) {
+      v0 = acc[2 * cc] + ring[cc & 1][0][0];
+      v1 = acc[2 * cc + 1] + ring[cc & 1][0][1];
+    } else {
+      v0 = ring[cc & 1][0][0];
+      v1 = ring[cc & 1][0][1];
+    }
+#pragma unroll
+    for (int p = 1; p < NR; ++p) {
+      v0 += ring[cc & 1][p][0];
+      v1 += ring[cc & 1][p][1];
+    }
+    float in8[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      in8[r] = fmaxf(v0[r], 0.f);
+      in8[4 + r] = fmaxf(v1[r], 0.f);
+    }
+    if (cc == 0) GW_REQUEST_SLICE(0, 2)
+    if (cc == 1) GW_REQUEST_SLICE(1, 3)
+    if (cc == 2) GW_REQUEST_SLICE(0, 4)
+    if (cc == 3) GW_REQUEST_SLICE(1, 5)
+    if (cc == 4) GW_REQUEST_SLICE(0, 6)
+    if (cc == 5) GW_REQUEST_SLICE(1, 7)
+    mma_chunk(acc2, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
+    ++ci;
+  }
+
+  // ---- further hidden layers (hidden_layers > 2; not used by the forecaster defaults) ----
+  float hin[64];
+#pragma unroll 1
+  for (int l = 1; l < a.n_mid; ++l) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hin[4 * t + r] = fmaxf(acc2[t][r], 0.f);
+    wait_vm<0>();
+    hld_row(acc2, a.b_mid + l * 256 + 4 * q);
+    wait_regs<0>(acc2);
+    const float* wl = a.w_mid + (size_t)l * kChunksPerLayer * kChunkFloats;
+#pragma unroll
+    for (int cc = 0; cc < kChunksPerLayer; ++cc) {
+      wait_vm<0>();
+      lds_barrier();
+      const float* nxt = (cc + 1 < kChunksPerLayer) ? wl + (size_t)(cc + 1) * kChunkFloats
+                                                    : (l + 1 < a.n_mid ? wl + (size_t)kChunksPerLayer * kChunkFloats : a.w_out);
+      issue_chunk32k(nxt, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
+      float in8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) in8[i] = hin[8 * cc + i];
+      mma_chunk(acc2, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
+      ++ci;
+    }
+  }
+  GW_STAMP(3)
+
+  // ---- output layer; its bias and the residual rows are requested underneath it ----
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hin[4 * t + r] = fmaxf(acc2[t][r], 0.f);
+  f32x4 o[16];
+  f32x4 rres[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cc = 0; cc < kChunksPerLayer; ++cc) {
+    if (cc == 1) wait_vm<16>(); else wait_vm<0>();  // chunk 1: the 16 residual loads issued in chunk 0 stay in flight
+    lds_barrier();
+    if (cc + 1 < kChunksPerLayer)
+      issue_chunk32k(a.w_out + (size_t)(cc + 1) * kChunkFloats, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
+    if (cc == 0) hld_row(rres, rrow);
+    float in8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) in8[i] = hin[8 * cc + i];
+    mma_chunk(o, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
+    ++ci;
+  }
+  wait_regs<0>(rres);
+  GW_STAMP(4)
+
+  // ---- bias, LayerNorm over the 256 features of each column (eps 1e-5, biased variance), residual ----
+  {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o[t] += ldg4(a.b_out + 16 * t + 4 * q);
+    constexpr float inv_n = 1.0f / 256.0f;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += (o[t].x + o[t].y) + (o[t].z + o[t].w);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s * inv_n;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = o[t][r] - mean;
+        v += d * d;
+      }
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const f32x4 gm = ldg4(a.gamma + 16 * t + 4 * q);
+      const f32x4 bt = ldg4(a.beta + 16 * t + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[t][r] = (o[t][r] - mean) * rstd * gm[r] + bt[r] + rres[t][r];
+    }
+  }
+
+  // ---- stage e' through LDS: [64 columns][260] + 64 global destination ids ----
+  __syncthreads();  // every wave is done reading the weight buffers
+  {
+    float* srow = lds + (wave * kColsPerWave + j) * kStageLd + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) *(f32x4*)(srow + 16 * t) = o[t];
+    if (q == 0) ((int*)(lds + kStageFloats))[wave * kColsPerWave + j] = valid ? b * a.n_dst + d_idx : -1;
+  }
+  __syncthreads();
+  GW_STAMP(5)
+  const int* gdl = (const int*)(lds + kStageFloats);
+
+  // e_out rows: one 1 KiB coalesced store per row (wave w writes the rows of its own 16 columns)
+  if (a.e_out != nullptr) {
+#pragma unroll 4
+    for (int i = 0; i < kColsPerWave; ++i) {
+      const int col = wave * kColsPerWave + i;
+      if (tile_c0 + col < a.n_cols) {
+        const f32x4 vv = *(const f32x4*)(lds + col * kStageLd + 4 * lane);
+        stg4(a.e_out + (size_t)(tile_c0 + col) * 256 + 4 * lane, vv);
+      }
+    }
+  }
+
+  // segment sum: thread f owns feature f; columns are sorted by global destination id, so equal ids form runs.
+  // Interior runs belong to this tile alone -> plain stores; the first and the last run may continue in the
+  // neighbouring tiles -> atomics (agg is zero-filled by the caller).
+  {
+    const int f = threadIdx.x;
+    float run = 0.f;
+    int cur = gdl[0];
+    bool first = true;
+#pragma unroll 8
+    for (int col = 0; col < kColsPerWG; ++col) {
+      const int g = gdl[col];
+      const float vv = lds[col * kStageLd + f];
+      if (g != cur) {
+        if (cur >= 0) {
+          float* dstp = a.agg + (size_t)cur * 256 + f;
+          if (first) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else stg1(dstp, run);
+        }
+        first = false;
+        run = 0.f;
+        cur = g;
+      }
+      run += vv;
+    }
+    if (cur >= 0)
+      __hip_atomic_fetch_add((GW_AS1 float*)(a.agg + (size_t)cur * 256 + f), run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#undef GW_REQUEST_SLICE
+
+  if (a.dbg != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = gw_clock();
+    if (threadIdx.x == 0 && (int)blockIdx.x < a.dbg_cap) {
+      unsigned long long* rec = a.dbg + (size_t)blockIdx.x * 16;
+      for (int i = 0; i < 7; ++i) rec[i] = ts[i];
+      rec[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+      rec[9] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID
+      rec[10] = blockIdx.x;
+    }
+  }
+}
+
+template <typename K>
+int launch(K kernel, const EdgeArgs& a, void* stream) {
+  static bool attr_done = false;  // per template instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes);
+    attr_done = true;
+  }
+  const int grid = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), kEdgeLdsBytes, (hipStream_t)stream, a);
+  return check_launch("edge_kernel launch");
+}
+
+inline bool is_raw(const gw_operand* op) { return op->k > 0 && !op->projected; }
+inline bool is_proj(const gw_operand* op) { return op->k > 0 && op->projected; }
+
+}  // namespace
+
+namespace gw {
+
+bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w) {
+  const gw_operand* ops[3] = {x_src, x_dst, e_in};
+  int n_raw = 0, n_proj = 0;
+  for (int i = 0; i < 3; ++i) {
+    n_raw += is_raw(ops[i]) ? 1 : 0;
+    n_proj += is_proj(ops[i]) ? 1 : 0;
+  }
+  if (n_raw > 1 || n_proj < 1) return false;
+  if (w->n_mid < 1) return false;
+  static int impl = -1;  // GW_EDGE_IMPL=0 forces the general chain kernel (A/B measurements, tests of both paths)
+  if (impl < 0) impl = env_int("GW_EDGE_IMPL", 1);
+  return impl != 0;
+}
+
+int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
+                     const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
+                     float* e_out, float* agg, int32_t n_dst, void* stream) {
+  EdgeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = batch * n_edges;
+  a.n_edges = n_edges;
+  a.n_dst = n_dst;
+  a.src = src;
+  a.dst = dst;
+  const gw_operand* ops[3] = {x_src, x_dst, e_in};
+  int n_proj = 0;
+  bool raw = false;
+  for (int i = 0; i < 3; ++i) {
+    if (is_raw(ops[i])) {
+      raw = true;
+      a.raw_ptr = ops[i]->ptr;
+      a.raw_rows_pb = ops[i]->rows_per_batch;
+      a.raw_ld = ops[i]->ld;
+      a.raw_kind = i;
+      a.w_raw = w->w1[i];
+    } else if (is_proj(ops[i])) {
+      a.p_ptr[n_proj] = ops[i]->ptr;
+      a.p_rows_pb[n_proj] = ops[i]->rows_per_batch;
+      a.p_ld[n_proj] = ops[i]->ld;
+      a.p_kind[n_proj] = i;
+      ++n_proj;
+    }
+  }
+  a.b1 = w->b1;
+  a.w_mid = w->w_mid;
+  a.b_mid = w->b_mid;
+  a.n_mid = w->n_mid;
+  a.w_out = w->w_out;
+  a.b_out = w->b_out;
+  a.gamma = w->ln_gamma;
+  a.beta = w->ln_beta;
+  a.res_ptr = e_res->ptr;
+  a.res_rows_pb = e_res->rows_per_batch;
+  a.res_ld = e_res->ld;
+  a.e_out = e_out;
+  a.agg = agg;
+  if (g_dbg != nullptr && g_dbg_kind == 1) {
+    a.dbg = g_dbg;
+    a.dbg_cap = g_dbg_cap;
+  }
+  {
+    static int stagger_override = -2;
+    if (stagger_override == -2) stagger_override = env_int("GW_STAGGER", -1);
+    const int passes = 1 + a.n_mid + (raw ? 1 : 0);
+    a.stagger = stagger_override >= 0 ? stagger_override * passes : 2 * passes + 2;
+    if ((a.n_cols + kColsPerWG - 1) / kColsPerWG <= 256) a.stagger = 0;
+  }
+  if (raw) {
+    if (n_proj == 1) return launch(edge_kernel<true, 1>, a, stream);
+    return launch(edge_kernel<true, 2>, a, stream);
+  }
+  if (n_proj == 1) return launch(edge_kernel<false, 1>, a, stream);
+  if (n_proj == 2) return launch(edge_kernel<false, 2>, a, stream);
+  return launch(edge_kernel<false, 3>, a, stream);
+}
+
+}  // namespace gw

@@ -23,17 +23,12 @@
 #include <string.h>
 
 #include "../../include/gw_amd.h"
+#include "gw_device.hpp"
+#include "gw_internal.hpp"
+
+using namespace gw;
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;         // 4 waves per workgroup; two workgroups per CU (2 waves per SIMD)
-constexpr int kColsPerWave = 16;
-constexpr int kColsPerWG = 64;
-constexpr int kChunkSteps = 8;        // K-steps (4 k's each) per LDS buffer: K = 32 per chunk
-constexpr int kLdsBufFloats = kChunkSteps * 4 * 256;  // 8 steps x 16 tiles x 16 rows x 4 k = 32 KiB
-constexpr int kLdsBytes = 2 * kLdsBufFloats * 4;       // double buffered: 64 KiB per workgroup
 
 enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
 
@@ -76,31 +71,6 @@ struct ChainArgs {
   const int* agg_idx;
   int agg_rows_pb;
 };
-
-#define GW_AS1 __attribute__((address_space(1)))
-__device__ __forceinline__ unsigned long long gw_clock() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define GW_STAMP(i) \
-  if (a.dbg != nullptr) { ts[i] = gw_clock(); }
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(const GW_AS1 f32x4*)p; }
-__device__ __forceinline__ float ldg1(const float* p) { return *(const GW_AS1 float*)p; }
-__device__ __forceinline__ int ldgi(const int* p) { return *(const GW_AS1 int*)p; }
-__device__ __forceinline__ void stg4(float* p, f32x4 v) { *(GW_AS1 f32x4*)p = v; }
-__device__ __forceinline__ void stg1(float* p, float v) { *(GW_AS1 float*)p = v; }
-
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
-// Each wave DMAs its share of `nfloats` (multiple of 256) from the packed weight stream into an LDS buffer.
-__device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
-  const int npieces = nfloats >> 8;
-  for (int p = wave; p < npieces; p += 4) glds16(g + (size_t)p * 256 + lane * 4, ldsbuf + p * 256);
-}
 
 // in[8c .. 8c+7] <- row[k(s,q)] for the K-steps of chunk c (full 16-byte aligned rows)
 template <int NSTEPS>
@@ -590,7 +560,14 @@ __global__ void nmse_kernel(const float* __restrict__ pred, const float* __restr
 
 thread_local char g_err[512] = "";
 
-int fail(int code, const char* msg) {
+}  // namespace
+
+namespace gw {
+unsigned long long* g_dbg = nullptr;
+int g_dbg_cap = 0;
+int g_dbg_kind = -1;  // which launch family to stamp: 0 mlp, 1 edge, 2 node, 3 project
+
+int set_error(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
 }
@@ -604,10 +581,17 @@ int check_launch(const char* what) {
   return GW_OK;
 }
 
-int g_stagger_override = -1;
-unsigned long long* g_dbg = nullptr;
-int g_dbg_cap = 0;
-int g_dbg_kind = -1;  // which launch family to stamp: 0 mlp, 1 edge, 2 node, 3 project  // GW_STAGGER env (tuning): -1 = automatic
+int env_int(const char* name, int fallback) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : fallback;
+}
+}  // namespace gw
+
+namespace {
+
+int fail(int code, const char* msg) { return gw::set_error(code, msg); }
+
+int g_stagger_override = -1;  // GW_STAGGER env (tuning): -1 = automatic
 
 template <typename K>
 int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1, int kind = 0) {
@@ -769,6 +753,8 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
   if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
+  if (gw::edge_fast_eligible(x_src, x_dst, e_in, w))
+    return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, stream);
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;
