@@ -36,6 +36,31 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The same LDS-DMA issued from an asm statement.  global_load_lds is a FLAT-class instruction: while hipcc has one
+// pending in its s_waitcnt model, EVERY wait it generates is a full drain (vmcnt(0) / lgkmcnt(0)) - also the lgkmcnt
+// in front of each MFMA group that consumes ds_read results, which then exposes the LDS latency of the reads issued
+// for the NEXT step.  Hidden in asm, the DMA is counted by the kernel's own vmcnt waits and hipcc's ds_read waits are
+// the normal counted ones.  lds_byte_addr: wave-uniform LDS byte address of this wave's 1 KiB piece (lane l lands at
+// +16 l).  M0 is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16_asm(const float* g, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_byte_addr)
+      : "memory");
+}
+
+// Scalar-base form: g_uniform is a wave-uniform pointer (SGPR pair), lane_off_bytes each lane's byte offset (16 l).
+__device__ __forceinline__ void glds16_asm_s(const float* g_uniform, unsigned lane_off_bytes, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_off_bytes), "s"(g_uniform), "s"(lds_byte_addr)
+      : "memory");
+}
+
 // Each wave DMAs its share of `nfloats` (multiple of 256) from the packed weight stream into an LDS buffer.
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
   const int npieces = nfloats >> 8;

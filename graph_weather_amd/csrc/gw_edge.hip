@@ -8,7 +8,10 @@
 // the encoder); the others are per-node / per-edge products that are only gathered and added.  Compared with the
 // general chain_kernel this kernel
 //   * keeps the gathered rows of the projected operands in a two-chunk-deep register ring, requested two weight
-//     chunks ahead and left in flight across the chunk barrier (s_waitcnt vmcnt(N) instead of vmcnt(0)),
+//     chunks ahead from asm statements hipcc does not count, so no gather is waited for where it is issued,
+//   * streams the weights with asm-issued LDS-DMA (hipcc's waits stay counted instead of full drains), two 1 KiB
+//     pieces per K-step interleaved with the MFMAs, and does the chunk hand-over (wait, barrier, first fragments of the
+//     next chunk) in front of the last 16 MFMAs of a chunk instead of behind them,
 //   * needs no layer-1 accumulator at all when nothing is raw (decoder, first processor block),
 //   * stages e' through LDS (the weight buffers are free by then) so that the rows of e_out are written with one
 //     fully coalesced 1 KiB store per row and the segment sum runs with one thread per feature: interior
@@ -39,6 +42,7 @@ struct EdgeArgs {
   int n_edges;
   int n_dst;
   int stagger;
+  int skip;  // tuning aid (GW_EDGE_SKIP): 1 = no segment sum, 2 = no staging either (results are then wrong)
   unsigned long long* dbg;
   int dbg_cap;
   const int* src;
@@ -70,30 +74,6 @@ struct EdgeArgs {
   float* e_out;
   float* agg;
 };
-
-// One weight chunk: acc[t] += W[16t.., k(s)] * in[s] for the 8 K-steps of the chunk (16 row tiles).
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[16], const float (&in8)[8], const float* buf_lane) {
-  f32x4 a_cur[4];
-#pragma unroll
-  for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = *(const f32x4*)(buf_lane + b4 * 256);
-#pragma unroll
-  for (int s = 0; s < kChunkSteps; ++s) {
-    f32x4 a_nxt[4];
-    if (s + 1 < kChunkSteps) {
-#pragma unroll
-      for (int b4 = 0; b4 < 4; ++b4) a_nxt[b4] = *(const f32x4*)(buf_lane + (s + 1) * 1024 + b4 * 256);
-    }
-    const float b = in8[s];
-    __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of step s+1 ahead of the MFMAs of step s
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < kChunkSteps) {
-#pragma unroll
-      for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = a_nxt[b4];
-    }
-  }
-}
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -160,6 +140,15 @@ __device__ __forceinline__ void hld_row(f32x4 (&r)[16], const float* p) {
   r[12] = hld4<768>(p);  r[13] = hld4<832>(p);  r[14] = hld4<896>(p);  r[15] = hld4<960>(p);
 }
 
+// one half (tiles 8h .. 8h+7) of such a row
+template <int H>
+__device__ __forceinline__ void hld_half_row(f32x4 (&r)[16], const float* p) {
+  r[8 * H + 0] = hld4<512 * H + 0>(p);    r[8 * H + 1] = hld4<512 * H + 64>(p);
+  r[8 * H + 2] = hld4<512 * H + 128>(p);  r[8 * H + 3] = hld4<512 * H + 192>(p);
+  r[8 * H + 4] = hld4<512 * H + 256>(p);  r[8 * H + 5] = hld4<512 * H + 320>(p);
+  r[8 * H + 6] = hld4<512 * H + 384>(p);  r[8 * H + 7] = hld4<512 * H + 448>(p);
+}
+
 // Workgroup barrier for the LDS weight ring.  __syncthreads() carries a workgroup-scope release fence, which hipcc
 // lowers to s_waitcnt vmcnt(0): that would drain the gathers this kernel deliberately keeps in flight.  Here only
 // LDS traffic has to be ordered: this wave's LDS reads are complete (lgkmcnt(0)) and its share of the weight DMA
@@ -168,19 +157,77 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+extern __shared__ __attribute__((aligned(16))) float gw_edge_lds[];
+__device__ __forceinline__ float* lds_base() { return gw_edge_lds; }
+
 // Each wave DMAs its 8 KiB share of one 32 KiB weight chunk into an LDS buffer: exactly 8 x global_load_lds (1 KiB
 // each), no branches - the vmcnt(N) bookkeeping of the kernel counts on that.
 __device__ __forceinline__ void issue_chunk32k(const float* __restrict__ g, float* ldsbuf, int lane, int wave) {
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(ldsbuf - lds_base()) * 4u + (unsigned)wave * 1024u);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = wave + 4 * i;
-    glds16(g + (size_t)p * 256 + lane * 4, ldsbuf + p * 256);
-  }
+  for (int i = 0; i < 8; ++i) glds16_asm_s(g + (size_t)(wave + 4 * i) * 256, (unsigned)lane * 16u, base + (unsigned)i * 4096u);
 }
+
+// N of this wave's 8 pieces (first..first+N-1) of a chunk; buf_floats = float offset of the destination LDS buffer.
+constexpr int kDmaSteps = 4;  // the 8 pieces of the next chunk are issued 2 per K-step during the first 4 steps of a chunk
+template <int N>
+__device__ __forceinline__ void issue_pieces(const float* __restrict__ g, int buf_floats, int first, int lane, int wave) {
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)buf_floats * 4u + (unsigned)wave * 1024u);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    glds16_asm_s(g + (size_t)(wave + 4 * (first + i)) * 256, (unsigned)lane * 16u, base + (unsigned)(first + i) * 4096u);
+}
+
+// Source of weight chunk i of a tile: [w_raw (8 chunks)] w_mid (8 x n_mid, contiguous) w_out (8).
+template <bool RAW>
+__device__ __forceinline__ const float* chunk_src(const EdgeArgs& a, int i) {
+  if (RAW) {
+    if (i < kChunksPerLayer) return a.w_raw + (size_t)i * kChunkFloats;
+    i -= kChunksPerLayer;
+  }
+  const int nm = a.n_mid * kChunksPerLayer;
+  if (i < nm) return a.w_mid + (size_t)i * kChunkFloats;
+  return a.w_out + (size_t)(i - nm) * kChunkFloats;
+}
+
+// One weight chunk (8 K-steps x 16 row tiles): ACC[t] += W[16t.., k(s)] * IN8[s].
+// The A fragments of a step are read from LDS one step ahead (a_cur / a_nxt), ACROSS chunk boundaries: during the
+// last step of chunk ci the boundary work for chunk ci+1 is done - counted wait WAIT_STMT (this wave's share of chunk
+// ci+1 has landed), workgroup barrier (everybody's share has, and everybody is done reading chunk ci), DMA of chunk
+// ci+2 into the buffer chunk ci vacates, first fragments of chunk ci+1 - and only then the step's 16 MFMAs are
+// issued, so barrier skew and LDS latency sit underneath 16 MFMAs instead of draining the matrix pipe.
+#define GW_CHUNK(ACC, IN8, NEXT_EXISTS, WAIT_STMT)                                                             \
+  {                                                                                                            \
+    const float* bl_ = lds + (ci & 1) * kLdsBufFloats + lane * 4;                                              \
+    const float* nsrc_ = chunk_src<RAW>(a, ci + 1);                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < kChunkSteps; ++s_) {                                               \
+      f32x4 a_nxt_[4];                                                                                         \
+      if ((NEXT_EXISTS) && s_ < kDmaSteps && a.skip != 4) {                                                     \
+        issue_pieces<8 / kDmaSteps>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, s_ * (8 / kDmaSteps), lane, wave);  \
+      }                                                                                                        \
+      if (s_ + 1 < kChunkSteps) {                                                                              \
+        _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) a_nxt_[b4] = *(const f32x4*)(bl_ + (s_ + 1) * 1024 + b4 * 256); \
+      } else if (NEXT_EXISTS) {                                                                                \
+        WAIT_STMT;                                                                                             \
+        if (a.skip != 5) lds_barrier();                                                                        \
+        const float* bn_ = lds + ((ci + 1) & 1) * kLdsBufFloats + lane * 4;                                    \
+        _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) a_nxt_[b4] = *(const f32x4*)(bn_ + b4 * 256);          \
+      }                                                                                                        \
+      const float b_ = IN8[s_];                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int t = 0; t < 16; ++t)                                                           \
+          ACC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b_, ACC[t], 0, 0, 0);             \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if (s_ + 1 < kChunkSteps || (NEXT_EXISTS)) {                                                             \
+        _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = a_nxt_[b4];                                \
+      }                                                                                                        \
+    }                                                                                                          \
+    ++ci;                                                                                                      \
+  }
 
 template <bool RAW, int NPROJ>
 __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const lds = lds_base();  // dynamic LDS starts at byte address 0 (the kernel has no static LDS)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
@@ -191,19 +238,20 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
   const int c = valid ? c_raw : a.n_cols - 1;
   const int b = c / a.n_edges;
   const int k = c - b * a.n_edges;
+  const int total = kChunksPerLayer * ((RAW ? 1 : 0) + a.n_mid + 1);  // weight chunks per tile
 
   // anti-phase start of the second batch of workgroups (see chain_kernel)
-  if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+  if (a.stagger > 0 && (blockIdx.x >> 8) == 1) {
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   GW_STAMP(0)
 
-  // ---- indices, then the first weight chunk; weight stream = [w_raw] w_mid x n_mid, w_out, chunk i in buffer i & 1 ----
+  // ---- prologue.  Issue order matters for the counted waits (vmcnt retires in order) ----
   int s_idx = hldi(a.src + k);
   int d_idx = hldi(a.dst + k);
-  issue_chunk32k(RAW ? a.w_raw : a.w_mid, lds, lane, wave);
-  int ci = 0;  // chunk counter of this tile (wave uniform)
+  issue_chunk32k(chunk_src<RAW>(a, 0), lds, lane, wave);
+  int ci = 0;  // chunk counter of this tile (wave uniform); chunk i lives in LDS buffer i & 1
   wait_regs<8>(s_idx, d_idx);  // the 8 DMA pieces stay in flight
 
   const float* prow[NPROJ];
@@ -212,10 +260,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     const int r = a.p_kind[p] == 0 ? s_idx : (a.p_kind[p] == 1 ? d_idx : k);
     prow[p] = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
   }
-  const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)k) * (size_t)a.res_ld + 4 * q;
+  const int gd_id = valid ? b * a.n_dst + d_idx : -1;  // global destination row of this column (segment-sum key)
 
-  // ring[c & 1][p][h]: features 32c + 16h + 4q .. +3 of projected operand p (the B-operand slice of produce chunk c).
-  // When nothing is raw the layer-1 bias is one more ring member (same address for all columns: L1 broadcast).
+  // ring[s & 1][p][h]: features 32s + 16h + 4q .. +3 of projected operand p = its part of the B operand of produce
+  // chunk s.  Slice s is requested when slice s-2 has been consumed (end of chunk s-3) and consumed at the end of
+  // chunk s-1.  When nothing is raw the layer-1 bias is one more ring member (same address for all columns).
   constexpr int NR = RAW ? NPROJ : NPROJ + 1;
   const float* brow = a.b1 + 4 * q;
   f32x4 ring[2][NR][2];
@@ -230,20 +279,43 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
       ring[slot][NR - 1][1] = hld4<128 * (slice) + 64>(brow);                  \
     }                                                                          \
   }
+  // B operand of produce chunk `slice` from ring slot `slot` (+ the layer-1 accumulator tiles when RAW)
+#define GW_CONSUME_SLICE(slot, slice)                                          \
+  {                                                                            \
+    f32x4 v0_, v1_;                                                            \
+    if (RAW) {                                                                 \
+      v0_ = acc[2 * (slice)] + ring[slot][0][0];                               \
+      v1_ = acc[2 * (slice) + 1] + ring[slot][0][1];                           \
+    } else {                                                                   \
+      v0_ = ring[slot][0][0];                                                  \
+      v1_ = ring[slot][0][1];                                                  \
+    }                                                                          \
+    _Pragma("unroll") for (int p = 1; p < NR; ++p) {                           \
+      v0_ += ring[slot][p][0];                                                 \
+      v1_ += ring[slot][p][1];                                                 \
+    }                                                                          \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                            \
+      in8[r] = fmaxf(v0_[r], 0.f);                                             \
+      in8[4 + r] = fmaxf(v1_[r], 0.f);                                         \
+    }                                                                          \
+  }
 
+  f32x4 a_cur[4];  // A fragments of the next K-step to run
   f32x4 acc[16];   // layer-1 accumulator (RAW only)
   f32x4 acc2[16];  // first hidden layer accumulator
+  float in8[8];    // B operand values of the next chunk
   if (RAW) {
     const int r = a.raw_kind == 0 ? s_idx : (a.raw_kind == 1 ? d_idx : k);
     const float* xrow = a.raw_ptr + ((size_t)b * (size_t)a.raw_rows_pb + (size_t)r) * (size_t)a.raw_ld + 4 * q;
     f32x4 xv[16];
     hld_row(xv, xrow);
     hld_row(acc, brow);
-    GW_REQUEST_SLICE(0, 0)
-    GW_REQUEST_SLICE(1, 1)
-    wait_regs<4 * NR>(xv);   // x and the bias rows landed (and chunk 0 of the weights, issued before them);
-    wait_regs<4 * NR>(acc);  // the two ring slices stay in flight
+    wait_regs<0>(xv);  // chunk 0, x and the bias rows have landed
+    wait_regs<0>(acc);
+    lds_barrier();
     GW_STAMP(1)
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = *(const f32x4*)(lds + lane * 4 + b4 * 256);
     float x[64];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -254,75 +326,63 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     }
 #pragma unroll
     for (int cc = 0; cc < kChunksPerLayer; ++cc) {
-      if (cc > 0) wait_vm<0>();
-      lds_barrier();
-      const float* nxt = (cc + 1 < kChunksPerLayer) ? a.w_raw + (size_t)(cc + 1) * kChunkFloats : a.w_mid;
-      issue_chunk32k(nxt, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
-      if (cc == kChunksPerLayer - 1) hld_row(acc2, a.b_mid + 4 * q);  // next layer's bias, under the last chunk
-      float in8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) in8[i] = x[8 * cc + i];
-      mma_chunk(acc, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
-      ++ci;
+      if (cc == kChunksPerLayer - 3) {  // the first two ring slices, once most of x is dead
+        GW_REQUEST_SLICE(0, 0)
+        GW_REQUEST_SLICE(1, 1)
+      }
+      if (cc == kChunksPerLayer - 1) hld_row(acc2, a.b_mid + 4 * q);  // next layer's bias, under the last chunk (x is dead)
+      if (cc == kChunksPerLayer - 1) {
+        GW_CHUNK(acc, in8, true, wait_regs<0>(acc2))
+      } else {
+        GW_CHUNK(acc, in8, true, wait_vm<0>())
+      }
     }
-    wait_regs<0>(acc2);
+    wait_regs<0>(ring[0]);  // (landed long ago: everything was drained by the vmcnt(0) boundaries above)
+    wait_regs<0>(ring[1]);
+    GW_CONSUME_SLICE(0, 0)
+    GW_REQUEST_SLICE(0, 2)
   } else {
-    // issue order matters for the counted waits: bias rows first, the two ring slices last
     hld_row(acc2, a.b_mid + 4 * q);
     GW_REQUEST_SLICE(0, 0)
     GW_REQUEST_SLICE(1, 1)
-    wait_regs<4 * NR>(acc2);
+    wait_regs<2 * NR>(acc2);     // chunk 0, the bias rows and slice 0 have landed;
+    wait_regs<2 * NR>(ring[0]);  // slice 1 stays in flight
+    lds_barrier();
     GW_STAMP(1)
+#pragma unroll
+    for (int b4 = 0; b4 < 4; ++b4) a_cur[b4] = *(const f32x4*)(lds + lane * 4 + b4 * 256);
+    GW_CONSUME_SLICE(0, 0)
+    GW_REQUEST_SLICE(0, 2)
   }
   GW_STAMP(2)
 
   // ---- first hidden layer: B operand produced slice by slice = relu(layer-1 accumulator + gathered rows) ----
-#pragma unroll
-  for (int cc = 0; cc < kChunksPerLayer; ++cc) {
-    // In flight across the barrier: the ring slice requested during the previous chunk (issued after that chunk's
-    // weight DMA), i.e. slice cc+1.  Everything older - this chunk's weights and slice cc - has landed.
-    if (cc == 0) {
-      if (RAW) wait_regs<0>(ring[0]); else wait_regs<2 * NR>(ring[0]);
-    } else if (cc <= kChunksPerLayer - 2) {
-      wait_regs<2 * NR>(ring[cc & 1]);
-    } else {
-      wait_regs<0>(ring[cc & 1]);
-    }
-    lds_barrier();
-    {
-      const bool last = (cc + 1 == kChunksPerLayer);
-      const float* nxt = !last ? a.w_mid + (size_t)(cc + 1) * kChunkFloats
-                               : (a.n_mid > 1 ? a.w_mid + (size_t)kChunksPerLayer * kChunkFloats : a.w_out);
-      issue_chunk32k(nxt, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
-    }
-    f32x4 v0, v1;
-    if (RAW) {
-      v0 = acc[2 * cc] + ring[cc & 1][0][0];
-      v1 = acc[2 * cc + 1] + ring[cc & 1][0][1];
-    } else {
-      v0 = ring[cc & 1][0][0];
-      v1 = ring[cc & 1][0][1];
-    }
-#pragma unroll
-    for (int p = 1; p < NR; ++p) {
-      v0 += ring[cc & 1][p][0];
-      v1 += ring[cc & 1][p][1];
-    }
-    float in8[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      in8[r] = fmaxf(v0[r], 0.f);
-      in8[4 + r] = fmaxf(v1[r], 0.f);
-    }
-    if (cc == 0) GW_REQUEST_SLICE(0, 2)
-    if (cc == 1) GW_REQUEST_SLICE(1, 3)
-    if (cc == 2) GW_REQUEST_SLICE(0, 4)
-    if (cc == 3) GW_REQUEST_SLICE(1, 5)
-    if (cc == 4) GW_REQUEST_SLICE(0, 6)
-    if (cc == 5) GW_REQUEST_SLICE(1, 7)
-    mma_chunk(acc2, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
-    ++ci;
+  // boundary into produce chunk cc+1: the pieces of chunk cc+1 were issued during this chunk's first K-steps, i.e.
+  // AFTER slice cc+2 was requested, so the wait is a full drain; the slice has had a whole chunk to land.
+#define GW_PRODUCE_CHUNK(cc)                                                              \
+  {                                                                                       \
+    if ((cc) <= 6) {                                                                      \
+      GW_CHUNK(acc2, in8, true, wait_regs<0>(ring[((cc) + 1) & 1]))                        \
+    } else {                                                                              \
+      GW_CHUNK(acc2, in8, true, wait_vm<0>())                                              \
+    }                                                                                     \
+    if ((cc) + 1 < kChunksPerLayer) GW_CONSUME_SLICE(((cc) + 1) & 1, (cc) + 1)             \
   }
+  GW_PRODUCE_CHUNK(0)
+  GW_REQUEST_SLICE(1, 3)
+  GW_PRODUCE_CHUNK(1)
+  GW_REQUEST_SLICE(0, 4)
+  GW_PRODUCE_CHUNK(2)
+  GW_REQUEST_SLICE(1, 5)
+  GW_PRODUCE_CHUNK(3)
+  GW_REQUEST_SLICE(0, 6)
+  GW_PRODUCE_CHUNK(4)
+  GW_REQUEST_SLICE(1, 7)
+  GW_PRODUCE_CHUNK(5)
+  GW_PRODUCE_CHUNK(6)
+  GW_PRODUCE_CHUNK(7)
 
   // ---- further hidden layers (hidden_layers > 2; not used by the forecaster defaults) ----
   float hin[64];
@@ -332,27 +392,18 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     for (int t = 0; t < 16; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hin[4 * t + r] = fmaxf(acc2[t][r], 0.f);
-    wait_vm<0>();
     hld_row(acc2, a.b_mid + l * 256 + 4 * q);
     wait_regs<0>(acc2);
-    const float* wl = a.w_mid + (size_t)l * kChunksPerLayer * kChunkFloats;
 #pragma unroll
     for (int cc = 0; cc < kChunksPerLayer; ++cc) {
-      wait_vm<0>();
-      lds_barrier();
-      const float* nxt = (cc + 1 < kChunksPerLayer) ? wl + (size_t)(cc + 1) * kChunkFloats
-                                                    : (l + 1 < a.n_mid ? wl + (size_t)kChunksPerLayer * kChunkFloats : a.w_out);
-      issue_chunk32k(nxt, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
-      float in8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) in8[i] = hin[8 * cc + i];
-      mma_chunk(acc2, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
-      ++ci;
+      GW_CHUNK(acc2, in8, true, wait_vm<0>())
     }
   }
   GW_STAMP(3)
 
-  // ---- output layer; its bias and the residual rows are requested underneath it ----
+  // ---- output layer; the residual rows are requested underneath it ----
 #pragma unroll
   for (int t = 0; t < 16; ++t)
 #pragma unroll
@@ -363,16 +414,18 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
   for (int t = 0; t < 16; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int cc = 0; cc < kChunksPerLayer; ++cc) {
-    if (cc == 1) wait_vm<16>(); else wait_vm<0>();  // chunk 1: the 16 residual loads issued in chunk 0 stay in flight
-    lds_barrier();
-    if (cc + 1 < kChunksPerLayer)
-      issue_chunk32k(a.w_out + (size_t)(cc + 1) * kChunkFloats, lds + ((ci + 1) & 1) * kLdsBufFloats, lane, wave);
-    if (cc == 0) hld_row(rres, rrow);
-    float in8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) in8[i] = hin[8 * cc + i];
-    mma_chunk(o, in8, lds + (ci & 1) * kLdsBufFloats + lane * 4);
-    ++ci;
+    if (cc + 1 < kChunksPerLayer) {
+      GW_CHUNK(o, in8, true, wait_vm<0>())
+    } else {
+      GW_CHUNK(o, in8, false, wait_vm<0>())
+    }
+    // residual rows, requested late and in halves: by now 32 / 48 of the 64 B-operand registers are dead
+    if (cc == 3 || cc == 5) {  // (pointer recomputed here rather than kept live since the prologue)
+      const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)k) * (size_t)a.res_ld + 4 * q;
+      if (cc == 3) hld_half_row<0>(rres, rrow); else hld_half_row<1>(rres, rrow);
+    }
   }
   wait_regs<0>(rres);
   GW_STAMP(4)
@@ -408,13 +461,14 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     }
   }
 
+  if (a.skip >= 2) return;
   // ---- stage e' through LDS: [64 columns][260] + 64 global destination ids ----
   __syncthreads();  // every wave is done reading the weight buffers
   {
     float* srow = lds + (wave * kColsPerWave + j) * kStageLd + 4 * q;
 #pragma unroll
     for (int t = 0; t < 16; ++t) *(f32x4*)(srow + 16 * t) = o[t];
-    if (q == 0) ((int*)(lds + kStageFloats))[wave * kColsPerWave + j] = valid ? b * a.n_dst + d_idx : -1;
+    if (q == 0) ((int*)(lds + kStageFloats))[wave * kColsPerWave + j] = gd_id;
   }
   __syncthreads();
   GW_STAMP(5)
@@ -432,6 +486,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     }
   }
 
+  if (a.skip >= 1) return;
   // segment sum: thread f owns feature f; columns are sorted by global destination id, so equal ids form runs.
   // Interior runs belong to this tile alone -> plain stores; the first and the last run may continue in the
   // neighbouring tiles -> atomics (agg is zero-filled by the caller).
@@ -460,6 +515,8 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
       __hip_atomic_fetch_add((GW_AS1 float*)(a.agg + (size_t)cur * 256 + f), run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #undef GW_REQUEST_SLICE
+#undef GW_CONSUME_SLICE
+#undef GW_PRODUCE_CHUNK
 
   if (a.dbg != nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -477,12 +534,14 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
 template <typename K>
 int launch(K kernel, const EdgeArgs& a, void* stream) {
   static bool attr_done = false;  // per template instantiation
+  static int lds_bytes = kEdgeLdsBytes;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEdgeLdsBytes);
+    lds_bytes = kEdgeLdsBytes + env_int("GW_EDGE_LDS_PAD", 0);  // tuning aid: > 15 KiB of padding forces one workgroup per CU
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_done = true;
   }
   const int grid = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), kEdgeLdsBytes, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
   return check_launch("edge_kernel launch");
 }
 
@@ -552,6 +611,11 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
   if (g_dbg != nullptr && g_dbg_kind == 1) {
     a.dbg = g_dbg;
     a.dbg_cap = g_dbg_cap;
+  }
+  {
+    static int skip = -1;
+    if (skip < 0) skip = env_int("GW_EDGE_SKIP", 0);
+    a.skip = skip;
   }
   {
     static int stagger_override = -2;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   // in lockstep - both gathering, then both queueing on the matrix pipe - so neither hides the other's memory
   // phase (measured: MFMA busy 57 %).  Delaying the second batch of 256 workgroups by about half a tile puts the
   // pair on each CU in anti-phase: one gathers / normalises / scatters while the other owns the matrix pipe.
-  if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+  if (a.stagger > 0 && (blockIdx.x >> 8) == 1) {  // only the second batch of the first wave: later workgroups start when a slot frees up, already out of phase
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
 

@@ -15,13 +15,14 @@ run_pass () {
   if [ -n "$f" ]; then
     # keep only our chain kernels, aggregated per (kernel, counter)
     python - "$f" > $GRAFT_REPO_ROOT/$OUT/pmc_$name.txt <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 agg = collections.defaultdict(lambda: [0.0, 0])
 with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
         k = r.get("Kernel_Name", "")
-        if "chain_kernel" not in k: continue
-        key = (k.split("(")[0][-60:], r.get("Grid_Size"), r["Counter_Name"])
+        m = re.search(r"(chain_kernel|edge_kernel)<[^>]*>", k)
+        if not m: continue
+        key = (m.group(0), r.get("Grid_Size"), r["Counter_Name"])
         agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
 for (k, g, c), (v, n) in sorted(agg.items()):
     print(f"{k}\tgrid={g}\t{c}\tmean={v/n:.6g}\tn={n}")
@@ -32,6 +33,6 @@ run_pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 run_pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
-run_pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM
+[ "${PMC_LDS:-1}" = "1" ] && run_pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM
 ls -la $GRAFT_REPO_ROOT/$OUT
 tail -n 60 $GRAFT_REPO_ROOT/$OUT/pmc_sq.txt

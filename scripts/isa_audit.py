@@ -38,6 +38,9 @@ def audit(body, verbose):
             continue
         op = t.split()[0]
         toks = re.findall(r"v\[\d+:\d+\]|v\d+", t)
+        if in_asm and op.startswith("global_load_lds"):
+            cnt["dma"] += 1
+            continue
         if in_asm and op.startswith("global_load"):
             for r in regs_of(toks[0]):
                 pending[r] = n
