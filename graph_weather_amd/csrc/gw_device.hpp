@@ -64,7 +64,9 @@ __device__ __forceinline__ void glds16_asm_s(const float* g_uniform, unsigned la
 // Each wave DMAs its share of `nfloats` (multiple of 256) from the packed weight stream into an LDS buffer.
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
   const int npieces = nfloats >> 8;
-  for (int p = wave; p < npieces; p += 4) glds16(g + (size_t)p * 256 + lane * 4, ldsbuf + p * 256);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf;  // LDS byte address
+  for (int p = wave; p < npieces; p += 4)
+    glds16_asm_s(g + (size_t)p * 256, (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)p * 1024u));
 }
 
 

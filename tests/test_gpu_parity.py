@@ -216,3 +216,43 @@ def test_full_size_1deg_properties_and_oracle_sample():
     d_ref = y_ref - feats[:1, :, :78]
     rel = _close(y[:1].cpu() - feats[:1, :, :78], d_ref, what="1 degree sample vs oracle (delta)")
     print(f"[parity] 1deg: rel err of decoder delta = {rel:.2e}")
+
+
+def test_quarter_degree_stress_properties():
+    """BASELINE.json configs[4]: 0.25 degree grid (1 036 800 nodes), mesh resolution 3 (41 162 nodes, 288 122 latent
+    and 7.25 M decoder edges), batch 1 - too large for the CPU oracle, so size-independent properties:
+    zero parameters give the residual identity exactly; a sample's forecast does not depend on what else is in
+    the batch (batch elements never interact, encoder.py:212-218)."""
+    import time
+
+    lat_lons = regular_lat_lons(0.25)
+    t0 = time.time()
+    model = gw.GraphWeatherForecaster(lat_lons, resolution=3)
+    t_build = time.time() - t0
+    assert model.encoder.num_h3 == 41162 and model.encoder.graphs.lat_plan.num_edges == 7 * 41162 - 12
+    G = len(lat_lons)
+    rs = np.random.RandomState(5)
+    f1 = torch.from_numpy(rs.standard_normal((1, G, 102)).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.zero_()
+        model = model.to(DEV).eval()
+        y0 = model(f1)
+        assert torch.equal(y0, f1[..., :78]), "zero parameters must give the residual identity exactly"
+        deterministic_fill_(model, seed=0)
+        y1 = model(f1)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        y1b = model(f1)
+        torch.cuda.synchronize()
+        t_fwd = time.time() - t0
+        assert torch.isfinite(y1).all()
+        # long destination segments (3 446 grid points in one polar cell) span many tiles: their partial sums meet in
+        # atomics whose order is not fixed, so two runs agree to fp32 round-off, not bitwise
+        _close(y1b, y1, rel=1e-5, what="run-to-run at 0.25 degree")
+        f2 = torch.cat([torch.from_numpy(rs.standard_normal((1, G, 102)).astype(np.float32)).to(DEV), f1])
+        y2 = model(f2)
+    _close(y2[1:], y1, rel=1e-5, what="batch independence at 0.25 degree")
+    delta = (y1 - f1[..., :78]).abs().max().item()
+    assert delta > 1e-3, "forecast must differ from the input with non-zero weights"
+    print(f"[stress] 0.25deg: build {t_build:.1f}s, forward B=1 {1e3 * t_fwd:.1f} ms, max|delta| {delta:.3f}")
