@@ -69,6 +69,19 @@ def cpu_baseline(lat_lons, state, graphs, budget_s=30.0):
                       + f"; host has {ncpu} logical CPUs"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE applied by scripts/gpu_pmc.sh).  None if not collected."""
+    p = os.path.join(ROOT, "profiles", "pmc_decoder_edge.json")
+    try:
+        d = json.load(open(p))
+        if d.get("hbm_read_bytes") is None or d.get("hbm_write_bytes") is None:
+            return None, None
+        return d["hbm_read_bytes"] + d["hbm_write_bytes"], d
+    except (OSError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +145,10 @@ def main():
         flops = EDGE_MLP_FLOPS * e_dec * args.batch
         achieved = flops / (dec_ms * 1e-3) / 1e12
         executed = DEC_EDGE_EXECUTED_FLOPS * e_dec * args.batch / (dec_ms * 1e-3) / 1e12
+        traffic, pmc = pmc_traffic() if (args.grid == 1.0 and args.batch == 2) else (None, None)
+        # algorithmic HBM bytes of one decoder edge launch: per (sample, edge) the cached product row and the residual
+        # edge-feature row (2 x 1 KiB), per destination row one 1 KiB sum written; indices 8 B per edge
+        alg_bytes = args.batch * e_dec * (2 * 1024 + 8) + args.batch * len(lat_lons) * 1024
         out = {
             "metric": "forward forecasts/sec (1° grid, 102→78 feat)", "value": world * args.batch * args.steps / elapsed,
             "unit": "forecasts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -142,7 +159,9 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
             "roofline": {"bound": "mfma", "kernel": "chain_kernel<EDGE> (decoder edge update)", "achieved": achieved,
                          "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
-                         "traffic": None, "launch_ms": dec_ms, "algorithmic_flops_per_launch": flops,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_decoder_edge.json)",
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "mfma_busy_frac_pmc": None if pmc is None else pmc.get("mfma_busy_frac"), "launch_ms": dec_ms, "algorithmic_flops_per_launch": flops,
                          "executed_tflops": executed, "executed_frac": executed / PEAK_F32_MATRIX_TFLOPS,
                          "note": "achieved/frac use the ALGORITHMIC flops of the reference edge MLP (768->256->256->256 per "
                                  "edge); the kernel legally executes fewer (layer-1 split), executed_* is the MFMA work it runs",

@@ -34,5 +34,39 @@ run_pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 [ "${PMC_LDS:-1}" = "1" ] && run_pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM
+# summary JSON of the dominant kernel (decoder edge update = the edge_kernel launch with the largest grid); bench.py reads
+# the committed copy (profiles/pmc_decoder_edge.json) for roofline.traffic
+python - $GRAFT_REPO_ROOT/$OUT <<'PY'
+import json, sys, os, re
+out = sys.argv[1]
+def load(name):
+    rows = {}
+    p = os.path.join(out, f"pmc_{name}.txt")
+    if not os.path.exists(p): return rows
+    for line in open(p):
+        k, g, c, v, n = line.rstrip("\n").split("\t")
+        rows[(k, int(g.split("=")[1]), c)] = float(v.split("=")[1])
+    return rows
+r = {}
+for n in ("sq", "grbm", "fetch", "write", "lds"): r.update(load(n))
+edge = [(g, k) for (k, g, c) in r if k.startswith("edge_kernel")]
+if edge:
+    g, k = max(edge)
+    get = lambda c: r.get((k, g, c))
+    fetch_kib, write_kib = get("FETCH_SIZE"), get("WRITE_SIZE")
+    d = {"kernel": k, "grid_threads": g,
+         "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+         # MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> x2
+         "hbm_read_bytes": None if fetch_kib is None else 2.0 * fetch_kib * 1024.0,
+         "hbm_write_bytes": None if write_kib is None else write_kib * 1024.0,
+         "SQ_VALU_MFMA_BUSY_CYCLES": get("SQ_VALU_MFMA_BUSY_CYCLES"), "SQ_INSTS_VALU_MFMA_F32": get("SQ_INSTS_VALU_MFMA_F32"),
+         "GRBM_GUI_ACTIVE": get("GRBM_GUI_ACTIVE"), "SQ_WAVE_CYCLES": get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": get("SQ_WAIT_ANY"),
+         "SQ_WAIT_INST_ANY": get("SQ_WAIT_INST_ANY"), "SQ_LDS_BANK_CONFLICT": get("SQ_LDS_BANK_CONFLICT")}
+    if d["SQ_VALU_MFMA_BUSY_CYCLES"] and d["GRBM_GUI_ACTIVE"]:
+        # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+        d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (d["GRBM_GUI_ACTIVE"] / 8.0)
+    json.dump(d, open(os.path.join(out, "pmc_decoder_edge.json"), "w"), indent=1)
+    print(json.dumps(d))
+PY
 ls -la $GRAFT_REPO_ROOT/$OUT
 tail -n 60 $GRAFT_REPO_ROOT/$OUT/pmc_sq.txt
