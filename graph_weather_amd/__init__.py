@@ -15,6 +15,7 @@ from .layers import (  # noqa: F401
     NodeProcessor,
     Processor,
     build_graph_processor_block,
+    set_compute_dtype,
 )
 from .losses import NormalizedMSELoss  # noqa: F401
 

@@ -15,8 +15,12 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
+ABI_VERSION = 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
 EXPORTS = [
-    "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_padded_n", "gw_pad_vector",
+    "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
+    "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector",
     "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_node_update_forward",
     "gw_normalized_mse_forward",
 ]
@@ -30,7 +34,7 @@ class GwOperand(Structure):
 class GwMlpWeights(Structure):
     _fields_ = [("w1", c_void_p * 3), ("b1", c_void_p), ("w_mid", c_void_p), ("b_mid", c_void_p), ("w_out", c_void_p),
                 ("b_out", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("hidden", c_int32),
-                ("n_mid", c_int32), ("n_out", c_int32)]
+                ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32)]
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -68,6 +72,10 @@ def lib():
     L.gw_packed_floats.argtypes = [c_int, c_int, c_int]
     L.gw_pack_linear.restype = c_int
     L.gw_pack_linear.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.gw_packed_bytes_bf16.restype = c_size_t
+    L.gw_packed_bytes_bf16.argtypes = [c_int, c_int, c_int]
+    L.gw_pack_linear_bf16.restype = c_int
+    L.gw_pack_linear_bf16.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.gw_padded_n.restype = c_int
     L.gw_padded_n.argtypes = [c_int]
     L.gw_pad_vector.restype = c_int
@@ -84,11 +92,11 @@ def lib():
                                          POINTER(GwMlpWeights), c_void_p, c_int32, c_void_p]
     L.gw_project_forward.restype = c_int
     L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
-                                     c_int32, c_void_p]
+                                     c_int32, c_int32, c_void_p]
     L.gw_normalized_mse_forward.restype = c_int
     L.gw_normalized_mse_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                             c_void_p, c_void_p]
-    if L.gw_version() != 1:
+    if L.gw_version() != ABI_VERSION:
         raise RuntimeError("graph_weather_amd: libgw_amd.so ABI version mismatch")
     _lib = L
     return L

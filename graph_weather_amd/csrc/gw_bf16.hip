@@ -1,0 +1,471 @@
+// gw_bf16.hip - bf16-MFMA variant of the fused MLP kernels (BASELINE.json configs[2]: "bf16 MFMA node-MLPs").
+//
+// Same transposed, register-resident scheme as the fp32 kernels (gw_kernels.hip / gw_edge.hip):
+//       H_out[feature][column] = W[feature][k] . H_in[k][column],
+// but on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): weights are the A operand (lane: row = lane & 15, 8 consecutive
+// packed k's selected by lane >> 4), activations the B operand (column = lane & 15), converted fp32 -> bf16 (RNE) in
+// registers.  With the K order
+//       k(s, q, i) = 32 s + 16 (i >> 2) + 4 q + (i & 3)        (s = K-step, q = lane >> 4, i = 0..7)
+// the 8 values a lane must supply for K-step s of the next layer are exactly its accumulator entries of row tiles
+// 2s and 2s+1, so the chain of layers + LayerNorm + residual stays in registers as in fp32.
+// Everything that is not a matrix product (bias, LayerNorm statistics, residual adds, segment sums, and every tensor
+// in HBM) stays fp32.
+//
+// bf16 matrix cores are 16x faster than the fp32 ones, so the balance moves to the weight stream: one A fragment
+// (1 KiB per wave) read from LDS feeds 4 MFMAs here - every wave works on FOUR 16-column groups (64 columns, 256 per
+// workgroup) - which keeps LDS reads at a quarter of their peak and the L2->LDS weight DMA at 0.5 KiB per column
+// and layer.  That needs ~420 VGPRs per wave: one workgroup (4 waves) per CU.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "gw_device.hpp"
+#include "gw_internal.hpp"
+
+using namespace gw;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NG = 2;                       // 16-column groups per wave (4 would halve the weight stream again but spills)
+constexpr int kCols16 = 4 * NG * 16;        // columns per workgroup (256)
+constexpr int kBufBytes = 32768;            // one weight chunk buffer (2 K-steps x 16 tiles x 1 KiB)
+constexpr int kStageLd16 = 260;
+constexpr int kStageFloats16 = 64 * kStageLd16;
+constexpr int kLdsWeights = 2 * kBufBytes;  // double buffered
+constexpr int kLdsEdge = kLdsWeights + (kStageFloats16 + 64) * 4;
+
+template <int N>
+__device__ __forceinline__ void wait_vm16() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier16() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// DMA `bytes` (multiple of 1 KiB) of the packed weight stream into LDS at byte offset lds_off; pieces round-robin
+// over the 4 waves.
+__device__ __forceinline__ void issue_bytes(const char* __restrict__ g, int bytes, unsigned lds_off, int lane, int wave) {
+  const int npieces = bytes >> 10;
+  for (int p = wave; p < npieces; p += 4)
+    glds16_asm_s((const float*)(g + (size_t)p * 1024), (unsigned)lane * 16u,
+                 __builtin_amdgcn_readfirstlane(lds_off + (unsigned)p * 1024u));
+}
+
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+  r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+  return r;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+
+// One layer pass: acc[g][t] += W[16t.., k] . bin[g][k], K = 32 KS, NT row tiles, NTP = tiles per K-step in the packed
+// stream (NT rounded up to 4).  The stream of this pass starts at gw; its first chunk has already been issued into
+// buffer `parity`; while the last chunk computes, the first chunk of the next pass (next_gw, next_bytes) is issued.
+template <int KS, int NT, int NTP>
+__device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)[NG][KS], const char* __restrict__ gw,
+                                       const char* __restrict__ next_gw, int next_bytes, const char* lds, int& parity,
+                                       int lane, int wave) {
+  constexpr int STEP_BYTES = NTP * 1024;
+  constexpr int CS = (2 * STEP_BYTES <= kBufBytes) ? 2 : 1;  // K-steps per chunk
+  constexpr int NCH = (KS + CS - 1) / CS;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int steps_c = (KS - c * CS) < CS ? (KS - c * CS) : CS;
+    wait_vm16<0>();
+    lds_barrier16();  // chunk c has landed for every wave; nobody still reads the other buffer
+    if (c + 1 < NCH) {
+      const int sn = (KS - (c + 1) * CS) < CS ? (KS - (c + 1) * CS) : CS;
+      issue_bytes(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+    } else if (next_gw != nullptr) {
+      issue_bytes(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+    }
+    const char* buf = lds + parity * kBufBytes + lane * 16;
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+      if (s < steps_c) {
+#pragma unroll
+        for (int t4 = 0; t4 < NTP / 4; ++t4) {
+          bf16x8 afrag[4];
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) afrag[tt] = *(const bf16x8*)(buf + s * STEP_BYTES + (t4 * 4 + tt) * 1024);
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            if (t4 * 4 + tt < NT) {
+#pragma unroll
+              for (int g = 0; g < NG; ++g)
+                acc[g][t4 * 4 + tt] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[tt], bin[g][c * CS + s], acc[g][t4 * 4 + tt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    parity ^= 1;
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_bias16(f32x4 (&acc)[NG][NT], const float* __restrict__ bias, int q) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 bv = bias ? ldg4(bias + 16 * t + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g][t] = bv;
+  }
+}
+
+// bin[s] <- bf16(row[k(s,q,i)]) for a raw operand row (valid features [0, kvalid))
+template <int KS, bool FULL>
+__device__ __forceinline__ void load_raw16(bf16x8 (&bin)[KS], const float* __restrict__ row, int kvalid, int q) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f32x4 lo, hi;
+    if (FULL) {
+      lo = ldg4(row + 32 * s + 4 * q);
+      hi = ldg4(row + 32 * s + 16 + 4 * q);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k0 = 32 * s + 4 * q + r, k1 = k0 + 16;
+        lo[r] = k0 < kvalid ? ldg1(row + k0) : 0.f;
+        hi[r] = k1 < kvalid ? ldg1(row + k1) : 0.f;
+      }
+    }
+    bin[s] = pack8(lo, hi);
+    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 8 row pieces in flight per group: registers are scarce
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_to_bin(bf16x8 (&bin)[NT / 2], const f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int s = 0; s < NT / 2; ++s) bin[s] = pack8(relu4(acc[2 * s]), relu4(acc[2 * s + 1]));
+}
+
+__device__ __forceinline__ const float* operand_row16(const float* ptr, const int* idx, int rows_pb, int ld, int b, int k) {
+  const int r = idx ? ldgi(idx + k) : k;
+  return ptr + ((size_t)b * (size_t)rows_pb + (size_t)r) * (size_t)ld;
+}
+
+// K1S: 32-wide K-steps of a raw layer-1 operand (8: k = 256, 4: k <= 128, 1: k <= 32); HT / OT: hidden / output row tiles.
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE>
+__global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds16[];
+  constexpr int HTP = (HT + 3) / 4 * 4, OTP = (OT + 3) / 4 * 4;
+  constexpr int HKS = HT / 2;  // K-steps of a layer fed by the hidden activations
+  constexpr int H_STEP = HTP * 1024, O_STEP = OTP * 1024;
+  constexpr int H_CS = (2 * H_STEP <= kBufBytes) ? 2 : 1, O_CS = (2 * O_STEP <= kBufBytes) ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const int tile_c0 = blockIdx.x * kCols16;
+
+  int cc[NG], bb[NG], kk[NG];
+  bool valid[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c_raw = tile_c0 + g * 64 + wave * 16 + j;
+    valid[g] = c_raw < a.n_cols;
+    cc[g] = valid[g] ? c_raw : a.n_cols - 1;
+    bb[g] = cc[g] / a.cols_per_batch;
+    kk[g] = cc[g] - bb[g] * a.cols_per_batch;
+  }
+
+  bool on[3], prj[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    on[i] = (i < NSEG) && (a.seg_k[i] > 0) && (a.seg_proj[i] == 0);
+    prj[i] = (i < NSEG) && (a.seg_k[i] > 0) && (a.seg_proj[i] != 0);
+  }
+  const char* w1[3] = {(const char*)a.w1[0], (const char*)a.w1[1], (const char*)a.w1[2]};
+  if (SINGLE) w1[0] = (const char*)a.proj_w[blockIdx.y];
+  const char* w_mid = (const char*)a.w_mid;
+  const char* w_out = (const char*)a.w_out;
+  constexpr int K1_CS = H_CS;
+  constexpr int K1FIRST = (K1S < K1_CS ? K1S : K1_CS) * H_STEP;
+  const char* after_l1 = SINGLE ? nullptr : (a.n_mid > 0 ? w_mid : w_out);
+  const int after_l1_bytes = SINGLE ? 0 : (a.n_mid > 0 ? H_CS * H_STEP : O_CS * O_STEP);
+  int parity = 0;
+  {
+    const char* first = on[0] ? w1[0] : (on[1] ? w1[1] : (on[2] ? w1[2] : after_l1));
+    const int first_bytes = (on[0] || on[1] || on[2]) ? K1FIRST : after_l1_bytes;
+    issue_bytes(first, first_bytes, 0u, lane, wave);
+  }
+
+  // ---- layer 1 ----
+  f32x4 acc[NG][HT];
+  init_bias16<HT>(acc, a.b1, q);
+  {
+    bf16x8 bin[NG][K1S];
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) {
+      if (on[i]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+          load_raw16<K1S, K1FULL>(bin[g], row, a.seg_k[i], q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        bool more = false;
+        const char* nx = after_l1;
+        int nb = after_l1_bytes;
+#pragma unroll
+        for (int i2 = NSEG - 1; i2 > i; --i2)
+          if (on[i2]) {
+            more = true;
+            nx = w1[i2];
+            nb = K1FIRST;
+          }
+        (void)more;
+        pass16<K1S, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave);
+      } else if (prj[i]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            acc[g][t] += ldg4(row + 16 * t + 4 * q);
+            if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  }
+
+  f32x4 o[NG][OT];
+  if constexpr (SINGLE) {
+    static_assert(!SINGLE || HT == OT, "single-layer mode stores the layer-1 accumulator");
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < OT; ++t) o[g][t] = acc[g][t < HT ? t : 0];
+  } else {
+    bf16x8 hin[NG][HKS];
+    // ---- middle layers (hidden -> hidden) ----
+#pragma unroll 1
+    for (int l = 0; l < a.n_mid; ++l) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) relu_to_bin<HT>(hin[g], acc[g]);
+      __builtin_amdgcn_sched_barrier(0);
+      init_bias16<HT>(acc, a.b_mid + l * (HT * 16), q);
+      const bool last = (l + 1 == a.n_mid);
+      const char* nx = last ? w_out : w_mid + (size_t)(l + 1) * HKS * H_STEP;
+      const int nb = last ? O_CS * O_STEP : H_CS * H_STEP;
+      pass16<HKS, HT, HTP>(acc, hin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave);
+    }
+    // ---- output layer ----
+#pragma unroll
+    for (int g = 0; g < NG; ++g) relu_to_bin<HT>(hin[g], acc[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    init_bias16<OT>(o, a.b_out, q);
+    pass16<HKS, OT, OTP>(o, hin, w_out, nullptr, 0, lds16, parity, lane, wave);
+  }
+
+  // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
+  if (!SINGLE && a.gamma != nullptr) {
+    constexpr float inv_n = 1.0f / (OT * 16);
+    float mean[NG], rstd[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) s += (o[g][t].x + o[g][t].y) + (o[g][t].z + o[g][t].w);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      mean[g] = s * inv_n;
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = o[g][t][r] - mean[g];
+          v += d * d;
+        }
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      rstd[g] = 1.0f / sqrtf(v * inv_n + 1e-5f);
+    }
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      const f32x4 gm = ldg4(a.gamma + 16 * t + 4 * q);
+      const f32x4 bt = ldg4(a.beta + 16 * t + 4 * q);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[g][t][r] = (o[g][t][r] - mean[g]) * rstd[g] * gm[r] + bt[r];
+    }
+  }
+
+  // ---- residual ----
+  if (!SINGLE && a.res_ptr != nullptr) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float* rrow = operand_row16(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]);
+#pragma unroll
+      for (int t = 0; t < OT; ++t) {
+        const int f0 = 16 * t + 4 * q;
+        if (EPI == EPI_DEC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) o[g][t][r] += ldg1(rrow + f0 + r);
+        } else {
+          o[g][t] += ldg4(rrow + f0);
+          if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  // ---- store ----
+  float* outp = SINGLE ? a.proj_out[blockIdx.y] : a.out;
+  if (outp != nullptr) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (valid[g]) {
+        float* orow = outp + (size_t)cc[g] * (size_t)a.out_ld;
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+          const int f0 = 16 * t + 4 * q;
+          if (EPI == EPI_DEC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[g][t][r]);
+          } else {
+            stg4(orow + f0, o[g][t]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- segment sum over destination-sorted columns, 64 columns at a time through LDS (see gw_edge.hip) ----
+  if (EPI == EPI_EDGE) {
+    float* stage = (float*)(lds16 + kLdsWeights);
+    int* gdl = (int*)(stage + kStageFloats16);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      __syncthreads();  // previous round's readers are done
+      {
+        float* srow = stage + (wave * 16 + j) * kStageLd16 + 4 * q;
+        // (dynamic g: select the group's registers with a fully unrolled compare chain)
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2)
+          if (g2 == g) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) *(f32x4*)(srow + 16 * t) = o[g2][t];
+            if (q == 0) gdl[wave * 16 + j] = valid[g2] ? bb[g2] * a.agg_rows_pb + ldgi(a.agg_idx + kk[g2]) : -1;
+          }
+      }
+      __syncthreads();
+      const int f = threadIdx.x;
+      float run = 0.f;
+      int cur = gdl[0];
+      bool first = true;
+#pragma unroll 8
+      for (int col = 0; col < 64; ++col) {
+        const int gd = gdl[col];
+        const float vv = stage[col * kStageLd16 + f];
+        if (gd != cur) {
+          if (cur >= 0) {
+            float* dstp = a.agg + (size_t)cur * 256 + f;
+            if (first) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else stg1(dstp, run);
+          }
+          first = false;
+          run = 0.f;
+          cur = gd;
+        }
+        run += vv;
+      }
+      if (cur >= 0)
+        __hip_atomic_fetch_add((GW_AS1 float*)(a.agg + (size_t)cur * 256 + f), run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---- weight packing: nn.Linear [n_out, k_total] slice -> bf16 MFMA A-operand stream -------------------------------
+// out[s][tile][lane][i] = bf16(W[16 tile + (lane & 15)][k_lo + 32 s + 16 (i >> 2) + 4 (lane >> 4) + (i & 3)]), 0 outside
+__global__ void pack_linear_bf16_kernel(const float* __restrict__ w, int n_out, int k_total, int k_lo, int kseg, int ntp,
+                                        int nsteps, __bf16* __restrict__ out) {
+  const size_t total = (size_t)nsteps * ntp * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e & 7);
+    const int lane = (int)((e >> 3) & 63);
+    const int tile = (int)((e >> 9) % ntp);
+    const int s = (int)((e >> 9) / ntp);
+    const int f = 16 * tile + (lane & 15);
+    const int kx = 32 * s + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+    out[e] = (__bf16)((f < n_out && kx < kseg) ? w[(size_t)f * k_total + k_lo + kx] : 0.f);
+  }
+}
+
+template <typename K>
+int launch16(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes) {
+  static bool attr_done = false;  // per template instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEdge);
+    attr_done = true;
+  }
+  const int grid = (a.n_cols + kCols16 - 1) / kCols16;
+  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(256), lds_bytes, (hipStream_t)stream, a);
+  return check_launch("chain16_kernel launch");
+}
+
+}  // namespace
+
+namespace gw {
+
+int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream) {
+  switch (kind) {
+    case 0:  // mlp rows
+      if (hidden == 256 && n_out == 256) {
+        if (k_in <= 32) return launch16(chain16_kernel<1, false, 1, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+        if (k_in <= 128) return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+        if (k_in == 256) return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+      } else if (hidden == 128 && n_out <= 80 && k_in == 256) {
+        return launch16(chain16_kernel<8, true, 1, 8, 5, EPI_DEC, false>, a, stream, 1, kLdsWeights);
+      }
+      return set_error(GW_E_UNSUPPORTED, "bf16 mlp: unsupported (hidden, n_out, k) combination");
+    case 1:
+      return launch16(chain16_kernel<8, true, 3, 16, 16, EPI_EDGE, false>, a, stream, 1, kLdsEdge);
+    case 2:
+      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+    case 3:
+      return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, true>, a, stream, grid_y, kLdsWeights);
+  }
+  return set_error(GW_E_BADARG, "chain16_launch: bad kind");
+}
+
+}  // namespace gw
+
+extern "C" {
+
+size_t gw_packed_bytes_bf16(int n_out, int k_lo, int k_hi) {
+  const int kseg = k_hi - k_lo;
+  const int nsteps = (kseg + 31) / 32;
+  const int ntp = (((n_out + 15) / 16) + 3) / 4 * 4;
+  return (size_t)nsteps * ntp * 1024;
+}
+
+int gw_pack_linear_bf16(const float* w, int n_out, int k_total, int k_lo, int k_hi, void* out, void* stream) {
+  if (!w || !out || n_out <= 0 || k_lo < 0 || k_hi <= k_lo || k_hi > k_total)
+    return gw::set_error(GW_E_BADARG, "gw_pack_linear_bf16: bad arguments");
+  const int kseg = k_hi - k_lo;
+  const int nsteps = (kseg + 31) / 32;
+  const int ntp = (((n_out + 15) / 16) + 3) / 4 * 4;
+  const size_t total = (size_t)nsteps * ntp * 512;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_linear_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, n_out, k_total, k_lo, kseg, ntp,
+                     nsteps, (__bf16*)out);
+  return gw::check_launch("pack_linear_bf16_kernel launch");
+}
+
+}  // extern "C"

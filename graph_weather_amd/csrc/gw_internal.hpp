@@ -8,6 +8,53 @@
 
 namespace gw {
 
+// Arguments of the general fused-MLP kernels (fp32: chain_kernel in gw_kernels.hip, bf16: chain16_kernel in gw_bf16.hip).
+// Weight pointers are typed float* but address the packed stream of the launch's weight dtype.
+enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
+
+struct ChainArgs {
+  int n_cols;          // total columns (batch * cols_per_batch)
+  int cols_per_batch;
+  unsigned long long* dbg;  // optional per-workgroup timestamp records (16 x u64 each), debug only
+  int dbg_cap;
+  int stagger;         // start-up delay (x 8k cycles) of every second wave of workgroups, see chain_kernel
+  // layer-1 operands
+  const float* seg_ptr[3];
+  const int* seg_idx[3];
+  int seg_rows_pb[3];
+  int seg_ld[3];
+  int seg_k[3];
+  int seg_proj[3];     // operand is already multiplied by its layer-1 weight slice: rows are [hidden] wide
+  // single-layer projection mode: blockIdx.y selects the weight slice / output table
+  const float* proj_w[4];
+  float* proj_out[4];
+  // weights
+  const float* w1[3];
+  const float* b1;
+  const float* w_mid;
+  const float* b_mid;
+  const float* w_out;
+  const float* b_out;
+  const float* gamma;
+  const float* beta;
+  int n_mid;
+  // residual
+  const float* res_ptr;
+  const int* res_idx;
+  int res_rows_pb;
+  int res_ld;
+  // outputs
+  float* out;
+  int out_ld;
+  int out_cols;
+  float* agg;
+  const int* agg_idx;
+  int agg_rows_pb;
+};
+
+// bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices).
+int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
+
 // debug timestamp hook (gw_debug_timestamps) and tuning overrides, defined in gw_kernels.hip
 extern unsigned long long* g_dbg;
 extern int g_dbg_cap;

@@ -30,48 +30,6 @@ using namespace gw;
 
 namespace {
 
-enum { EPI_ROWS = 0, EPI_EDGE = 1, EPI_DEC = 2 };
-
-struct ChainArgs {
-  int n_cols;          // total columns (batch * cols_per_batch)
-  int cols_per_batch;
-  unsigned long long* dbg;  // optional per-workgroup timestamp records (16 x u64 each), debug only
-  int dbg_cap;
-  int stagger;         // start-up delay (x 8k cycles) of every second wave of workgroups, see chain_kernel
-  // layer-1 operands
-  const float* seg_ptr[3];
-  const int* seg_idx[3];
-  int seg_rows_pb[3];
-  int seg_ld[3];
-  int seg_k[3];
-  int seg_proj[3];     // operand is already multiplied by its layer-1 weight slice: rows are [hidden] wide
-  // single-layer projection mode: blockIdx.y selects the weight slice / output table
-  const float* proj_w[4];
-  float* proj_out[4];
-  // weights
-  const float* w1[3];
-  const float* b1;
-  const float* w_mid;
-  const float* b_mid;
-  const float* w_out;
-  const float* b_out;
-  const float* gamma;
-  const float* beta;
-  int n_mid;
-  // residual
-  const float* res_ptr;
-  const int* res_idx;
-  int res_rows_pb;
-  int res_ld;
-  // outputs
-  float* out;
-  int out_ld;
-  int out_cols;
-  float* agg;
-  const int* agg_idx;
-  int agg_rows_pb;
-};
-
 // in[8c .. 8c+7] <- row[k(s,q)] for the K-steps of chunk c (full 16-byte aligned rows)
 template <int NSTEPS>
 __device__ __forceinline__ void load_operand_slice(float (&in)[NSTEPS], const float* __restrict__ row, int c, int q) {
@@ -720,6 +678,13 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   a.out = out;
   a.out_ld = out_ld;
   a.out_cols = w->n_out;
+  if (w->weight_dtype == GW_DTYPE_BF16) {
+    if (residual && w->n_out == 256 && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
+    if (w->n_out == 256 && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
+    if (x->k == 256 && x->ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input ld must be a multiple of 4");
+    if (x->k > 128 && x->k != 256) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=128 or ==256");
+    return gw::chain16_launch(0, a, x->k, w->hidden, w->n_out, 1, stream);
+  }
   if (w->hidden == 256 && w->n_out == 256) {
     if (residual && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
     if (out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
@@ -753,7 +718,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
   if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
-  if (gw::edge_fast_eligible(x_src, x_dst, e_in, w))
+  if (w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w))
     return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, stream);
   ChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -772,6 +737,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg = agg;
   a.agg_idx = dst;
   a.agg_rows_pb = n_dst;
+  if (w->weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(1, a, 256, 256, 256, 1, stream);
   return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream, 1, 1);
 }
 
@@ -798,11 +764,13 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.out = x_out;
   a.out_ld = out_ld;
   a.out_cols = 256;
+  if (w->weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(2, a, 256, 256, 256, 1, stream);
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }
 
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
-                       const float* const* w_slices, float* const* outs, int32_t out_ld, void* stream) {
+                       const float* const* w_slices, float* const* outs, int32_t out_ld, int32_t weight_dtype,
+                       void* stream) {
   if (!x || !w_slices || !outs || n_rows < 0 || rows_per_batch <= 0 || n_slices <= 0 || n_slices > 4)
     return fail(GW_E_BADARG, "gw_project_forward: bad arguments (1..4 slices)");
   if (n_rows == 0) return GW_OK;
@@ -820,6 +788,7 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   }
   a.out_ld = out_ld;
   a.out_cols = 256;
+  if (weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(3, a, 256, 256, 256, n_slices, stream);
   return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices, 3);
 }
 

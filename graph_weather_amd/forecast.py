@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from .graphs import build_forecast_graphs
-from .layers import Decoder, Encoder, Processor
+from .layers import Decoder, Encoder, Processor, set_compute_dtype
 
 try:  # forecast.py:8,61 - hub mixin gives save_pretrained / from_pretrained / push_to_hub
     from huggingface_hub import PyTorchModelHubMixin
@@ -93,6 +93,11 @@ class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
                                hidden_layers_processor_edge=hidden_layers_processor_edge, mlp_norm_type=norm_type,
                                hidden_dim_decoder=hidden_dim_decoder, hidden_layers_decoder=hidden_layers_decoder,
                                use_checkpointing=use_checkpointing, _graphs=graphs)
+
+    def set_compute_dtype(self, dtype: torch.dtype) -> "GraphWeatherForecaster":
+        """float32 (default) or bfloat16 matrix products - see ``layers.set_compute_dtype``."""
+        set_compute_dtype(self, dtype)
+        return self
 
     def _create_grid_mapping(self, unique_lats, unique_lons):
         """forecast.py:178-192 (vectorised; identical (row, col) pairs)."""

@@ -30,6 +30,23 @@ def _version_key(params) -> tuple:
     return tuple((p.data_ptr(), p._version, p.device) for p in params)
 
 
+def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
+    """Select the matrix-product dtype of every MLP under ``module``: ``torch.float32`` (default, the reference's
+    arithmetic) or ``torch.bfloat16`` (bf16 MFMA with fp32 accumulation; parameters, activations in HBM, LayerNorm,
+    residuals and segment sums stay fp32) - what a reference user gets from ``torch.autocast(dtype=torch.bfloat16)``."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32 or torch.bfloat16")
+    for m in module.modules():
+        if isinstance(m, MLP):
+            m.compute_dtype = dtype
+        for attr in ("_cache",):
+            if hasattr(m, attr):
+                getattr(m, attr).clear()
+        if hasattr(m, "_e0_cache"):
+            m._e0_cache = None
+    return module
+
+
 class MLP(nn.Module):
     """``MLP`` - graph_net_block.py:17-77.  ``model`` is the same nn.Sequential layout (Linear/ReLU.../[LayerNorm])."""
 
@@ -50,6 +67,9 @@ class MLP(nn.Module):
         self._packed: Optional[PackedMLP] = None
         self._packed_key = None
         self._splits: Tuple[Tuple[int, int], ...] = ((0, in_dim),)
+        # dtype of the matrix products: float32 (fp32 MFMA, bitwise an fmaf chain) or bfloat16 (bf16 MFMA, fp32
+        # accumulate); parameters and activations stay fp32 either way.  Set through set_compute_dtype().
+        self.compute_dtype = torch.float32
 
     def set_input_splits(self, splits) -> None:
         """Column slices of layer 1 fed by separate operands (``cat`` order of the reference)."""
@@ -63,14 +83,15 @@ class MLP(nn.Module):
         lin = self._linears()
         norm = self.model[-1] if isinstance(self.model[-1], nn.LayerNorm) else None
         params = [p for m in lin for p in (m.weight, m.bias)] + ([norm.weight, norm.bias] if norm is not None else [])
-        key = _version_key(params)
+        key = (_version_key(params), self.compute_dtype)
         if self._packed is None or key != self._packed_key:
             if not lin[0].weight.is_cuda:
                 raise RuntimeError("graph_weather_amd: module parameters must be on a HIP device (no CPU path exists)")
             if norm is not None and abs(norm.eps - 1e-5) > 0:
                 raise RuntimeError("graph_weather_amd: LayerNorm eps must be 1e-5")
             self._packed = PackedMLP([m.weight for m in lin], [m.bias for m in lin],
-                                     (norm.weight, norm.bias) if norm is not None else None, self._splits)
+                                     (norm.weight, norm.bias) if norm is not None else None, self._splits,
+                                     self.compute_dtype)
             self._packed_key = key
         return self._packed
 

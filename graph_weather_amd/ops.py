@@ -80,8 +80,12 @@ class PackedMLP:
     """Device-resident packed form of one reference ``MLP`` (graph_net_block.py:45-61)."""
 
     def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-                 ln: Optional[Tuple[torch.Tensor, torch.Tensor]], splits: Sequence[Tuple[int, int]]):
+                 ln: Optional[Tuple[torch.Tensor, torch.Tensor]], splits: Sequence[Tuple[int, int]],
+                 compute_dtype: torch.dtype = torch.float32):
         L = _lib.lib()
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32 or torch.bfloat16")
+        self.weight_dtype = _lib.DTYPE_BF16 if compute_dtype == torch.bfloat16 else _lib.DTYPE_F32
         n_lin = len(weights)
         if n_lin < 2:
             raise RuntimeError("graph_weather_amd: MLP needs at least one hidden layer")
@@ -97,6 +101,12 @@ class PackedMLP:
 
         def pack(w, k_lo, k_hi):
             w = w.detach().contiguous().float()
+            if self.weight_dtype == _lib.DTYPE_BF16:  # bf16 MFMA A-operand stream (rounded to nearest even)
+                nb = L.gw_packed_bytes_bf16(int(w.shape[0]), k_lo, k_hi)
+                out = torch.empty(nb // 2, dtype=torch.bfloat16, device=dev)
+                _lib.check(L.gw_pack_linear_bf16(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), k_lo, k_hi, out.data_ptr(),
+                                                 st), "gw_pack_linear_bf16")
+                return out
             n = L.gw_packed_floats(int(w.shape[0]), k_lo, k_hi)
             out = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(L.gw_pack_linear(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), k_lo, k_hi, out.data_ptr(), st),
@@ -133,6 +143,7 @@ class PackedMLP:
         w.ln_gamma = self.gamma.data_ptr() if self.gamma is not None else None
         w.ln_beta = self.beta.data_ptr() if self.beta is not None else None
         w.hidden, w.n_mid, w.n_out = self.hidden, self.n_mid, self.n_out
+        w.weight_dtype = self.weight_dtype
         return w
 
 
@@ -153,7 +164,8 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
     return out
 
 
-def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, rows_per_batch: int) -> List[torch.Tensor]:
+def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, rows_per_batch: int,
+                    weight_dtype: Optional[int] = None) -> List[torch.Tensor]:
     """out_s = x . W_s^T for up to four packed [256, 256] layer-1 slices in one launch (layer-1 split of
     graph_net_block.py:131-134 / :189: products over node tables are shared by all incident edges)."""
     import ctypes
@@ -163,8 +175,10 @@ def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, r
     outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=dev) for _ in range(n)]
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w_slices])
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
-    _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, _stream(outs[0])),
-               "gw_project_forward")
+    if weight_dtype is None:
+        weight_dtype = _lib.DTYPE_BF16 if w_slices[0].dtype == torch.bfloat16 else _lib.DTYPE_F32
+    _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, weight_dtype,
+                                             _stream(outs[0])), "gw_project_forward")
     return outs
 
 

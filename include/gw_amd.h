@@ -31,7 +31,13 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 1
+#define GW_ABI_VERSION 2
+
+/* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
+ * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
+ * in registers - BASELINE.json configs[2]. */
+#define GW_DTYPE_F32 0
+#define GW_DTYPE_BF16 1
 
 /* Library / ABI version and last error text (thread local). */
 int gw_version(void);
@@ -47,6 +53,9 @@ int gw_debug_timestamps(void* buffer, int capacity_workgroups, int kind);
 size_t gw_packed_floats(int n_out, int k_lo, int k_hi);
 /* w: device pointer to [n_out, k_total] fp32 (nn.Linear.weight); out: gw_packed_floats() floats. */
 int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, float* out, void* stream);
+/* bf16 form of the packed stream (byte size / packing); same arguments, out receives gw_packed_bytes_bf16() bytes. */
+size_t gw_packed_bytes_bf16(int n_out, int k_lo, int k_hi);
+int gw_pack_linear_bf16(const float* w, int n_out, int k_total, int k_lo, int k_hi, void* out, void* stream);
 /* Zero-pad a vector (bias / LayerNorm gamma, beta) to a multiple of 32 floats. out has gw_padded_n(n). */
 int gw_padded_n(int n);
 int gw_pad_vector(const float* v, int n, float* out, void* stream);
@@ -76,6 +85,7 @@ typedef struct gw_mlp_weights {
   int32_t hidden;      /* 128 or 256 */
   int32_t n_mid;       /* hidden_layers - 1 */
   int32_t n_out;       /* 256, or <= 80 for the decoder head */
+  int32_t weight_dtype; /* GW_DTYPE_F32: streams from gw_pack_linear; GW_DTYPE_BF16: streams from gw_pack_linear_bf16 */
 } gw_mlp_weights;
 
 /* ---- MLP.forward (graph_net_block.py:63-77) applied to rows --------------------------------------------
@@ -91,7 +101,8 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
  * edges incident to a node, and the ones over batch-independent tables are cacheable.)
  * out_s[c, :] = x[c, :256] . W_s^T for s < n_slices (<= 4); W_s = packed [256, 256] slices from gw_pack_linear. */
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
-                       const float* const* w_slices, float* const* outs, int32_t out_ld, void* stream);
+                       const float* const* w_slices, float* const* outs, int32_t out_ld,
+                       int32_t weight_dtype /* GW_DTYPE_* of the slices */, void* stream);
 
 /* ---- EdgeProcessor.forward + scatter_sum (graph_net_block.py:131-137 and :188) --------------------------
  * For every batch element b and edge e (dst-sorted):

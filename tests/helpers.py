@@ -83,3 +83,28 @@ def mfma_16x16x4_emulate(a_lane: np.ndarray, b_lane: np.ndarray, acc: np.ndarray
         for r in range(4):
             out[r, lane] += D[4 * (lane >> 4) + r, lane & 15]
     return out
+
+
+def k16_of(s: int, q: int, i: int) -> int:
+    """K walk order of the bf16 kernels: K-step s (32 wide), lane quarter q, element i of the 8-vector."""
+    return 32 * s + 16 * (i >> 2) + 4 * q + (i & 3)
+
+
+def pack_linear_bf16_ref(w: np.ndarray, k_lo: int, k_hi: int) -> np.ndarray:
+    """numpy statement of gw_pack_linear_bf16's layout: out[s][tile][lane][i] (float32 values before rounding)."""
+    n_out = w.shape[0]
+    kseg = k_hi - k_lo
+    nsteps = (kseg + 31) // 32
+    ntp = (((n_out + 15) // 16) + 3) // 4 * 4
+    out = np.zeros((nsteps, ntp, 64, 8), dtype=np.float32)
+    for s in range(nsteps):
+        for lane in range(64):
+            for i in range(8):
+                kk = k16_of(s, lane >> 4, i)
+                if kk >= kseg:
+                    continue
+                for tile in range(ntp):
+                    f = 16 * tile + (lane & 15)
+                    if f < n_out:
+                        out[s, tile, lane, i] = w[f, k_lo + kk]
+    return out

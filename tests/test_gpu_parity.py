@@ -36,7 +36,7 @@ def _golden(golden_dir, name):
 
 def test_extension_is_loaded():
     L = _lib.lib()
-    assert L.gw_version() == 1
+    assert L.gw_version() == 2
     assert torch.cuda.is_available()
 
 
@@ -256,3 +256,79 @@ def test_quarter_degree_stress_properties():
     delta = (y1 - f1[..., :78]).abs().max().item()
     assert delta > 1e-3, "forecast must differ from the input with non-zero weights"
     print(f"[stress] 0.25deg: build {t_build:.1f}s, forward B=1 {1e3 * t_fwd:.1f} ms, max|delta| {delta:.3f}")
+
+
+# ---- bf16 matrix products (BASELINE.json configs[2]); parity is reported against the fp32 oracle, bar 3e-2 of scale ----
+BF16_REL = 3e-2
+
+
+@pytest.mark.parametrize("n_out,k_total,k_lo,k_hi", [(256, 768, 256, 512), (256, 102, 0, 102), (78, 128, 0, 128), (256, 2, 0, 2)])
+def test_pack_linear_bf16_matches_layout_statement(n_out, k_total, k_lo, k_hi):
+    from .helpers import pack_linear_bf16_ref
+
+    rs = np.random.RandomState(0)
+    w = rs.standard_normal((n_out, k_total)).astype(np.float32)
+    L = _lib.lib()
+    nb = L.gw_packed_bytes_bf16(n_out, k_lo, k_hi)
+    wd = torch.from_numpy(w).to(DEV)
+    out = torch.empty(nb // 2, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gw_pack_linear_bf16(wd.data_ptr(), n_out, k_total, k_lo, k_hi, out.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "pack bf16")
+    ref = torch.from_numpy(pack_linear_bf16_ref(w, k_lo, k_hi).reshape(-1)).to(torch.bfloat16)  # RNE, like the kernel
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("i,o,h,norm,rows", [(102, 256, 256, "LayerNorm", 1000), (2, 256, 256, "LayerNorm", 300),
+                                             (256, 78, 128, None, 515), (256, 256, 256, "LayerNorm", 1)])
+def test_bf16_mlp_vs_oracle(i, o, h, norm, rows):
+    m = gw.MLP(i, o, h, 2, norm)
+    deterministic_fill_(m, seed=21)
+    x = torch.from_numpy(np.random.RandomState(rows).standard_normal((rows, i)).astype(np.float32))
+    ref = om.mlp({"m." + k: v for k, v in m.state_dict().items()}, "m", x)
+    gw.set_compute_dtype(m, torch.bfloat16)
+    y = m.to(DEV)(x.to(DEV))
+    rel = _close(y, ref, rel=BF16_REL, what=f"bf16 mlp {i}->{o}")
+    assert rel > 1e-5, "bf16 path suspiciously exact: is it really running bf16?"
+
+
+def test_bf16_graph_processor_edge_cases_vs_oracle():
+    gp = gw.GraphProcessor(mp_iterations=2, in_dim_node=256, in_dim_edge=256, hidden_dim_node=256, hidden_dim_edge=256)
+    deterministic_fill_(gp, seed=8)
+    p = {"gp." + k: v.clone() for k, v in gp.state_dict().items()}
+    gw.set_compute_dtype(gp, torch.bfloat16)
+    gp = gp.to(DEV)
+    rs = np.random.RandomState(3)
+    n = 300
+    x = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
+    for e in (0, 5, 2000):
+        src = rs.randint(0, n, size=e)
+        dst = np.where(rs.rand(e) < 0.3, 7, rs.randint(0, n, size=e)) if e else np.zeros(0, dtype=np.int64)
+        ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+        ea = torch.from_numpy(rs.standard_normal((e, 256)).astype(np.float32))
+        xr, er = om.graph_processor(p, "gp", x, ei, ea)
+        xo, eo = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
+        _close(xo, xr, rel=BF16_REL, what=f"bf16 E={e} x")
+        if e:
+            _close(eo, er, rel=BF16_REL, what=f"bf16 E={e} e")
+
+
+def test_bf16_forecaster_vs_oracle_10deg():
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    feats = seeded_features(2, len(lat_lons), 102, seed=42)
+    y_ref = om.forecaster_forward(sd, model.encoder.graphs.as_oracle_dict(), feats)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y32 = model(feats.to(DEV))
+        model.set_compute_dtype(torch.bfloat16)
+        y16 = model(feats.to(DEV))
+        model.set_compute_dtype(torch.float32)
+        y32b = model(feats.to(DEV))
+    d_ref = y_ref - feats[..., :78]
+    rel32 = _close(y32.cpu() - feats[..., :78], d_ref, what="fp32 delta")
+    rel16 = _close(y16.cpu() - feats[..., :78], d_ref, rel=BF16_REL, what="bf16 delta")
+    _close(y32b, y32, rel=1e-6, what="switching back to fp32")
+    print(f"[parity] 10deg: rel err of decoder delta fp32 {rel32:.2e}, bf16 {rel16:.2e}")
+    assert rel16 > 10 * rel32
