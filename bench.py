@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 acc
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 EDGE_MLP_FLOPS = 2 * (768 * 256 + 256 * 256 + 256 * 256)  # per edge, SURVEY.md 8(d): mlp(768,256,256) - algorithmic
 # What the decoder edge kernel executes on the matrix cores after the layer-1 split: x_dst == 0 and the x_src / e
 # products are gathered (per-node product, cached per-edge product) -> only the two 256x256 layers remain per edge.
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=float, default=1.0, help="grid spacing in degrees (1.0 = BASELINE configs[1])")
     ap.add_argument("--batch", type=int, default=2, help="batch per GPU")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="matrix-product dtype: fp32 = BASELINE configs[1] (default), bf16 = configs[2] (use --batch 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,6 +118,8 @@ def main():
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     graphs = model.encoder.graphs
     model = model.to(dev).eval()
+    if args.precision == "bf16":
+        model.set_compute_dtype(torch.bfloat16)
     feats = seeded_features(args.batch, len(lat_lons), 102, seed=42 + rank).to(dev)  # resident in HBM before timing
 
     def barrier():
@@ -145,7 +150,8 @@ def main():
         flops = EDGE_MLP_FLOPS * e_dec * args.batch
         achieved = flops / (dec_ms * 1e-3) / 1e12
         executed = DEC_EDGE_EXECUTED_FLOPS * e_dec * args.batch / (dec_ms * 1e-3) / 1e12
-        traffic, pmc = pmc_traffic() if (args.grid == 1.0 and args.batch == 2) else (None, None)
+        traffic, pmc = pmc_traffic() if (args.grid == 1.0 and args.batch == 2 and args.precision == "fp32") else (None, None)
+        peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_BF16_MATRIX_TFLOPS
         # algorithmic HBM bytes of one decoder edge launch: per (sample, edge) the cached product row and the residual
         # edge-feature row (2 x 1 KiB), per destination row one 1 KiB sum written; indices 8 B per edge
         alg_bytes = args.batch * e_dec * (2 * 1024 + 8) + args.batch * len(lat_lons) * 1024
@@ -153,16 +159,17 @@ def main():
             "metric": "forward forecasts/sec (1° grid, 102→78 feat)", "value": world * args.batch * args.steps / elapsed,
             "unit": "forecasts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands; fp32 accumulate, fp32 storage / LayerNorm / sums)",
+            "data": "synthetic",
             "config": {"workload": f"GraphWeatherForecaster {args.grid:g}deg grid ({len(lat_lons)} nodes), 102->78 feat, "
-                                   f"batch={args.batch} per GPU, fp32, mesh res 2 (5882 nodes), random-init weights",
+                                   f"batch={args.batch} per GPU, {args.precision}, mesh res 2 (5882 nodes), random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
-            "roofline": {"bound": "mfma", "kernel": "chain_kernel<EDGE> (decoder edge update)", "achieved": achieved,
-                         "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "edge_kernel (decoder edge update)", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_decoder_edge.json)",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mfma_busy_frac_pmc": None if pmc is None else pmc.get("mfma_busy_frac"), "launch_ms": dec_ms, "algorithmic_flops_per_launch": flops,
-                         "executed_tflops": executed, "executed_frac": executed / PEAK_F32_MATRIX_TFLOPS,
+                         "executed_tflops": executed, "executed_frac": executed / peak,
                          "note": "achieved/frac use the ALGORITHMIC flops of the reference edge MLP (768->256->256->256 per "
                                  "edge); the kernel legally executes fewer (layer-1 split), executed_* is the MFMA work it runs",
                          "other_kernels_ms": {"processor_edge": timer.mean_ms("processor_edge"),

@@ -65,8 +65,8 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // One layer pass: acc[g][t] += W[16t.., k] . bin[g][k], K = 32 KS, NT row tiles, NTP = tiles per K-step in the packed
 // stream (NT rounded up to 4).  The stream of this pass starts at gw; its first chunk has already been issued into
 // buffer `parity`; while the last chunk computes, the first chunk of the next pass (next_gw, next_bytes) is issued.
-template <int KS, int NT, int NTP>
-__device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)[NG][KS], const char* __restrict__ gw,
+template <int KS, int BKS, int NT, int NTP>
+__device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)[NG][BKS], const char* __restrict__ gw,
                                        const char* __restrict__ next_gw, int next_bytes, const char* lds, int& parity,
                                        int lane, int wave) {
   constexpr int STEP_BYTES = NTP * 1024;
@@ -200,31 +200,32 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   }
 
   // ---- layer 1 ----
+  // One accumulator array and one B-operand array serve every layer (the output layer gets its own accumulator only
+  // when its tile count differs from the hidden one): register allocation does not reuse them otherwise.
+  constexpr int BKS = K1S > HKS ? K1S : HKS;
+  constexpr bool SHARE_ACC = (OT == HT);
   f32x4 acc[NG][HT];
+  bf16x8 bin[NG][BKS];
   init_bias16<HT>(acc, a.b1, q);
   {
-    bf16x8 bin[NG][K1S];
 #pragma unroll
     for (int i = 0; i < NSEG; ++i) {
       if (on[i]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
-          load_raw16<K1S, K1FULL>(bin[g], row, a.seg_k[i], q);
+          load_raw16<K1S, K1FULL>(reinterpret_cast<bf16x8(&)[K1S]>(bin[g]), row, a.seg_k[i], q);
           __builtin_amdgcn_sched_barrier(0);
         }
-        bool more = false;
         const char* nx = after_l1;
         int nb = after_l1_bytes;
 #pragma unroll
         for (int i2 = NSEG - 1; i2 > i; --i2)
           if (on[i2]) {
-            more = true;
             nx = w1[i2];
             nb = K1FIRST;
           }
-        (void)more;
-        pass16<K1S, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave);
+        pass16<K1S, BKS, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave);
       } else if (prj[i]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -239,33 +240,27 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     }
   }
 
-  f32x4 o[NG][OT];
-  if constexpr (SINGLE) {
-    static_assert(!SINGLE || HT == OT, "single-layer mode stores the layer-1 accumulator");
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int t = 0; t < OT; ++t) o[g][t] = acc[g][t < HT ? t : 0];
-  } else {
-    bf16x8 hin[NG][HKS];
+  f32x4 o_sep[SHARE_ACC ? 1 : NG][SHARE_ACC ? 1 : OT];
+  f32x4 (&o)[NG][OT] = *reinterpret_cast<f32x4(*)[NG][OT]>(SHARE_ACC ? (void*)acc : (void*)o_sep);
+  if constexpr (!SINGLE) {
     // ---- middle layers (hidden -> hidden) ----
 #pragma unroll 1
     for (int l = 0; l < a.n_mid; ++l) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g) relu_to_bin<HT>(hin[g], acc[g]);
+      for (int g = 0; g < NG; ++g) relu_to_bin<HT>(reinterpret_cast<bf16x8(&)[HKS]>(bin[g]), acc[g]);
       __builtin_amdgcn_sched_barrier(0);
       init_bias16<HT>(acc, a.b_mid + l * (HT * 16), q);
       const bool last = (l + 1 == a.n_mid);
       const char* nx = last ? w_out : w_mid + (size_t)(l + 1) * HKS * H_STEP;
       const int nb = last ? O_CS * O_STEP : H_CS * H_STEP;
-      pass16<HKS, HT, HTP>(acc, hin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave);
+      pass16<HKS, BKS, HT, HTP>(acc, bin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave);
     }
     // ---- output layer ----
 #pragma unroll
-    for (int g = 0; g < NG; ++g) relu_to_bin<HT>(hin[g], acc[g]);
+    for (int g = 0; g < NG; ++g) relu_to_bin<HT>(reinterpret_cast<bf16x8(&)[HKS]>(bin[g]), acc[g]);
     __builtin_amdgcn_sched_barrier(0);
     init_bias16<OT>(o, a.b_out, q);
-    pass16<HKS, OT, OTP>(o, hin, w_out, nullptr, 0, lds16, parity, lane, wave);
+    pass16<HKS, BKS, OT, OTP>(o, bin, w_out, nullptr, 0, lds16, parity, lane, wave);
   }
 
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
