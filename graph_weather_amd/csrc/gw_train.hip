@@ -1,0 +1,305 @@
+// gw_train.hip - building blocks of the backward pass / training step of the hot path (SURVEY.md section 8f row 1,
+// appendix G): what autograd launches through ATen + torch_scatter in the reference (train/run.py:509-521:
+// loss.backward(); optimizer.step()).  First, correctness-oriented version: activations are materialised in HBM by the
+// forward kernels ("save" pointers) and the backward is composed from the generic kernels below.
+//
+//   gw_gemm_f32            fp32-MFMA GEMM with bounds checks: NN (input gradients  dX = dZ . W) and
+//                          TN (weight gradients dW += dZ^T . X, split over row slabs, accumulated with atomics)
+//   gw_relu_backward       dZ = dH * (H > 0) and bias gradient db += column sums of dZ        (nn.ReLU / nn.Linear.bias)
+//   gw_layernorm_backward  dY, dgamma +=, dbeta += from dN and the saved pre-norm rows        (nn.LayerNorm, eps 1e-5)
+//   gw_gather_rows         out[b, k] = table[b, idx[k]] (+ add[b, k])     dual of the segment sum (graph_net_block.py:188)
+//   gw_segment_sum_rows    out[b, n] (+)= sum_{i in seg(n)} rows[b, perm[i]]      dual of the x[row] / x[col] gathers (:221-228)
+//   gw_normalized_mse_backward, gw_adamw_step
+// All fp32; matrix products are fmaf chains on v_mfma_f32_16x16x4_f32 like the forward.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gw_device.hpp"
+#include "gw_internal.hpp"
+
+using namespace gw;
+
+namespace {
+
+// ---- GEMM ------------------------------------------------------------------------------------------------------------
+// Block = 4 waves, block tile 64 (m) x 64 (n); wave w owns rows 16w..16w+15 of the tile, 4 MFMA tiles along n.
+// TN: C[m][n] += sum_k A[k][m] * B[k][n]   (k = row index of both operands; blockIdx.z = slab of k; atomics)
+// NN: C[m][n]  = sum_k A[m][k] * B[k][n]
+template <bool TN>
+__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                   const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                   int k_slab) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 64 + wave * 16;
+  const int n0 = blockIdx.y * 64;
+  const int k_begin = TN ? blockIdx.z * k_slab : 0;
+  const int k_end = TN ? (k_begin + k_slab < K ? k_begin + k_slab : K) : K;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int m = m0 + i;
+  const bool m_ok = m < M;
+#pragma unroll 4
+  for (int k0 = k_begin; k0 < k_end; k0 += 4) {
+    const int k = k0 + kq;
+    const bool k_ok = k < k_end;
+    float a = 0.f;
+    if (m_ok && k_ok) a = TN ? ldg1(A + (size_t)k * lda + m) : ldg1(A + (size_t)m * lda + k);
+    float b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = n0 + 16 * t + i;
+      b[t] = (k_ok && n < N) ? ldg1(B + (size_t)k * ldb + n) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+  }
+  // D layout: column (n) = lane & 15, rows (m) = 4 * (lane >> 4) + r
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mm = m0 + 4 * kq + r;
+      if (mm < M && n < N) {
+        float* p = C + (size_t)mm * ldc + n;
+        if (TN) __hip_atomic_fetch_add((GW_AS1 float*)p, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else stg1(p, acc[t][r]);
+      }
+    }
+  }
+}
+
+// ---- ReLU backward + bias gradient ----------------------------------------------------------------------------------
+// thread t owns column t of a strip of rows: dz = dh * (h > 0) (h == nullptr: no mask), db[t] += sum of dz over the strip
+__global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t rows, int width, const float* __restrict__ dh, int ld_dh,
+                                                       const float* __restrict__ h, int ld_h, float* __restrict__ dz, int ld_dz,
+                                                       float* __restrict__ db, int strip) {
+  const int col = threadIdx.x;
+  if (col >= width) return;
+  const int64_t r0 = (int64_t)blockIdx.x * strip;
+  const int64_t r1 = r0 + strip < rows ? r0 + strip : rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    float g = dh[r * ld_dh + col];
+    if (h != nullptr && !(h[r * ld_h + col] > 0.f)) g = 0.f;
+    if (dz != nullptr) dz[r * ld_dz + col] = g;
+    s += g;
+  }
+  if (db != nullptr) __hip_atomic_fetch_add(db + col, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- LayerNorm backward (width 256, eps 1e-5, biased variance) --------------------------------------------------------
+// one wave per row (lane l owns columns 4l..4l+3); a block walks a strip of rows, 4 at a time
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t rows, const float* __restrict__ dn, int ld_dn,
+                                                     const float* __restrict__ y, int ld_y, const float* __restrict__ gamma,
+                                                     float* __restrict__ dy, int ld_dy, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int strip) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * strip;
+  const int64_t r1 = r0 + strip < rows ? r0 + strip : rows;
+  const f32x4 gm = *(const f32x4*)(gamma + 4 * lane);
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, dbt = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + wave; r < r1; r += 4) {
+    const f32x4 yv = *(const f32x4*)(y + r * ld_y + 4 * lane);
+    const f32x4 dv = *(const f32x4*)(dn + r * ld_dn + 4 * lane);
+    float s = (yv.x + yv.y) + (yv.z + yv.w);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.0f / 256.0f);
+    f32x4 d = yv - mean;
+    float v = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / 256.0f) + 1e-5f);
+    const f32x4 xh = d * rstd;
+    const f32x4 g = dv * gm;
+    float sg = (g.x + g.y) + (g.z + g.w);
+    float sgx = g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sg += __shfl_xor(sg, off);
+      sgx += __shfl_xor(sgx, off);
+    }
+    const float mg = sg * (1.0f / 256.0f), mgx = sgx * (1.0f / 256.0f);
+    const f32x4 out = (g - mg - xh * mgx) * rstd;
+    *(f32x4*)(dy + r * ld_dy + 4 * lane) = out;
+    dg += dv * xh;
+    dbt += dv;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (dgamma) __hip_atomic_fetch_add(dgamma + 4 * lane + c, dg[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dbeta) __hip_atomic_fetch_add(dbeta + 4 * lane + c, dbt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- gather / segment sum of 256-float rows --------------------------------------------------------------------------
+// out[b * n_idx + k] = table[(b * rows_pb + idx[k])] (+ add[b * n_idx + k]);  one wave per output row
+__global__ __launch_bounds__(256) void gather_rows_kernel(int batch, int n_idx, const float* __restrict__ table, int rows_pb,
+                                                          const int* __restrict__ idx, const float* __restrict__ add,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= (int64_t)batch * n_idx) return;
+  const int b = (int)(c / n_idx), k = (int)(c - (int64_t)b * n_idx);
+  const int r = idx ? idx[k] : k;
+  f32x4 v = *(const f32x4*)(table + ((size_t)b * rows_pb + r) * 256 + 4 * lane);
+  if (add) v += *(const f32x4*)(add + (size_t)c * 256 + 4 * lane);
+  *(f32x4*)(out + (size_t)c * 256 + 4 * lane) = v;
+}
+
+// out[bo * n_seg + n] (+)= sum_{b in group(bo)} sum_{i = ptr[n] .. ptr[n+1]-1} rows[(b * rows_pb_in + perm[i])]
+// batch_out == batch: per-sample sums;  batch_out == 1: also summed over the batch (tables shared by the batch).
+__global__ __launch_bounds__(256) void segment_sum_kernel(int batch, int batch_out, int n_seg, const float* __restrict__ rows,
+                                                          int rows_pb_in, const int* __restrict__ perm,
+                                                          const int* __restrict__ ptr, float* __restrict__ out, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (int64_t)batch_out * n_seg) return;
+  const int bo = (int)(o / n_seg), n = (int)(o - (int64_t)bo * n_seg);
+  const int i0 = ptr[n], i1 = ptr[n + 1];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const int b_lo = batch_out == 1 ? 0 : bo, b_hi = batch_out == 1 ? batch : bo + 1;
+  for (int b = b_lo; b < b_hi; ++b)
+    for (int i = i0; i < i1; ++i) {
+      const int r = perm ? perm[i] : i;
+      s += *(const f32x4*)(rows + ((size_t)b * rows_pb_in + r) * 256 + 4 * lane);
+    }
+  float* p = out + (size_t)o * 256 + 4 * lane;
+  if (accumulate) s += *(const f32x4*)p;
+  *(f32x4*)p = s;
+}
+
+// ---- loss backward, optimiser ---------------------------------------------------------------------------------------
+__global__ void nmse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                const float* __restrict__ inv_var, const float* __restrict__ lat_w, int num_lon, int nodes,
+                                int channels, size_t total, float scale, const float* __restrict__ dloss,
+                                float* __restrict__ dpred) {
+  const float g = dloss[0] * scale;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / channels;
+    const int ch = (int)(i - row * channels);
+    const int n = (int)(row % nodes);
+    float d = 2.0f * (pred[i] - target[i]) * lat_w[n / num_lon] * g;
+    if (inv_var) d *= inv_var[ch];
+    dpred[i] = d;
+  }
+}
+
+// torch.optim.AdamW (decoupled weight decay, bias-corrected, amsgrad off): one fused elementwise pass
+__global__ void adamw_kernel(size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                             float bc2_sqrt) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+int fail(int code, const char* msg) { return set_error(code, msg); }
+
+}  // namespace
+
+extern "C" {
+
+int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
+                float* c, int32_t ldc, void* stream) {
+  if (!a || !b || !c || m < 0 || n < 0 || k < 0 || (mode != GW_GEMM_NN && mode != GW_GEMM_TN))
+    return fail(GW_E_BADARG, "gw_gemm_f32: bad arguments");
+  if (m == 0 || n == 0) return GW_OK;
+  if (m >= ((int64_t)1 << 31) || k >= ((int64_t)1 << 31)) return fail(GW_E_UNSUPPORTED, "gw_gemm_f32: dimension exceeds int32");
+  const dim3 block(256);
+  if (mode == GW_GEMM_TN) {
+    if (k == 0) return GW_OK;  // nothing to add
+    const int k_slab = 2048;
+    const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)((k + k_slab - 1) / k_slab));
+    hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, k_slab);
+  } else {
+    const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), 1);
+    hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, 0);
+  }
+  return check_launch("gemm_kernel launch");
+}
+
+int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
+                     int32_t ld_dz, float* db, void* stream) {
+  if (!dh || rows < 0 || width <= 0 || width > 256) return fail(GW_E_BADARG, "gw_relu_backward: bad arguments (width <= 256)");
+  if (rows == 0) return GW_OK;
+  const int strip = 128;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, width,
+                     dh, ld_dh, h, ld_h, dz, ld_dz, db, strip);
+  return check_launch("relu_bwd_kernel launch");
+}
+
+int gw_layernorm_backward(int64_t rows, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y, const float* gamma,
+                          float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream) {
+  if (!dn || !y || !gamma || !dy || rows < 0 || (ld_dn | ld_y | ld_dy) % 4 != 0)
+    return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments (width 256, strides multiple of 4)");
+  if (rows == 0) return GW_OK;
+  const int strip = 256;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, dn, ld_dn,
+                     y, ld_y, gamma, dy, ld_dy, dgamma, dbeta, strip);
+  return check_launch("ln_bwd_kernel launch");
+}
+
+int gw_gather_rows(int32_t batch, int32_t n_idx, const float* table, int32_t rows_per_batch, const int32_t* idx,
+                   const float* add, float* out, void* stream) {
+  if (!table || !out || batch <= 0 || n_idx < 0) return fail(GW_E_BADARG, "gw_gather_rows: bad arguments");
+  const int64_t total = (int64_t)batch * n_idx;
+  if (total == 0) return GW_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, batch, n_idx, table,
+                     rows_per_batch, idx, add, out);
+  return check_launch("gather_rows_kernel launch");
+}
+
+int gw_segment_sum_rows(int32_t batch, int32_t batch_out, int32_t n_seg, const float* rows, int32_t rows_per_batch_in,
+                        const int32_t* perm, const int32_t* ptr, float* out, int32_t accumulate, void* stream) {
+  if (!rows || !ptr || !out || batch <= 0 || n_seg < 0 || (batch_out != batch && batch_out != 1))
+    return fail(GW_E_BADARG, "gw_segment_sum_rows: bad arguments");
+  const int64_t total = (int64_t)batch_out * n_seg;
+  if (total == 0) return GW_OK;
+  hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, batch, batch_out,
+                     n_seg, rows, rows_per_batch_in, perm, ptr, out, accumulate);
+  return check_launch("segment_sum_kernel launch");
+}
+
+int gw_normalized_mse_backward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,
+                               int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, const float* dloss,
+                               float* dpred, void* stream) {
+  if (!pred || !target || !lat_weights || !dloss || !dpred || num_unique_lat <= 0 || batch <= 0 || nodes <= 0 || channels <= 0)
+    return fail(GW_E_BADARG, "gw_normalized_mse_backward: bad arguments");
+  const int num_lon = nodes / num_unique_lat;
+  if (num_lon <= 0) return fail(GW_E_BADARG, "gw_normalized_mse_backward: nodes must equal num_unique_lat * num_lon");
+  const size_t total = (size_t)batch * nodes * channels;
+  const float scale = 1.0f / ((float)channels * (float)batch * (float)nodes);
+  int grid = (int)((total + 1023) / 1024);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(nmse_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, inv_var, lat_weights, num_lon,
+                     nodes, channels, total, scale, dloss, dpred);
+  return check_launch("nmse_bwd_kernel launch");
+}
+
+int gw_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step <= 0) return fail(GW_E_BADARG, "gw_adamw_step: bad arguments");
+  if (n == 0) return GW_OK;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  int grid = (int)((n + 1023) / 1024);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg, exp_avg_sq, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+  return check_launch("adamw_kernel launch");
+}
+
+}  // extern "C"

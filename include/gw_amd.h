@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 2
+#define GW_ABI_VERSION 3
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -129,6 +129,51 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
 int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var /* NULL or [c] */,
                               const float* lat_weights, int32_t num_unique_lat, int32_t batch, int32_t nodes,
                               int32_t channels, float* loss_out, void* stream);
+
+/* =====================================================================================================================
+ * Backward / training step (reference: autograd through the same modules + torch.optim.AdamW, train/run.py:509-521;
+ * SURVEY.md 8f row 1).  The forward entry points above take an optional gw_activation_save: when given, the fused
+ * kernels also write the activations autograd would have saved; the backward is then composed from the generic
+ * kernels below (all fp32, matrix products on the fp32 MFMA like the forward).
+ * ===================================================================================================================== */
+
+/* Activations written by a forward call for its backward (all row-major fp32, one row per column of the launch):
+ * hidden[l] = relu output of Linear l (l = 0 .. n_mid), hidden_ld floats per row (>= hidden width);
+ * pre_norm = output of the last Linear before LayerNorm (NULL when the MLP has no norm). */
+typedef struct gw_activation_save {
+  float* hidden;        /* [(n_mid + 1), n_rows, hidden_ld] */
+  int64_t hidden_stride; /* floats between consecutive hidden layers */
+  int32_t hidden_ld;
+  float* pre_norm;      /* [n_rows, 256] or NULL */
+} gw_activation_save;
+
+#define GW_GEMM_NN 0 /* C[m][n]  = sum_k A[m][k] * B[k][n]   (input gradients:  dX = dZ . W)                         */
+#define GW_GEMM_TN 1 /* C[m][n] += sum_k A[k][m] * B[k][n]   (weight gradients: dW += dZ^T . X; C must hold the sum) */
+int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
+                float* c, int32_t ldc, void* stream);
+/* nn.ReLU backward fused with the nn.Linear bias gradient: dz = dh * (h > 0) (h NULL: dz = dh), db[c] += sum_r dz[r][c].
+ * dz may alias dh or be NULL (bias gradient only); db may be NULL. width <= 256. */
+int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
+                     int32_t ld_dz, float* db, void* stream);
+/* nn.LayerNorm(256, eps 1e-5) backward from the saved pre-norm rows y: dy; dgamma += , dbeta += (may be NULL). */
+int gw_layernorm_backward(int64_t rows, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y, const float* gamma,
+                          float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream);
+/* Dual of the segment sum (graph_net_block.py:188): out[b, k, :] = table[b, idx[k], :] (+ add[b, k, :]); 256-float rows;
+ * idx NULL = identity; rows_per_batch 0 = table shared by the batch. */
+int gw_gather_rows(int32_t batch, int32_t n_idx, const float* table, int32_t rows_per_batch, const int32_t* idx,
+                   const float* add, float* out, void* stream);
+/* Dual of the x[row] / x[col] gathers (MetaLayer, graph_net_block.py:221-228):
+ * out[bo, n, :] (+)= sum_{b} sum_{i in [ptr[n], ptr[n+1])} rows[b, perm[i], :]; perm NULL = identity;
+ * batch_out == batch: per sample; batch_out == 1: summed over the batch too (gradient of a batch-shared table). */
+int gw_segment_sum_rows(int32_t batch, int32_t batch_out, int32_t n_seg, const float* rows, int32_t rows_per_batch_in,
+                        const int32_t* perm, const int32_t* ptr, float* out, int32_t accumulate, void* stream);
+/* NormalizedMSELoss backward (losses.py:66-94): dpred = dloss * d loss / d pred. */
+int gw_normalized_mse_backward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,
+                               int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, const float* dloss,
+                               float* dpred, void* stream);
+/* torch.optim.AdamW step (decoupled weight decay, bias correction with `step` >= 1) on a flat fp32 buffer. */
+int gw_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 #ifdef __cplusplus
 }
