@@ -18,5 +18,6 @@ from .layers import (  # noqa: F401
     set_compute_dtype,
 )
 from .losses import NormalizedMSELoss  # noqa: F401
+from .optim import AdamW  # noqa: F401
 
 __version__ = "0.1.0"

@@ -40,6 +40,10 @@ class GwMlpWeights(Structure):
                 ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32)]
 
 
+class GwActivationSave(Structure):
+    _fields_ = [("hidden", c_void_p), ("hidden_stride", c_int64), ("hidden_ld", c_int32), ("pre_norm", c_void_p)]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libgw_amd.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
@@ -85,14 +89,14 @@ def lib():
     L.gw_pad_vector.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
     L.gw_mlp_forward.restype = c_int
     L.gw_mlp_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwMlpWeights), POINTER(GwOperand),
-                                 c_void_p, c_int32, c_void_p]
+                                 c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]
     L.gw_edge_update_forward.restype = c_int
     L.gw_edge_update_forward.argtypes = [c_int32, c_int32, c_void_p, c_void_p, POINTER(GwOperand), POINTER(GwOperand),
                                          POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_void_p,
-                                         c_int32, c_void_p]
+                                         c_int32, POINTER(GwActivationSave), c_void_p]
     L.gw_node_update_forward.restype = c_int
     L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
-                                         POINTER(GwMlpWeights), c_void_p, c_int32, c_void_p]
+                                         POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]
     L.gw_project_forward.restype = c_int
     L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
                                      c_int32, c_int32, c_void_p]

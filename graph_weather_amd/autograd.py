@@ -1,0 +1,353 @@
+"""Backward pass of the hot path: ``torch.autograd.Function`` wrappers around the C ABI.
+
+The reference trains through autograd over ATen / torch_scatter ops (``train/run.py:509-521``: ``loss.backward();
+optimizer.step()``).  Here each fused forward op (``gw_mlp_forward``, ``gw_project_forward``, ``gw_edge_update_forward``,
+``gw_node_update_forward``, ``gw_normalized_mse_forward``) is one autograd node whose backward is composed from the
+generic HIP kernels of ``csrc/gw_train.hip`` (fp32-MFMA GEMMs, LayerNorm / ReLU backward, gather and segment-sum duals).
+PyTorch only links the nodes and sums gradients of tensors that are used more than once; no torch arithmetic op touches
+an activation.  Forward calls made under autograd also write the activations the reference's autograd would have saved
+(relu outputs, pre-LayerNorm rows) - SURVEY.md appendix G.
+
+First version: correctness before speed (activations are materialised, nothing is recomputed or fused).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from .ops import Operand, SavedActivations
+
+
+def _st(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _L():
+    return _lib.lib()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# thin wrappers over the generic kernels
+# ---------------------------------------------------------------------------------------------------------------------
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, n: int, b_col0: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, :n] = a[m, :k] @ b[:k, b_col0:b_col0+n]   (k = a.shape[1])."""
+    m, k = int(a.shape[0]), int(a.shape[1])
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _lib.check(_L().gw_gemm_f32(_lib.GEMM_NN, m, n, k, a.data_ptr(), int(a.stride(0)), b.data_ptr() + 4 * b_col0,
+                                int(b.stride(0)), out.data_ptr(), int(out.stride(0)), _st(a)), "gw_gemm_f32 NN")
+    return out
+
+
+def gemm_tn_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, c_col0: int = 0) -> None:
+    """c[:ma, c_col0:c_col0+nb] += a^T @ b   (a [rows, ma], b [rows, nb])."""
+    rows, ma, nb = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
+    _lib.check(_L().gw_gemm_f32(_lib.GEMM_TN, ma, nb, rows, a.data_ptr(), int(a.stride(0)), b.data_ptr(), int(b.stride(0)),
+                                c.data_ptr() + 4 * c_col0, int(c.stride(0)), _st(a)), "gw_gemm_f32 TN")
+
+
+def relu_backward(dh: torch.Tensor, h: Optional[torch.Tensor], db: Optional[torch.Tensor]) -> torch.Tensor:
+    """in place: dh *= (h > 0); db += column sums."""
+    rows, width = int(dh.shape[0]), int(dh.shape[1])
+    _lib.check(_L().gw_relu_backward(rows, width, dh.data_ptr(), int(dh.stride(0)), None if h is None else h.data_ptr(),
+                                     0 if h is None else int(h.stride(0)), dh.data_ptr() if h is not None else None,
+                                     int(dh.stride(0)), None if db is None else db.data_ptr(), _st(dh)), "gw_relu_backward")
+    return dh
+
+
+def layernorm_backward(dn: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor) -> torch.Tensor:
+    dy = torch.empty_like(y)
+    _lib.check(_L().gw_layernorm_backward(int(y.shape[0]), dn.data_ptr(), int(dn.stride(0)), y.data_ptr(), int(y.stride(0)),
+                                          gamma.data_ptr(), dy.data_ptr(), int(dy.stride(0)), dgamma.data_ptr(), dbeta.data_ptr(),
+                                          _st(y)), "gw_layernorm_backward")
+    return dy
+
+
+def gather_rows(table: torch.Tensor, rows_pb: int, idx: Optional[torch.Tensor], batch: int, n_idx: int,
+                add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty((batch * n_idx, 256), dtype=torch.float32, device=table.device)
+    _lib.check(_L().gw_gather_rows(batch, n_idx, table.data_ptr(), rows_pb, None if idx is None else idx.data_ptr(),
+                                   None if add is None else add.data_ptr(), out.data_ptr(), _st(table)), "gw_gather_rows")
+    return out
+
+
+def segment_sum_rows(rows: torch.Tensor, rows_pb_in: int, batch: int, batch_out: int, n_seg: int, ptr: torch.Tensor,
+                     perm: Optional[torch.Tensor]) -> torch.Tensor:
+    out = torch.empty((batch_out * n_seg, 256), dtype=torch.float32, device=rows.device)
+    _lib.check(_L().gw_segment_sum_rows(batch, batch_out, n_seg, rows.data_ptr(), rows_pb_in, None if perm is None else perm.data_ptr(),
+                                        ptr.data_ptr(), out.data_ptr(), 0, _st(rows)), "gw_segment_sum_rows")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward of the Linear/ReLU chain shared by all fused ops
+# ---------------------------------------------------------------------------------------------------------------------
+def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
+                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]]):
+    """Backward through [LayerNorm] <- Linear_L <- ReLU <- ... <- Linear_1 <- ReLU, down to the output of Linear_0.
+
+    ``weights`` = [W0, b0, W1, b1, ..., WL, bL, (gamma, beta)] (state_dict order of the reference ``MLP.model``);
+    ``grads`` has the same length and is filled in place for W1..WL, every bias and gamma / beta.  W0's gradient
+    depends on how the caller feeds layer 0 (concatenated operands, gathers, pre-multiplied tables) and is left to it.
+    Returns (dz0 [rows, hidden] = gradient at the output of Linear_0, already masked by its ReLU, device)."""
+    n_lin = (len(weights) - (2 if has_norm else 0)) // 2
+    if n_lin < 2:
+        raise RuntimeError("MLP needs at least one hidden layer")
+    if has_norm:
+        grads[-2] = torch.zeros_like(weights[-2])
+        grads[-1] = torch.zeros_like(weights[-1])
+        d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1])
+    else:
+        d = dout.contiguous()
+    # bias gradient of the last Linear = column sums of d
+    grads[2 * (n_lin - 1) + 1] = torch.zeros_like(weights[2 * (n_lin - 1) + 1])
+    relu_backward(d, None, grads[2 * (n_lin - 1) + 1])
+    for l in range(n_lin - 1, 0, -1):
+        W = weights[2 * l]
+        h_prev = saved.hidden[l - 1]  # relu output feeding Linear_l, [rows, in_l]
+        gW = torch.zeros_like(W)
+        gemm_tn_acc(d, h_prev, gW)  # dW_l = d^T h_prev
+        grads[2 * l] = gW
+        dh = gemm_nn(d, W, int(W.shape[1]))  # [rows, in_l]
+        # through the ReLU that produced h_prev; the column sums of the result are Linear_{l-1}'s bias gradient
+        grads[2 * (l - 1) + 1] = torch.zeros_like(weights[2 * (l - 1) + 1])
+        relu_backward(dh, h_prev, grads[2 * (l - 1) + 1])
+        d = dh
+    return d, d.device
+
+
+class MLPRowsFunction(torch.autograd.Function):
+    """``MLP.forward`` on rows (graph_net_block.py:63-77) [+ a constant residual]."""
+
+    @staticmethod
+    def forward(ctx, mlp, x2, residual_op, n_rows, rows_per_batch, *params):
+        pm = mlp.packed()
+        save = SavedActivations(pm, n_rows, x2.device)
+        y = ops.mlp_forward(pm, Operand(x2, rows_per_batch, mlp.in_dim), n_rows, rows_per_batch, residual=residual_op, save=save)
+        ctx.mlp, ctx.save, ctx.has_norm = mlp, save, pm.gamma is not None
+        ctx.save_for_backward(x2, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, *params = ctx.saved_tensors
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads)
+        W0 = params[0]
+        gW0 = torch.zeros_like(W0)
+        gemm_tn_acc(dz0, x2, gW0)
+        grads[0] = gW0
+        dx = gemm_nn(dz0, W0, int(W0.shape[1])) if ctx.needs_input_grad[1] else None
+        return (None, dx, None, None, None, *grads)
+
+
+def mlp_rows(mlp, x2: torch.Tensor, n_rows: int, rows_per_batch: int, residual_op: Optional[Operand] = None) -> torch.Tensor:
+    params = list(mlp.model.parameters())
+    return MLPRowsFunction.apply(mlp, x2, residual_op, n_rows, rows_per_batch, *params)
+
+
+class ProjectFunction(torch.autograd.Function):
+    """out_s = x @ W[:, lo_s:hi_s]^T for slices of a layer-1 weight (the layer-1 split of graph_net_block.py:131-134)."""
+
+    @staticmethod
+    def forward(ctx, mlp, slice_ids, x, n_rows, rows_per_batch, W):
+        pm = mlp.packed()
+        outs = ops.project_forward([pm.w1[s] for s in slice_ids], Operand(x, rows_per_batch, 256), n_rows, rows_per_batch)
+        ctx.mlp, ctx.slice_ids = mlp, slice_ids
+        ctx.save_for_backward(x, W)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, W = ctx.saved_tensors
+        gW = torch.zeros_like(W)
+        dx = None
+        for s, d in zip(ctx.slice_ids, douts):
+            if d is None:
+                continue
+            lo, hi = ctx.mlp._splits[s]
+            d = d.contiguous()
+            gemm_tn_acc(d, x, gW, c_col0=lo)  # dW[:, lo:hi] += d^T x
+            if ctx.needs_input_grad[2]:
+                part = gemm_nn(d, W, hi - lo, b_col0=lo)
+                dx = part if dx is None else dx.add_(part)
+        return None, None, dx, None, None, gW
+
+
+def project(mlp, slice_ids: Sequence[int], x: torch.Tensor, n_rows: int, rows_per_batch: int) -> Tuple[torch.Tensor, ...]:
+    return ProjectFunction.apply(mlp, tuple(slice_ids), x, n_rows, rows_per_batch, mlp.model[0].weight)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# message-passing ops
+# ---------------------------------------------------------------------------------------------------------------------
+class OperandSpec:
+    """How an operand of a fused op is fed: mode in {"zero", "raw", "proj"}; rows_pb 0 = table shared by the batch."""
+
+    def __init__(self, mode: str, rows_pb: int = 0):
+        self.mode, self.rows_pb = mode, rows_pb
+
+
+def _scatter_rows(rows: torch.Tensor, kind: int, plan, batch: int, table_rows_pb: int, n_table_rows: int) -> torch.Tensor:
+    """Gradient of a row table that was read through the plan's index of ``kind`` (0: src, 1: dst, 2: edge id):
+    sums the per-edge rows [batch * E, 256] into [batch or 1, table rows, 256]."""
+    E = plan.num_edges
+    batch_out = batch if table_rows_pb > 0 else 1
+    if kind == 1:
+        return segment_sum_rows(rows, E, batch, batch_out, n_table_rows, plan.dst_ptr(), None)
+    if kind == 0:
+        perm, ptr = plan.src_sorted()
+        return segment_sum_rows(rows, E, batch, batch_out, n_table_rows, ptr, perm)
+    if batch_out == batch:
+        return rows
+    return segment_sum_rows(rows, E, batch, 1, E, plan.identity_ptr(), None)
+
+
+class EdgeUpdateFunction(torch.autograd.Function):
+    """``EdgeProcessor.forward`` + ``scatter_sum`` (graph_net_block.py:131-137, :188) on a destination-sorted shared graph."""
+
+    @staticmethod
+    def forward(ctx, mlp, plan, batch, specs, want_edges, x_src, x_dst, e_in, e_res, e_res_rows_pb, *params):
+        pm = mlp.packed()
+        E, n_dst = plan.num_edges, plan.n_dst
+        dev = e_res.device
+        tensors = (x_src, x_dst, e_in)
+        opnds = []
+        for t, sp in zip(tensors, specs):
+            opnds.append(ops.ZERO if sp.mode == "zero" else Operand(t, sp.rows_pb, 256, projected=(sp.mode == "proj")))
+        agg = torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=dev)
+        e_out = torch.empty((batch * E, 256), dtype=torch.float32, device=dev) if want_edges else None
+        save = SavedActivations(pm, batch * E, dev)
+        ops.edge_update_forward(pm, batch, plan.src, plan.dst, opnds[0], opnds[1], opnds[2], Operand(e_res, e_res_rows_pb, 256),
+                                n_dst, agg, e_out, save=save)
+        ctx.mlp, ctx.plan, ctx.batch, ctx.specs, ctx.save, ctx.e_res_rows_pb = mlp, plan, batch, specs, save, e_res_rows_pb
+        ctx.want_edges = want_edges
+        ctx.save_for_backward(x_src, x_dst, e_in, *params)
+        if want_edges:
+            return agg, e_out
+        return agg, torch.empty(0, device=dev)
+
+    @staticmethod
+    def backward(ctx, dagg, de_out):
+        x_src, x_dst, e_in, *params = ctx.saved_tensors
+        plan, B, specs, mlp = ctx.plan, ctx.batch, ctx.specs, ctx.mlp
+        E = plan.num_edges
+        # gradient at e' = LN(..) + e_res: from the aggregate (gather by destination) and, if exposed, from e_out
+        add = de_out.contiguous() if (ctx.want_edges and de_out is not None and de_out.numel()) else None
+        dn = gather_rows(dagg.contiguous(), plan.n_dst, plan.dst, B, E, add)
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, True, params[-2], grads)
+        W0 = params[0]
+        gW0 = torch.zeros_like(W0)
+        tensors = (x_src, x_dst, e_in)
+        n_rows_tab = (plan.n_src, plan.n_dst, E)
+        dts: List[Optional[torch.Tensor]] = [None, None, None]
+        for i, (t, sp) in enumerate(zip(tensors, specs)):
+            if sp.mode == "zero":
+                continue
+            lo, hi = mlp._splits[i]
+            if sp.mode == "proj":
+                if ctx.needs_input_grad[5 + i]:
+                    dts[i] = _scatter_rows(dz0, i, plan, B, sp.rows_pb, n_rows_tab[i])
+            else:  # raw rows multiplied by W0[:, lo:hi]
+                idx = (plan.src, plan.dst, None)[i]
+                g = t if (idx is None and sp.rows_pb > 0) else gather_rows(t, sp.rows_pb, idx, B, E)
+                gemm_tn_acc(dz0, g, gW0, c_col0=lo)
+                if ctx.needs_input_grad[5 + i]:
+                    dg = gemm_nn(dz0, W0, hi - lo, b_col0=lo)
+                    dts[i] = _scatter_rows(dg, i, plan, B, sp.rows_pb, n_rows_tab[i])
+        grads[0] = gW0
+        de_res = None
+        if ctx.needs_input_grad[8]:
+            de_res = dn if ctx.e_res_rows_pb > 0 else segment_sum_rows(dn, E, B, 1, E, plan.identity_ptr(), None)
+        return (None, None, None, None, None, dts[0], dts[1], dts[2], de_res, None, *grads)
+
+
+def edge_update(mlp, plan, batch: int, specs, want_edges: bool, x_src, x_dst, e_in, e_res, e_res_rows_pb: int):
+    params = list(mlp.model.parameters())
+    dummy = e_res.new_zeros(0)
+    ts = [t if t is not None else dummy for t in (x_src, x_dst, e_in)]
+    agg, e_out = EdgeUpdateFunction.apply(mlp, plan, batch, tuple(specs), want_edges, ts[0], ts[1], ts[2], e_res, e_res_rows_pb, *params)
+    return agg, (e_out if want_edges else None)
+
+
+class NodeUpdateFunction(torch.autograd.Function):
+    """``NodeProcessor.forward`` after the aggregation (graph_net_block.py:189-191)."""
+
+    @staticmethod
+    def forward(ctx, mlp, n_rows, rows_per_batch, x_spec, res_rows_pb, x, x_res, agg, *params):
+        pm = mlp.packed()
+        xo = ops.ZERO if x_spec.mode == "zero" else Operand(x, x_spec.rows_pb, 256, projected=(x_spec.mode == "proj"))
+        ro = ops.ZERO if x_res.numel() == 0 else Operand(x_res, res_rows_pb, 256)
+        save = SavedActivations(pm, n_rows, agg.device)
+        out = ops.node_update_forward(pm, n_rows, rows_per_batch, xo, ro, Operand(agg, rows_per_batch, 256), save=save)
+        ctx.mlp, ctx.n_rows, ctx.rows_per_batch, ctx.x_spec, ctx.res_rows_pb, ctx.save = mlp, n_rows, rows_per_batch, x_spec, res_rows_pb, save
+        ctx.has_res = x_res.numel() != 0
+        ctx.save_for_backward(x, agg, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, agg, *params = ctx.saved_tensors
+        mlp, n, rpb = ctx.mlp, ctx.n_rows, ctx.rows_per_batch
+        batch = n // rpb
+        dout = dout.contiguous()
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, True, params[-2], grads)
+        W0 = params[0]
+        gW0 = torch.zeros_like(W0)
+        (xlo, xhi), (alo, ahi) = mlp._splits
+        gemm_tn_acc(dz0, agg, gW0, c_col0=alo)
+        dagg = gemm_nn(dz0, W0, ahi - alo, b_col0=alo) if ctx.needs_input_grad[7] else None
+        dx = None
+        sp = ctx.x_spec
+
+        def over_batch(rows):  # gradient of a table shared by the batch: sum the per-sample rows
+            ident = torch.arange(rpb + 1, dtype=torch.int32, device=rows.device)
+            return segment_sum_rows(rows, rpb, batch, 1, rpb, ident, None)
+
+        if sp.mode == "raw":
+            xg = x if sp.rows_pb > 0 else gather_rows(x, 0, None, batch, rpb)
+            gemm_tn_acc(dz0, xg, gW0, c_col0=xlo)
+            if ctx.needs_input_grad[5]:
+                dx = gemm_nn(dz0, W0, xhi - xlo, b_col0=xlo)
+                if sp.rows_pb == 0:
+                    dx = over_batch(dx)
+        elif sp.mode == "proj" and ctx.needs_input_grad[5]:
+            dx = dz0 if sp.rows_pb > 0 else over_batch(dz0)
+        grads[0] = gW0
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[6]:
+            dres = dout if ctx.res_rows_pb > 0 else over_batch(dout)
+        return (None, None, None, None, None, dx, dres, dagg, *grads)
+
+
+def node_update(mlp, n_rows: int, rows_per_batch: int, x_spec: OperandSpec, x, x_res, res_rows_pb: int, agg):
+    params = list(mlp.model.parameters())
+    dummy = agg.new_zeros(0)
+    return NodeUpdateFunction.apply(mlp, n_rows, rows_per_batch, x_spec, res_rows_pb, x if x is not None else dummy,
+                                    x_res if x_res is not None else dummy, agg, *params)
+
+
+class NormalizedMSEFunction(torch.autograd.Function):
+    """``NormalizedMSELoss.forward`` (losses.py:66-94)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, lat_weights, inv_var):
+        ctx.save_for_backward(pred, target, lat_weights, inv_var if inv_var is not None else pred.new_zeros(0))
+        ctx.has_var = inv_var is not None
+        return ops.normalized_mse_forward(pred, target, lat_weights, inv_var)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pred, target, w, iv = ctx.saved_tensors
+        b, c = int(pred.shape[0]), int(pred.shape[-1])
+        nodes = pred.numel() // (b * c)
+        dpred = torch.empty_like(pred)
+        dl = dloss.reshape(1).contiguous().float()
+        _lib.check(_L().gw_normalized_mse_backward(pred.data_ptr(), target.data_ptr(), iv.data_ptr() if ctx.has_var else None,
+                                                   w.data_ptr(), int(w.numel()), b, nodes, c, dl.data_ptr(), dpred.data_ptr(),
+                                                   _st(pred)), "gw_normalized_mse_backward")
+        return dpred, None, None, None

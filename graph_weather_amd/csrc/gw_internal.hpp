@@ -50,6 +50,11 @@ struct ChainArgs {
   float* agg;
   const int* agg_idx;
   int agg_rows_pb;
+  // training: activations saved for the backward (gw_activation_save), NULL in inference
+  float* save_h;
+  long long save_stride;
+  int save_ld;
+  float* save_y;
 };
 
 // bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices).

@@ -118,7 +118,8 @@ __device__ __forceinline__ void mma_pass_produce(f32x4 (&acc)[NT], const f32x4 (
                                                  const float* __restrict__ prow0, const float* __restrict__ prow1,
                                                  const float* __restrict__ prow2, bool p0, bool p1, bool p2,
                                                  const float* __restrict__ gw, const float* __restrict__ next_gw,
-                                                 int next_floats, float* lds, int& parity, int lane, int wave, int q) {
+                                                 int next_floats, float* lds, int& parity, int lane, int wave, int q,
+                                                 float* __restrict__ save_row) {
   constexpr int NT4 = (NT + 3) / 4;
   constexpr int STEPF = NT4 * 256;
   constexpr int NCH = HTI / 2;  // 8 K-steps (two 16-feature tiles) per chunk
@@ -142,6 +143,10 @@ __device__ __forceinline__ void mma_pass_produce(f32x4 (&acc)[NT], const f32x4 (
     for (int r = 0; r < 4; ++r) {
       in8[r] = fmaxf(v0[r], 0.f);
       in8[4 + r] = fmaxf(v1[r], 0.f);
+    }
+    if (save_row != nullptr) {  // training: relu output of layer 1 (features 32c + 4q.., 32c + 16 + 4q..)
+      stg4(save_row + 32 * c + 4 * q, f32x4{in8[0], in8[1], in8[2], in8[3]});
+      stg4(save_row + 32 * c + 16 + 4 * q, f32x4{in8[4], in8[5], in8[6], in8[7]});
     }
     if (c + 1 < NCH) {
       const int f0 = 16 * (2 * c + 2) + 4 * q;
@@ -336,14 +341,20 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
         const bool last = (a.n_mid == 1);
         const float* nx = last ? a.w_out : a.w_mid + (size_t)HS * HSTEPF;
         const int nf = last ? kChunkSteps * OSTEPF : kChunkSteps * HSTEPF;
+        float* srow = (a.save_h != nullptr && valid) ? a.save_h + (size_t)c * (size_t)a.save_ld : nullptr;
         mma_pass_produce<HT, HT>(acc2, acc, ptmp, prow[0], prow[1], prow[2], prj[0], prj[1], prj[2], a.w_mid, nx, nf, lds,
-                                 parity, lane, wave, q);
+                                 parity, lane, wave, q, srow);
       }
       // ---- further middle layers (hidden -> hidden) ----
       float hin[HS];
 #pragma unroll 1
       for (int l = 1; l < a.n_mid; ++l) {
         relu_to_in<HT>(hin, acc2);
+        if (a.save_h != nullptr && valid) {
+          float* srow = a.save_h + (size_t)l * (size_t)a.save_stride + (size_t)c * (size_t)a.save_ld;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) stg4(srow + 16 * t + 4 * q, f32x4{hin[4 * t], hin[4 * t + 1], hin[4 * t + 2], hin[4 * t + 3]});
+        }
         init_bias<HT>(acc2, a.b_mid + l * (HT * 16), q);
         const bool last = (l + 1 == a.n_mid);
         const float* nx = last ? a.w_out : a.w_mid + (size_t)(l + 1) * HS * HSTEPF;
@@ -353,6 +364,11 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
       GW_STAMP(3)
       // ---- output layer ----
       relu_to_in<HT>(hin, acc2);
+      if (a.save_h != nullptr && valid) {
+        float* srow = a.save_h + (size_t)a.n_mid * (size_t)a.save_stride + (size_t)c * (size_t)a.save_ld;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) stg4(srow + 16 * t + 4 * q, f32x4{hin[4 * t], hin[4 * t + 1], hin[4 * t + 2], hin[4 * t + 3]});
+      }
       init_bias<OT>(o, a.b_out, q);
       if (EPI != EPI_DEC && a.res_ptr != nullptr) {
         // fetch the residual rows underneath the last pass
@@ -367,6 +383,11 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   GW_STAMP(4)
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance) ----
   if (!SINGLE && a.gamma != nullptr) {
+    if (a.save_y != nullptr && valid) {
+      float* srow = a.save_y + (size_t)c * (size_t)(OT * 16);
+#pragma unroll
+      for (int t = 0; t < OT; ++t) stg4(srow + 16 * t + 4 * q, o[t]);
+    }
     constexpr float inv_n = 1.0f / (OT * 16);
     float s = 0.f;
 #pragma unroll
@@ -655,8 +676,24 @@ int gw_pad_vector(const float* v, int n, float* out, void* stream) {
   return check_launch("pad_vector_kernel launch");
 }
 
+namespace {
+int fill_save(ChainArgs& a, const gw_activation_save* save, const gw_mlp_weights* w, const char* who) {
+  if (!save) return GW_OK;
+  if (w->weight_dtype != GW_DTYPE_F32) return fail(GW_E_UNSUPPORTED, "activation saving (training) is implemented for fp32 weights only");
+  if (!save->hidden || save->hidden_ld < w->hidden || save->hidden_ld % 4 != 0 || (w->ln_gamma && !save->pre_norm)) {
+    snprintf(g_err, sizeof(g_err), "%s: bad gw_activation_save", who);
+    return GW_E_BADARG;
+  }
+  a.save_h = save->hidden;
+  a.save_stride = save->hidden_stride;
+  a.save_ld = save->hidden_ld;
+  a.save_y = save->pre_norm;
+  return GW_OK;
+}
+}  // namespace
+
 int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
-                   const gw_operand* residual, float* out, int32_t out_ld, void* stream) {
+                   const gw_operand* residual, float* out, int32_t out_ld, const gw_activation_save* save, void* stream) {
   if (!x || !w || !out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_mlp_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: more than 2^31-1 rows");
@@ -678,6 +715,7 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   a.out = out;
   a.out_ld = out_ld;
   a.out_cols = w->n_out;
+  if (int rc = fill_save(a, save, w, "gw_mlp_forward")) return rc;
   if (w->weight_dtype == GW_DTYPE_BF16) {
     if (residual && w->n_out == 256 && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
     if (w->n_out == 256 && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
@@ -702,7 +740,7 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst,
-                           void* stream) {
+                           const gw_activation_save* save, void* stream) {
   if (batch <= 0 || n_edges < 0 || n_dst <= 0) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if (n_edges == 0) return GW_OK;  // nothing to add: agg stays as the caller zeroed it
   if (!src || !dst || !x_src || !x_dst || !e_in || !e_res || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
@@ -718,7 +756,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
   if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
-  if (w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w))
+  if (!save && w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w))
     return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, stream);
   ChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -737,12 +775,14 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg = agg;
   a.agg_idx = dst;
   a.agg_rows_pb = n_dst;
+  if (int rc = fill_save(a, save, w, "gw_edge_update_forward")) return rc;
   if (w->weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(1, a, 256, 256, 256, 1, stream);
   return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream, 1, 1);
 }
 
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
-                           const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream) {
+                           const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
+                           const gw_activation_save* save, void* stream) {
   if (!x || !agg || !w || !x_out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: more than 2^31-1 rows");
@@ -764,6 +804,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.out = x_out;
   a.out_ld = out_ld;
   a.out_cols = 256;
+  if (int rc = fill_save(a, save, w, "gw_node_update_forward")) return rc;
   if (w->weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(2, a, 256, 256, 256, 1, stream);
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }

@@ -51,6 +51,28 @@ class GraphPlan:
     def num_edges(self) -> int:
         return int(self.src.shape[0])
 
+    # ---- index structures of the backward pass (built lazily, on the device of the plan) ----
+    def dst_ptr(self) -> torch.Tensor:
+        """CSR row pointer over the destination-sorted edges: edges [ptr[n], ptr[n+1]) end in destination row n."""
+        if getattr(self, "_dst_ptr", None) is None:
+            counts = torch.bincount(self.dst.long(), minlength=self.n_dst)
+            self._dst_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+        return self._dst_ptr
+
+    def src_sorted(self):
+        """(perm, ptr): sorted positions grouped by source row - the dual of the x[row] gather (MetaLayer)."""
+        if getattr(self, "_src_sorted", None) is None:
+            perm = torch.argsort(self.src.long(), stable=True)
+            counts = torch.bincount(self.src.long(), minlength=self.n_src)
+            ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+            self._src_sorted = (perm.to(torch.int32).contiguous(), ptr)
+        return self._src_sorted
+
+    def identity_ptr(self) -> torch.Tensor:
+        if getattr(self, "_ident_ptr", None) is None:
+            self._ident_ptr = torch.arange(self.num_edges + 1, dtype=torch.int32, device=self.src.device)
+        return self._ident_ptr
+
     def to(self, device) -> "GraphPlan":
         return GraphPlan(self.n_src, self.n_dst, self.src.to(device), self.dst.to(device), self.perm.to(device),
                          None if self.edge_attr is None else self.edge_attr.to(device))

@@ -19,7 +19,9 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
+from .autograd import OperandSpec
 from .graphs import ForecastGraphs, GraphPlan, build_forecast_graphs
 from .ops import Operand, PackedMLP
 
@@ -28,6 +30,31 @@ _NORMS = ["LayerNorm", "GraphNorm", "InstanceNorm", "BatchNorm", "MessageNorm"]
 
 def _version_key(params) -> tuple:
     return tuple((p.data_ptr(), p._version, p.device) for p in params)
+
+
+def _autograd_on(module: nn.Module) -> bool:
+    """True when the call must be differentiable: grad mode on and the module has trainable parameters."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+class Feed:
+    """One input of a fused op: a row table, how many of its rows belong to one batch element (0 = shared by the
+    batch) and how it enters layer 1: "raw" rows (matrix pass), "proj" rows already multiplied by their layer-1
+    weight slice (gather-add), or "zero" (slice skipped)."""
+
+    def __init__(self, tensor: Optional[torch.Tensor], rows_pb: int, mode: str):
+        self.tensor, self.rows_pb, self.mode = tensor, rows_pb, mode
+
+    def operand(self) -> Operand:
+        if self.mode == "zero":
+            return ops.ZERO
+        return Operand(self.tensor, self.rows_pb, 256, projected=(self.mode == "proj"))
+
+    def spec(self) -> OperandSpec:
+        return OperandSpec(self.mode, self.rows_pb)
+
+
+FEED_ZERO = Feed(None, 0, "zero")
 
 
 def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
@@ -100,7 +127,10 @@ class MLP(nn.Module):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         n = int(x2.shape[0])
-        y = ops.mlp_forward(self.packed(), Operand(x2, n, self.in_dim), n, n)
+        if _autograd_on(self) or (torch.is_grad_enabled() and x2.requires_grad):
+            y = ag.mlp_rows(self, x2, n, n)
+        else:
+            y = ops.mlp_forward(self.packed(), Operand(x2, n, self.in_dim), n, n)
         return y.reshape(*lead, self.out_dim)
 
 
@@ -132,17 +162,24 @@ class GraphNetBlock(nn.Module):
         self.edge_model = edge_model
         self.node_model = node_model
 
-    def run(self, batch: int, plan: GraphPlan, x_src: Operand, x_dst: Operand, e_in: Operand, e_res: Operand,
-            x_node: Operand, x_node_res: Operand, want_edges: bool, device,
+    def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
+            x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
             tag: Optional[str] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
-        Operands may be raw rows, rows pre-projected through their layer-1 weight slice, or zeros."""
+        Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``)."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
+        if _autograd_on(self):
+            agg, e_out = ag.edge_update(self.edge_model.edge_mlp, plan, batch, (x_src.spec(), x_dst.spec(), e_in.spec()),
+                                        want_edges, x_src.tensor, x_dst.tensor, e_in.tensor, e_res, e_res_rows_pb)
+            x_new = ag.node_update(self.node_model.node_mlp, batch * n_dst, n_dst, x_node.spec(), x_node.tensor, x_res,
+                                   x_res_rows_pb, agg)
+            return x_new, e_out
         agg = torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
         e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
-        ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src, x_dst, e_in, e_res,
-                                n_dst, agg, e_out, tag=tag)
-        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node, x_node_res,
+        ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
+                                e_in.operand(), Operand(e_res, e_res_rows_pb, 256), n_dst, agg, e_out, tag=tag)
+        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(),
+                                        ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256),
                                         Operand(agg, n_dst, 256))
         return x_new, e_out
 
@@ -190,22 +227,29 @@ class GraphProcessor(nn.Module):
         _check_native_dims(*self._dims)
         n, n_edges = plan.n_dst, plan.num_edges
         e_cur, shared = e, e_shared
+        train = _autograd_on(self)
         for i, blk in enumerate(self.blocks):
             last = i == len(self.blocks) - 1
-            pm_e = blk.edge_model.edge_mlp.packed()
-            xop = Operand(x, n, 256)
-            ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], xop, batch * n, n)
-            if shared:
-                key = (e_cur.data_ptr(), e_cur._version, blk.params_key())
-                if self._e0_cache is None or self._e0_cache[0] != key:
-                    pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
-                    self._e0_cache = (key, pe)
-                e_in = Operand(self._e0_cache[1], 0, 256, projected=True)
+            mlp_e = blk.edge_model.edge_mlp
+            if train:
+                ps, pd = ag.project(mlp_e, (0, 1), x, batch * n, n)
             else:
-                e_in = Operand(e_cur, n_edges, 256)
-            x, e_new = blk.run(batch, plan, Operand(ps, n, 256, projected=True), Operand(pd, n, 256, projected=True), e_in,
-                               Operand(e_cur, 0 if shared else n_edges, 256), xop, xop, want_edges or not last, x.device,
-                               tag="processor_edge")
+                pm_e = mlp_e.packed()
+                ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n)
+            if shared:
+                if train:
+                    pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
+                else:
+                    key = (e_cur.data_ptr(), e_cur._version, blk.params_key())
+                    if self._e0_cache is None or self._e0_cache[0] != key:
+                        pe = ops.project_forward([mlp_e.packed().w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
+                        self._e0_cache = (key, pe)
+                    pe = self._e0_cache[1]
+                e_in = Feed(pe, 0, "proj")
+            else:
+                e_in = Feed(e_cur, n_edges, "raw")
+            x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_cur, 0 if shared else n_edges,
+                               Feed(x, n, "raw"), x, n, want_edges or not last, x.device, tag="processor_edge")
             if e_new is not None:
                 e_cur, shared = e_new, False
         return x, (e_cur if want_edges else None)
@@ -272,6 +316,8 @@ class Encoder(nn.Module):
         return self._dev_plans[key]
 
     def _cached(self, name: str, params, fn):
+        if _autograd_on(self):  # training: batch-independent embeddings are part of the graph, recomputed every step
+            return fn()
         key = _version_key(params)
         hit = self._cache.get(name)
         if hit is None or hit[0] != key:
@@ -281,7 +327,7 @@ class Encoder(nn.Module):
     def mesh_embedding(self) -> torch.Tensor:
         """node_encoder(h3_nodes): batch independent (encoder.py:199-205 recomputes it for every sample)."""
         ps = list(self.node_encoder.parameters()) + [self.h3_nodes]
-        return self._cached("mesh", ps, lambda: self.node_encoder(self.h3_nodes.detach()))
+        return self._cached("mesh", ps, lambda: self.node_encoder(self.h3_nodes if _autograd_on(self) else self.h3_nodes.detach()))
 
     def encoder_edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
         return self._cached("enc_e", list(self.edge_encoder.parameters()), lambda: self.edge_encoder(plan.edge_attr))
@@ -298,16 +344,18 @@ class Encoder(nn.Module):
         B, G, F = (int(s) for s in features.shape)
         feats = features.contiguous().reshape(B * G, F)
         enc_plan, _ = self._plans(features.device)
-        pm = self.node_encoder.packed()
-        xg = ops.mlp_forward(pm, Operand(feats, G, F), B * G, G)  # grid rows only
+        train = _autograd_on(self)
+        if train:
+            xg = ag.mlp_rows(self.node_encoder, feats, B * G, G)  # grid rows only
+        else:
+            xg = ops.mlp_forward(self.node_encoder.packed(), Operand(feats, G, F), B * G, G)
         xm = self.mesh_embedding()
         e = self.encoder_edge_embedding(enc_plan)
         blk = self.graph_processor.blocks[0]
         _check_native_dims(*self.graph_processor._dims)
         pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
-        x, _ = blk.run(B, enc_plan, Operand(xg, G, 256), Operand(pd_xm, 0, 256, projected=True),
-                       Operand(pe, 0, 256, projected=True), Operand(e, 0, 256), Operand(px_xm, 0, 256, projected=True),
-                       Operand(xm, 0, 256), False, features.device, tag="encoder_edge")
+        x, _ = blk.run(B, enc_plan, Feed(xg, G, "raw"), Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e, 0,
+                       Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge")
         return x
 
     def _static_projections(self, blk, xm: torch.Tensor, e: torch.Tensor):
@@ -316,9 +364,14 @@ class Encoder(nn.Module):
         ps = list(self.parameters())
 
         def make():
+            M, G = int(xm.shape[0]), int(e.shape[0])
+            if _autograd_on(self):
+                pd_xm = ag.project(blk.edge_model.edge_mlp, (1,), xm, M, M)[0]
+                pe = ag.project(blk.edge_model.edge_mlp, (2,), e, G, G)[0]
+                px_xm = ag.project(blk.node_model.node_mlp, (0,), xm, M, M)[0]
+                return pd_xm, pe, px_xm
             pm_e = blk.edge_model.edge_mlp.packed()
             pm_n = blk.node_model.node_mlp.packed()
-            M, G = int(xm.shape[0]), int(e.shape[0])
             pd_xm = ops.project_forward([pm_e.w1[1]], Operand(xm, M, 256), M, M)[0]
             pe = ops.project_forward([pm_e.w1[2]], Operand(e, G, 256), G, G)[0]
             px_xm = ops.project_forward([pm_n.w1[0]], Operand(xm, M, 256), M, M)[0]
@@ -414,6 +467,8 @@ class AssimilatorDecoder(nn.Module):
         return self._dev_plans[key]
 
     def edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
+        if _autograd_on(self):
+            return self.edge_encoder(plan.edge_attr)
         key = _version_key(list(self.edge_encoder.parameters()))
         hit = self._cache.get("dec_e")
         if hit is None or hit[0] != key:
@@ -434,20 +489,29 @@ class AssimilatorDecoder(nn.Module):
         # lat/lon rows are zeros (assimilator_decoder.py:84,190-192): x_dst = 0, node input [0 | agg], residual 0.
         # Layer 1 of the edge MLP is then relu(Ws.x[src] + (We.e + b)): a gather-add of a per-mesh-node product and a
         # cached batch-independent per-edge product - no matrix work per edge in layer 1.
-        pm_e = blk.edge_model.edge_mlp.packed()
-        ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M)[0]
-        key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
-        hit = self._cache.get("dec_pe")
-        if hit is None or hit[0] != key:
-            n_e = plan.num_edges
-            self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
-        pe = self._cache["dec_pe"][1]
-        xg, _ = blk.run(B, plan, Operand(ps, M, 256, projected=True), ops.ZERO, Operand(pe, 0, 256, projected=True),
-                        Operand(e, 0, 256), ops.ZERO, ops.ZERO, False, dev, tag="decoder_edge")
+        train = _autograd_on(self)
+        mlp_e = blk.edge_model.edge_mlp
+        n_e = plan.num_edges
+        if train:
+            ps = ag.project(mlp_e, (0,), processor_features.contiguous(), B * M, M)[0]
+            pe = ag.project(mlp_e, (2,), e, n_e, n_e)[0]
+        else:
+            pm_e = mlp_e.packed()
+            ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M)[0]
+            key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
+            hit = self._cache.get("dec_pe")
+            if hit is None or hit[0] != key:
+                self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
+            pe = self._cache["dec_pe"][1]
+        xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
+                        tag="decoder_edge")
         res = None
         if residual is not None:
             res = Operand(residual, G, self.output_dim)
-        y = ops.mlp_forward(self.node_decoder.packed(), Operand(xg, G, 256), B * G, G, residual=res)
+        if train:
+            y = ag.mlp_rows(self.node_decoder, xg, B * G, G, residual_op=res)
+        else:
+            y = ops.mlp_forward(self.node_decoder.packed(), Operand(xg, G, 256), B * G, G, residual=res)
         return y.reshape(B, G, self.output_dim)
 
     def forward(self, processor_features: torch.Tensor, batch_size: int) -> torch.Tensor:

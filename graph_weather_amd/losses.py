@@ -29,4 +29,8 @@ class NormalizedMSELoss(torch.nn.Module):
             if fv.numel() != pred.shape[-1]:
                 raise NotImplementedError("graph_weather_amd: feature_variance must be per-channel [C] on the HIP path")
             inv_var = (1.0 / fv.reshape(-1)).contiguous()
+        if torch.is_grad_enabled() and pred.requires_grad:
+            from .autograd import NormalizedMSEFunction
+
+            return NormalizedMSEFunction.apply(pred.contiguous(), target.contiguous(), self.weights.contiguous(), inv_var)
         return ops.normalized_mse_forward(pred.contiguous(), target.contiguous(), self.weights.contiguous(), inv_var)

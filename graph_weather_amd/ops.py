@@ -8,7 +8,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import GwMlpWeights, GwOperand
+from ._lib import GwActivationSave, GwMlpWeights, GwOperand
 
 
 class KernelTimer:
@@ -74,6 +74,19 @@ class Operand:
 
 
 ZERO = Operand(None, 0, 0)
+
+
+class SavedActivations:
+    """Buffers a forward call fills for its backward (include/gw_amd.h: gw_activation_save): the relu outputs of
+    every Linear but the last, and the pre-LayerNorm output."""
+
+    def __init__(self, pm: "PackedMLP", n_rows: int, device):
+        self.hidden = torch.empty((pm.n_mid + 1, n_rows, pm.hidden), dtype=torch.float32, device=device)
+        self.pre_norm = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=device) if pm.gamma is not None else None
+
+    def c(self) -> GwActivationSave:
+        return GwActivationSave(self.hidden.data_ptr(), int(self.hidden.stride(0)), int(self.hidden.stride(1)),
+                                None if self.pre_norm is None else self.pre_norm.data_ptr())
 
 
 class PackedMLP:
@@ -148,7 +161,7 @@ class PackedMLP:
 
 
 def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, residual: Optional[Operand] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, save: Optional[SavedActivations] = None) -> torch.Tensor:
     """graph_net_block.py:63-77 on ``n_rows`` rows (+ optional residual add)."""
     dev = x.tensor.device
     if out is None:
@@ -160,7 +173,7 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
     if rc is not None:
         rc.k = pm.n_out
     _lib.check(_lib.lib().gw_mlp_forward(n_rows, max(1, rows_per_batch), xc, wc, rc, out.data_ptr(), int(out.stride(0)),
-                                         _stream(out)), "gw_mlp_forward")
+                                         None if save is None else save.c(), _stream(out)), "gw_mlp_forward")
     return out
 
 
@@ -184,7 +197,7 @@ def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, r
 
 def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
                         e_in: Operand, e_res: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
-                        tag: Optional[str] = None) -> None:
+                        tag: Optional[str] = None, save: Optional[SavedActivations] = None) -> None:
     """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed."""
     _require(src, "src", torch.int32)
     _require(dst, "dst", torch.int32)
@@ -196,13 +209,14 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
     ev = TIMER.start(tag) if TIMER is not None else None
     _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), x_src.c(), x_dst.c(), e_in.c(),
                                                  e_res.c(), wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(),
-                                                 n_dst, _stream(agg)), "gw_edge_update_forward")
+                                                 n_dst, None if save is None else save.c(), _stream(agg)),
+               "gw_edge_update_forward")
     if ev is not None:
         TIMER.stop(tag, ev)
 
 
 def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, x_res: Operand, agg: Operand,
-                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        out: Optional[torch.Tensor] = None, save: Optional[SavedActivations] = None) -> torch.Tensor:
     """graph_net_block.py:189-191 (NodeProcessor after aggregation)."""
     dev = agg.tensor.device
     if out is None:
@@ -210,7 +224,8 @@ def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Oper
     _require(out, "out")
     wc = pm.c((x.k > 0 and not x.projected, True, False))
     _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), x_res.c(), agg.c(), wc, out.data_ptr(),
-                                                 int(out.stride(0)), _stream(out)), "gw_node_update_forward")
+                                                 int(out.stride(0)), None if save is None else save.c(), _stream(out)),
+               "gw_node_update_forward")
     return out
 
 

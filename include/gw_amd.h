@@ -88,13 +88,16 @@ typedef struct gw_mlp_weights {
   int32_t weight_dtype; /* GW_DTYPE_F32: streams from gw_pack_linear; GW_DTYPE_BF16: streams from gw_pack_linear_bf16 */
 } gw_mlp_weights;
 
+struct gw_activation_save; /* training only, defined with the backward entry points below; NULL in inference */
+
 /* ---- MLP.forward (graph_net_block.py:63-77) applied to rows --------------------------------------------
  * y[c, :] = MLP(x[c, :k]) (+ residual[c, :n_out]);   c in [0, n_rows).
  * Used for Encoder.node_encoder (encoder.py:205), the three edge encoders (encoder.py:206-208,235-241,
  * assimilator_decoder.py:175-177) and AssimilatorDecoder.node_decoder + the Decoder residual
  * (assimilator_decoder.py:197, decoder.py:93).  Supported k: <= 16, <= 112, or exactly 256. */
 int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
-                   const gw_operand* residual /* may be NULL */, float* out, int32_t out_ld, void* stream);
+                   const gw_operand* residual /* may be NULL */, float* out, int32_t out_ld,
+                   const struct gw_activation_save* save /* may be NULL */, void* stream);
 
 /* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
  * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7
@@ -115,14 +118,15 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w,
                            float* e_out /* [batch*n_edges,256] or NULL */, float* agg /* [batch*n_dst,256] */,
-                           int32_t n_dst, void* stream);
+                           int32_t n_dst, const struct gw_activation_save* save /* may be NULL */, void* stream);
 
 /* ---- NodeProcessor.forward after aggregation (graph_net_block.py:189-191) -------------------------------
  *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x_res[b, j]
  * x may be raw, pre-projected or zeros (k == 0: the decoder's lat/lon rows are zeros, assimilator_decoder.py:84,
  * 190 - the x-slice of layer 1 is skipped); x_res = raw node rows for the residual (NULL or k == 0: none). */
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
-                           const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld, void* stream);
+                           const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
+                           const struct gw_activation_save* save /* may be NULL */, void* stream);
 
 /* ---- NormalizedMSELoss.forward (losses.py:66-94, normalize on/off) ---------------------------------------
  * loss = mean_{b,n}( w_lat[n / num_lon] * mean_c( (pred-target)^2 [/ var_c] ) ); *loss_out must be zeroed. */

@@ -37,7 +37,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.gw_pack_linear(None, 256, 256, 0, 256, None, None) == -1
     assert b"bad arguments" in L.gw_last_error()
-    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, None, 1, None) == -1
+    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, None, 1, None, None) == -1
     assert L.gw_project_forward(10, 10, None, 1, None, None, 256, 0, None) == -1
     assert L.gw_pack_linear_bf16(None, 256, 256, 0, 256, None, None) == -1
     assert L.gw_packed_bytes_bf16(256, 0, 256) == 8 * 16 * 1024  # 8 K-steps x 16 row tiles x 1 KiB
