@@ -34,7 +34,13 @@ def _version_key(params) -> tuple:
 
 def _autograd_on(module: nn.Module) -> bool:
     """True when the call must be differentiable: grad mode on and the module has trainable parameters."""
-    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+    on = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+    if on:
+        for m in module.modules():
+            if isinstance(m, MLP) and m.compute_dtype != torch.float32:
+                raise NotImplementedError("graph_weather_amd: the backward pass is implemented for float32 matrix products; "
+                                          "call the bfloat16 mode under torch.no_grad() (inference)")
+    return on
 
 
 class Feed:

@@ -286,7 +286,8 @@ def test_bf16_mlp_vs_oracle(i, o, h, norm, rows):
     x = torch.from_numpy(np.random.RandomState(rows).standard_normal((rows, i)).astype(np.float32))
     ref = om.mlp({"m." + k: v for k, v in m.state_dict().items()}, "m", x)
     gw.set_compute_dtype(m, torch.bfloat16)
-    y = m.to(DEV)(x.to(DEV))
+    with torch.no_grad():  # bf16 is an inference mode: the training path (activation saving) is fp32 only
+        y = m.to(DEV)(x.to(DEV))
     rel = _close(y, ref, rel=BF16_REL, what=f"bf16 mlp {i}->{o}")
     assert rel > 1e-5, "bf16 path suspiciously exact: is it really running bf16?"
 
@@ -306,7 +307,8 @@ def test_bf16_graph_processor_edge_cases_vs_oracle():
         ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
         ea = torch.from_numpy(rs.standard_normal((e, 256)).astype(np.float32))
         xr, er = om.graph_processor(p, "gp", x, ei, ea)
-        xo, eo = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
+        with torch.no_grad():
+            xo, eo = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
         _close(xo, xr, rel=BF16_REL, what=f"bf16 E={e} x")
         if e:
             _close(eo, er, rel=BF16_REL, what=f"bf16 E={e} e")
