@@ -114,6 +114,41 @@ def whole_job_rate(ctx: ShardContext, units_this_rank: float, elapsed_max: float
     return sum_over_ranks(ctx, units_this_rank, device) / elapsed_max
 
 
+def allreduce_gradients(ctx: ShardContext, params, bucket_bytes: int = 64 << 20) -> int:
+    """Data-parallel gradient step: average the gradients of ``params`` over the ranks with one all-reduce
+    per flat bucket (RCCL over xGMI on GPUs, gloo in the CPU tests).  The whole model is 7.7 M fp32 gradients = 30.9 MB,
+    i.e. a single bucket: xGMI rings are per-link bound, so fewer, larger collectives are the right shape.
+    Returns the number of collectives issued (0 for world == 1)."""
+    if ctx.world == 1:
+        return 0
+    import torch.distributed as dist
+
+    grads = [p.grad for p in params if p.grad is not None]
+    n_coll, bucket, size = 0, [], 0
+
+    def flush():
+        nonlocal n_coll, bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(ctx.world)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        n_coll += 1
+        bucket, size = [], 0
+
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+    return n_coll
+
+
 def shutdown(ctx: ShardContext) -> None:
     if ctx.world > 1:
         import torch.distributed as dist

@@ -69,6 +69,15 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
     dist.all_gather_object(parts, (lo, hi, (feats[lo:hi] * 2.0).tolist()))
     whole = torch.cat([torch.tensor(p[2]).reshape(-1, 3) for p in sorted(parts)])
     assert torch.equal(whole, feats * 2.0)
+    # data-parallel gradient step: every rank ends with the mean gradient, bucketed into flat collectives
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(5, 3), (7,), (2, 2, 2), (1,)]]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    n = sh.allreduce_gradients(ctx, params, bucket_bytes=64)  # small buckets: several collectives
+    assert n >= 2
+    for i, p in enumerate(params):
+        assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * (world + 1) / 2.0))
     sh.shutdown(ctx)
     with open(os.path.join(out_dir, f"ok{rank}"), "w") as fh:
         fh.write("ok")
