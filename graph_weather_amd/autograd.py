@@ -81,11 +81,39 @@ def segment_sum_rows(rows: torch.Tensor, rows_pb_in: int, batch: int, batch_out:
     return out
 
 
+def _packed_transposed(mlp, layer: int, lo: int, hi: int):
+    """Packed stream of W[:, lo:hi]^T of Linear ``layer`` (cached per weight version) for the fast input-gradient
+    product d @ W[:, lo:hi] through the forward's single-layer kernel; only for 256 x 256 blocks, else None."""
+    W = [m for m in mlp.model if isinstance(m, torch.nn.Linear)][layer].weight
+    if W.shape[0] != 256 or hi - lo != 256:
+        return None
+    cache = mlp.__dict__.setdefault("_packed_t", {})
+    key = (layer, lo, hi)
+    ver = (W.data_ptr(), W._version)
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        Wt = W.detach()[:, lo:hi].t().contiguous()  # [256 (k), 256 (f)]: "Linear" that maps gradients back
+        n = _L().gw_packed_floats(256, 0, 256)
+        out = torch.empty(n, dtype=torch.float32, device=W.device)
+        _lib.check(_L().gw_pack_linear(Wt.data_ptr(), 256, 256, 0, 256, out.data_ptr(), _st(W)), "gw_pack_linear (transposed)")
+        cache[key] = (ver, out)
+    return cache[key][1]
+
+
+def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    """d @ W[:, lo:hi]  ([rows, hi-lo]): fused single-layer kernel for 256 x 256 blocks, generic GEMM otherwise."""
+    pt = _packed_transposed(mlp, layer, lo, hi) if (d.shape[1] == 256 and d.stride(0) % 4 == 0) else None
+    if pt is None:
+        return gemm_nn(d, W, hi - lo, b_col0=lo)
+    rows = int(d.shape[0])
+    return ops.project_forward([pt], Operand(d, rows, 256), rows, rows, weight_dtype=_lib.DTYPE_F32)[0]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # backward of the Linear/ReLU chain shared by all fused ops
 # ---------------------------------------------------------------------------------------------------------------------
 def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
-                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]]):
+                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None):
     """Backward through [LayerNorm] <- Linear_L <- ReLU <- ... <- Linear_1 <- ReLU, down to the output of Linear_0.
 
     ``weights`` = [W0, b0, W1, b1, ..., WL, bL, (gamma, beta)] (state_dict order of the reference ``MLP.model``);
@@ -110,7 +138,7 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         gW = torch.zeros_like(W)
         gemm_tn_acc(d, h_prev, gW)  # dW_l = d^T h_prev
         grads[2 * l] = gW
-        dh = gemm_nn(d, W, int(W.shape[1]))  # [rows, in_l]
+        dh = input_grad(mlp, l, d, W, 0, int(W.shape[1])) if mlp is not None else gemm_nn(d, W, int(W.shape[1]))  # [rows, in_l]
         # through the ReLU that produced h_prev; the column sums of the result are Linear_{l-1}'s bias gradient
         grads[2 * (l - 1) + 1] = torch.zeros_like(weights[2 * (l - 1) + 1])
         relu_backward(dh, h_prev, grads[2 * (l - 1) + 1])
@@ -134,12 +162,12 @@ class MLPRowsFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x2, *params = ctx.saved_tensors
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads)
+        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         gemm_tn_acc(dz0, x2, gW0)
         grads[0] = gW0
-        dx = gemm_nn(dz0, W0, int(W0.shape[1])) if ctx.needs_input_grad[1] else None
+        dx = input_grad(ctx.mlp, 0, dz0, W0, 0, int(W0.shape[1])) if ctx.needs_input_grad[1] else None
         return (None, dx, None, None, None, *grads)
 
 
@@ -171,7 +199,7 @@ class ProjectFunction(torch.autograd.Function):
             d = d.contiguous()
             gemm_tn_acc(d, x, gW, c_col0=lo)  # dW[:, lo:hi] += d^T x
             if ctx.needs_input_grad[2]:
-                part = gemm_nn(d, W, hi - lo, b_col0=lo)
+                part = input_grad(ctx.mlp, 0, d, W, lo, hi)
                 dx = part if dx is None else dx.add_(part)
         return None, None, dx, None, None, gW
 
@@ -238,7 +266,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
         add = de_out.contiguous() if (ctx.want_edges and de_out is not None and de_out.numel()) else None
         dn = gather_rows(dagg.contiguous(), plan.n_dst, plan.dst, B, E, add)
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, True, params[-2], grads)
+        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, True, params[-2], grads, mlp)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         tensors = (x_src, x_dst, e_in)
@@ -256,7 +284,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
                 g = t if (idx is None and sp.rows_pb > 0) else gather_rows(t, sp.rows_pb, idx, B, E)
                 gemm_tn_acc(dz0, g, gW0, c_col0=lo)
                 if ctx.needs_input_grad[5 + i]:
-                    dg = gemm_nn(dz0, W0, hi - lo, b_col0=lo)
+                    dg = input_grad(mlp, 0, dz0, W0, lo, hi)
                     dts[i] = _scatter_rows(dg, i, plan, B, sp.rows_pb, n_rows_tab[i])
         grads[0] = gW0
         de_res = None
@@ -295,12 +323,12 @@ class NodeUpdateFunction(torch.autograd.Function):
         batch = n // rpb
         dout = dout.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, True, params[-2], grads)
+        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, True, params[-2], grads, ctx.mlp)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         (xlo, xhi), (alo, ahi) = mlp._splits
         gemm_tn_acc(dz0, agg, gW0, c_col0=alo)
-        dagg = gemm_nn(dz0, W0, ahi - alo, b_col0=alo) if ctx.needs_input_grad[7] else None
+        dagg = input_grad(mlp, 0, dz0, W0, alo, ahi) if ctx.needs_input_grad[7] else None
         dx = None
         sp = ctx.x_spec
 
@@ -312,7 +340,7 @@ class NodeUpdateFunction(torch.autograd.Function):
             xg = x if sp.rows_pb > 0 else gather_rows(x, 0, None, batch, rpb)
             gemm_tn_acc(dz0, xg, gW0, c_col0=xlo)
             if ctx.needs_input_grad[5]:
-                dx = gemm_nn(dz0, W0, xhi - xlo, b_col0=xlo)
+                dx = input_grad(mlp, 0, dz0, W0, xlo, xhi)
                 if sp.rows_pb == 0:
                     dx = over_batch(dx)
         elif sp.mode == "proj" and ctx.needs_input_grad[5]:

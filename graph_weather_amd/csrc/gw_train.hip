@@ -73,6 +73,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
   }
 }
 
+// TN with more register reuse: block tile 128 (m) x 128 (n), wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles, so one
+// K-step (4 rows of A and B) costs 8 dword loads per lane for 16 MFMAs.
+__global__ __launch_bounds__(256) void gemm_tn_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                      int k_slab) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 128 + (wave >> 1) * 64;
+  const int n0 = blockIdx.y * 128 + (wave & 1) * 64;
+  const int k_begin = blockIdx.z * k_slab;
+  const int k_end = k_begin + k_slab < K ? k_begin + k_slab : K;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool m_ok[4], n_ok[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    m_ok[t] = m0 + 16 * t + i < M;
+    n_ok[t] = n0 + 16 * t + i < N;
+  }
+#pragma unroll 2
+  for (int k0 = k_begin; k0 < k_end; k0 += 4) {
+    const int k = k0 + kq;
+    const bool k_ok = k < k_end;
+    const float* arow = A + (size_t)k * lda + m0 + i;
+    const float* brow = B + (size_t)k * ldb + n0 + i;
+    float a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = (k_ok && m_ok[t]) ? ldg1(arow + 16 * t) : 0.f;
+      b[t] = (k_ok && n_ok[t]) ? ldg1(brow + 16 * t) : 0.f;
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = n0 + 16 * tn + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + 16 * tm + 4 * kq + r;
+        if (mm < M && n < N)
+          __hip_atomic_fetch_add((GW_AS1 float*)(C + (size_t)mm * ldc + n), acc[tm][tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+}
+
 // ---- ReLU backward + bias gradient ----------------------------------------------------------------------------------
 // thread t owns column t of a strip of rows: dz = dh * (h > 0) (h == nullptr: no mask), db[t] += sum of dz over the strip
 __global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t rows, int width, const float* __restrict__ dh, int ld_dh,
@@ -221,9 +275,14 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
   const dim3 block(256);
   if (mode == GW_GEMM_TN) {
     if (k == 0) return GW_OK;  // nothing to add
-    const int k_slab = 2048;
-    const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)((k + k_slab - 1) / k_slab));
-    hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, k_slab);
+    // slab of rows per block: enough blocks to fill the chip (>= ~1024), each at least 256 rows deep
+    const int tiles = (int)((m + 127) / 128) * ((n + 127) / 128);
+    int64_t k_slab = (k * tiles + 1023) / 1024;
+    k_slab = ((k_slab + 63) / 64) * 64;
+    if (k_slab < 256) k_slab = 256;
+    if (k_slab > 4096) k_slab = 4096;
+    const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab);
   } else {
     const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), 1);
     hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, 0);
