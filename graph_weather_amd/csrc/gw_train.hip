@@ -137,7 +137,22 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t rows, int width, 
   const int64_t r0 = (int64_t)blockIdx.x * strip;
   const int64_t r1 = r0 + strip < rows ? r0 + strip : rows;
   float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) {
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {  // 8 independent row loads in flight per thread
+    float g[8], hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      g[u] = dh[(r + u) * ld_dh + col];
+      hv[u] = h != nullptr ? h[(r + u) * ld_h + col] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (!(hv[u] > 0.f)) g[u] = 0.f;
+      if (dz != nullptr) dz[(r + u) * ld_dz + col] = g[u];
+      s += g[u];
+    }
+  }
+  for (; r < r1; ++r) {
     float g = dh[r * ld_dh + col];
     if (h != nullptr && !(h[r * ld_h + col] > 0.f)) g = 0.f;
     if (dz != nullptr) dz[r * ld_dz + col] = g;
@@ -294,7 +309,7 @@ int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh
                      int32_t ld_dz, float* db, void* stream) {
   if (!dh || rows < 0 || width <= 0 || width > 256) return fail(GW_E_BADARG, "gw_relu_backward: bad arguments (width <= 256)");
   if (rows == 0) return GW_OK;
-  const int strip = 128;
+  const int strip = 256;  // few blocks per column: the bias-gradient atomics of all blocks hit the same 256 addresses
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, width,
                      dh, ld_dh, h, ld_h, dz, ld_dz, db, strip);
   return check_launch("relu_bwd_kernel launch");
