@@ -17,7 +17,9 @@ from .layers import (  # noqa: F401
     build_graph_processor_block,
     set_compute_dtype,
 )
+from .graphcast import GraphCast, GraphCastConfig  # noqa: F401
 from .losses import NormalizedMSELoss  # noqa: F401
+from .rollout import rollout  # noqa: F401
 from .optim import AdamW  # noqa: F401
 
 __version__ = "0.1.0"

@@ -424,6 +424,8 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
         if (k_in <= 32) return launch16(chain16_kernel<1, false, 1, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
         if (k_in <= 128) return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
         if (k_in == 256) return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+      } else if (hidden == 256 && n_out <= 80 && k_in == 256) {
+        return launch16(chain16_kernel<8, true, 1, 16, 5, EPI_DEC, false>, a, stream, 1, kLdsWeights);
       } else if (hidden == 128 && n_out <= 80 && k_in == 256) {
         return launch16(chain16_kernel<8, true, 1, 8, 5, EPI_DEC, false>, a, stream, 1, kLdsWeights);
       }

@@ -731,6 +731,10 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
     if (x->k == 256 && x->ld % 4 == 0) return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS>, a, stream);
     return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=112 or ==256 for hidden 256");
   }
+  if (w->hidden == 256 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
+    // head with 256 hidden units (GraphCast wrapper: hidden_dim_decoder = hidden_dim, graphcast/model.py:100-114)
+    return launch_chain(chain_kernel<64, true, 1, 16, 5, EPI_DEC>, a, stream);
+  }
   if (w->hidden == 128 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
     return launch_chain(chain_kernel<64, true, 1, 8, 5, EPI_DEC>, a, stream);
   }

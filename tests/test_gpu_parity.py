@@ -334,3 +334,26 @@ def test_bf16_forecaster_vs_oracle_10deg():
     _close(y32b, y32, rel=1e-6, what="switching back to fp32")
     print(f"[parity] 10deg: rel err of decoder delta fp32 {rel32:.2e}, bf16 {rel16:.2e}")
     assert rel16 > 10 * rel32
+
+
+def test_graphcast_wrapper_matches_oracle_and_rollout_runs():
+    """graphcast/model.py: encoder -> processor -> decoder with the input as residual, decoder head 256 wide."""
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphCast(lat_lons, efficient_batching=True)
+    assert model.decoder.node_decoder.hidden_dim == 256
+    deterministic_fill_(model, seed=5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    feats = seeded_features(2, len(lat_lons), 78, seed=9)
+    y_ref = om.forecaster_forward(sd, model.encoder.graphs.as_oracle_dict(), feats, feature_dim=78)
+    gw.GraphCastConfig.balanced_checkpointing(model)
+    assert model.processor.checkpoint_segments == 3
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y = model(feats.to(DEV))
+    _close(y.cpu() - feats, y_ref - feats, what="GraphCast delta")
+    outs = gw.rollout(model, feats.to(DEV), steps=3)
+    assert len(outs) == 3 and all(torch.isfinite(o).all() for o in outs)
+    _close(outs[0], y, rel=1e-6, what="rollout step 0")
+    with torch.no_grad():
+        y2 = model(outs[0])
+    _close(outs[1], y2, rel=1e-5, what="rollout step 1 = model(model(x))")
