@@ -167,42 +167,80 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t rows, const float* 
                                                      const float* __restrict__ y, int ld_y, const float* __restrict__ gamma,
                                                      float* __restrict__ dy, int ld_dy, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int strip) {
+  constexpr int U = 4;  // rows per wave in flight: the three row reductions are shuffle chains, so interleave rows for ILP
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * strip;
   const int64_t r1 = r0 + strip < rows ? r0 + strip : rows;
   const f32x4 gm = *(const f32x4*)(gamma + 4 * lane);
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, dbt = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = r0 + wave; r < r1; r += 4) {
-    const f32x4 yv = *(const f32x4*)(y + r * ld_y + 4 * lane);
-    const f32x4 dv = *(const f32x4*)(dn + r * ld_dn + 4 * lane);
-    float s = (yv.x + yv.y) + (yv.z + yv.w);
+  for (int64_t rb = r0 + wave * U; rb < r1; rb += 4 * U) {
+    f32x4 yv[U], dv[U];
+    bool ok[U];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    const float mean = s * (1.0f / 256.0f);
-    f32x4 d = yv - mean;
-    float v = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / 256.0f) + 1e-5f);
-    const f32x4 xh = d * rstd;
-    const f32x4 g = dv * gm;
-    float sg = (g.x + g.y) + (g.z + g.w);
-    float sgx = g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sg += __shfl_xor(sg, off);
-      sgx += __shfl_xor(sgx, off);
+    for (int u = 0; u < U; ++u) {
+      ok[u] = rb + u < r1;
+      const int64_t r = ok[u] ? rb + u : rb;
+      yv[u] = *(const f32x4*)(y + r * ld_y + 4 * lane);
+      dv[u] = *(const f32x4*)(dn + r * ld_dn + 4 * lane);
     }
-    const float mg = sg * (1.0f / 256.0f), mgx = sgx * (1.0f / 256.0f);
-    const f32x4 out = (g - mg - xh * mgx) * rstd;
-    *(f32x4*)(dy + r * ld_dy + 4 * lane) = out;
-    dg += dv * xh;
-    dbt += dv;
-  }
+    float s[U];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (dgamma) __hip_atomic_fetch_add(dgamma + 4 * lane + c, dg[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (dbeta) __hip_atomic_fetch_add(dbeta + 4 * lane + c, dbt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = 0; u < U; ++u) s[u] = (yv[u].x + yv[u].y) + (yv[u].z + yv[u].w);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[u] += __shfl_xor(s[u], off);
+    f32x4 d[U];
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      d[u] = yv[u] - s[u] * (1.0f / 256.0f);
+      v[u] = d[u].x * d[u].x + d[u].y * d[u].y + d[u].z * d[u].z + d[u].w * d[u].w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] += __shfl_xor(v[u], off);
+    f32x4 xh[U], g[U];
+    float rstd[U], sg[U], sgx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rstd[u] = 1.0f / sqrtf(v[u] * (1.0f / 256.0f) + 1e-5f);
+      xh[u] = d[u] * rstd[u];
+      g[u] = dv[u] * gm;
+      sg[u] = (g[u].x + g[u].y) + (g[u].z + g[u].w);
+      sgx[u] = g[u].x * xh[u].x + g[u].y * xh[u].y + g[u].z * xh[u].z + g[u].w * xh[u].w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        sg[u] += __shfl_xor(sg[u], off);
+        sgx[u] += __shfl_xor(sgx[u], off);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) {
+        const float mg = sg[u] * (1.0f / 256.0f), mgx = sgx[u] * (1.0f / 256.0f);
+        *(f32x4*)(dy + (rb + u) * ld_dy + 4 * lane) = (g[u] - mg - xh[u] * mgx) * rstd[u];
+        dg += dv[u] * xh[u];
+        dbt += dv[u];
+      }
+    }
+  }
+  // combine the four waves through LDS: one set of atomics per block (all blocks hit the same 512 addresses)
+  __shared__ f32x4 red[2][4][64];
+  red[0][wave][lane] = dg;
+  red[1][wave][lane] = dbt;
+  __syncthreads();
+  if (wave == 0) {
+    dg = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    dbt = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (dgamma) __hip_atomic_fetch_add(dgamma + 4 * lane + c, dg[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbeta) __hip_atomic_fetch_add(dbeta + 4 * lane + c, dbt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -223,21 +261,49 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int batch, int n_idx, 
 
 // out[bo * n_seg + n] (+)= sum_{b in group(bo)} sum_{i = ptr[n] .. ptr[n+1]-1} rows[(b * rows_pb_in + perm[i])]
 // batch_out == batch: per-sample sums;  batch_out == 1: also summed over the batch (tables shared by the batch).
-__global__ __launch_bounds__(256) void segment_sum_kernel(int batch, int batch_out, int n_seg, const float* __restrict__ rows,
-                                                          int rows_pb_in, const int* __restrict__ perm,
-                                                          const int* __restrict__ ptr, float* __restrict__ out, int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (o >= (int64_t)batch_out * n_seg) return;
-  const int bo = (int)(o / n_seg), n = (int)(o - (int64_t)bo * n_seg);
-  const int i0 = ptr[n], i1 = ptr[n + 1];
+// W waves share one segment (entries strided by W, partial sums combined through LDS): W = 1 for the short segments of
+// the mesh (6-7 edges per node), 4 or 16 for the long ones (77 grid edges per mesh node, 3 000 grid points in a polar cell)
+// so that a segment's rows stream in from many waves instead of one wave's dependent loop.
+template <int W>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void segment_sum_kernel(int batch, int batch_out, int n_seg, const float* __restrict__ rows,
+                                                             int rows_pb_in, const int* __restrict__ perm,
+                                                             const int* __restrict__ ptr, float* __restrict__ out, int accumulate) {
+  constexpr int SEGS = W == 1 ? 4 : 1;  // segments per block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t o = W == 1 ? (int64_t)blockIdx.x * SEGS + wave : (int64_t)blockIdx.x;
+  __shared__ f32x4 part[W == 1 ? 1 : W][64];
+  const bool live = o < (int64_t)batch_out * n_seg;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const int b_lo = batch_out == 1 ? 0 : bo, b_hi = batch_out == 1 ? batch : bo + 1;
-  for (int b = b_lo; b < b_hi; ++b)
-    for (int i = i0; i < i1; ++i) {
-      const int r = perm ? perm[i] : i;
-      s += *(const f32x4*)(rows + ((size_t)b * rows_pb_in + r) * 256 + 4 * lane);
+  if (live) {
+    const int bo = (int)(o / n_seg), n = (int)(o - (int64_t)bo * n_seg);
+    const int i0 = ptr[n], i1 = ptr[n + 1];
+    const int b_lo = batch_out == 1 ? 0 : bo, b_hi = batch_out == 1 ? batch : bo + 1;
+    const int w0 = W == 1 ? 0 : wave;
+    for (int b = b_lo; b < b_hi; ++b) {
+      const float* base = rows + (size_t)b * rows_pb_in * 256 + 4 * lane;
+      int i = i0 + w0;
+      for (; i + 3 * W < i1; i += 4 * W) {  // four independent row loads in flight
+        const int ra = perm ? perm[i] : i, rb = perm ? perm[i + W] : i + W;
+        const int rc = perm ? perm[i + 2 * W] : i + 2 * W, rd = perm ? perm[i + 3 * W] : i + 3 * W;
+        const f32x4 va = *(const f32x4*)(base + (size_t)ra * 256), vb = *(const f32x4*)(base + (size_t)rb * 256);
+        const f32x4 vc = *(const f32x4*)(base + (size_t)rc * 256), vd = *(const f32x4*)(base + (size_t)rd * 256);
+        s += (va + vb) + (vc + vd);
+      }
+      for (; i < i1; i += W) {
+        const int r = perm ? perm[i] : i;
+        s += *(const f32x4*)(base + (size_t)r * 256);
+      }
     }
+  }
+  if (W > 1) {
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || !live) return;
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += part[w][lane];
+  } else if (!live) {
+    return;
+  }
   float* p = out + (size_t)o * 256 + 4 * lane;
   if (accumulate) s += *(const f32x4*)p;
   *(f32x4*)p = s;
@@ -320,7 +386,7 @@ int gw_layernorm_backward(int64_t rows, const float* dn, int32_t ld_dn, const fl
   if (!dn || !y || !gamma || !dy || rows < 0 || (ld_dn | ld_y | ld_dy) % 4 != 0)
     return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments (width 256, strides multiple of 4)");
   if (rows == 0) return GW_OK;
-  const int strip = 256;
+  const int strip = 512;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, dn, ld_dn,
                      y, ld_y, gamma, dy, ld_dy, dgamma, dbeta, strip);
   return check_launch("ln_bwd_kernel launch");
@@ -342,8 +408,17 @@ int gw_segment_sum_rows(int32_t batch, int32_t batch_out, int32_t n_seg, const f
     return fail(GW_E_BADARG, "gw_segment_sum_rows: bad arguments");
   const int64_t total = (int64_t)batch_out * n_seg;
   if (total == 0) return GW_OK;
-  hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, batch, batch_out,
-                     n_seg, rows, rows_per_batch_in, perm, ptr, out, accumulate);
+  // average rows per output segment decides how many waves share a segment (n_rows_hint: rows of one batch element)
+  const int64_t per_seg = n_seg > 0 ? ((int64_t)(rows_per_batch_in > 0 ? rows_per_batch_in : 1) * (batch_out == 1 ? batch : 1)) / n_seg : 0;
+  if (per_seg <= 12)
+    hipLaunchKernelGGL(segment_sum_kernel<1>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, batch, batch_out,
+                       n_seg, rows, rows_per_batch_in, perm, ptr, out, accumulate);
+  else if (per_seg <= 128)
+    hipLaunchKernelGGL(segment_sum_kernel<4>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, batch, batch_out, n_seg, rows,
+                       rows_per_batch_in, perm, ptr, out, accumulate);
+  else
+    hipLaunchKernelGGL(segment_sum_kernel<16>, dim3((unsigned)total), dim3(1024), 0, (hipStream_t)stream, batch, batch_out, n_seg, rows,
+                       rows_per_batch_in, perm, ptr, out, accumulate);
   return check_launch("segment_sum_kernel launch");
 }
 

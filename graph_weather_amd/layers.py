@@ -10,7 +10,8 @@ Batching uses *shared-graph* semantics everywhere (one edge list for all batch e
 ``tests/models/layers/test_efficient_batching.py:53,91,145``) without building B copies of the graph,
 re-encoding the batch-independent edge features B times, or running node MLPs on rows that are then dropped.
 
-Forward only in this round (inference / forecasts-per-second path); tensors must be fp32 on a HIP device.
+Under ``torch.no_grad()`` the inference kernels run; with autograd on, the same calls go through ``autograd.py`` (fp32).
+Tensors must be fp32 on a HIP device.
 """
 from __future__ import annotations
 
