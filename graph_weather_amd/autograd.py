@@ -376,6 +376,6 @@ class NormalizedMSEFunction(torch.autograd.Function):
         dpred = torch.empty_like(pred)
         dl = dloss.reshape(1).contiguous().float()
         _lib.check(_L().gw_normalized_mse_backward(pred.data_ptr(), target.data_ptr(), iv.data_ptr() if ctx.has_var else None,
-                                                   w.data_ptr(), int(w.numel()), b, nodes, c, dl.data_ptr(), dpred.data_ptr(),
+                                                   1 if (ctx.has_var and iv.numel() == pred.numel()) else 0, w.data_ptr(), int(w.numel()), b, nodes, c, dl.data_ptr(), dpred.data_ptr(),
                                                    _st(pred)), "gw_normalized_mse_backward")
         return dpred, None, None, None

@@ -512,7 +512,7 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, int n, int npad, 
 
 // ---- NormalizedMSELoss (losses.py:66-94) ----------------------------------------------------------------
 __global__ void nmse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
-                            const float* __restrict__ inv_var, const float* __restrict__ lat_w, int num_lon,
+                            const float* __restrict__ inv_var, int inv_var_full, const float* __restrict__ lat_w, int num_lon,
                             int nodes, int channels, size_t total, float scale, float* __restrict__ loss) {
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -521,7 +521,7 @@ __global__ void nmse_kernel(const float* __restrict__ pred, const float* __restr
     const int n = (int)(row % nodes);
     float d = pred[i] - target[i];
     d = d * d;
-    if (inv_var) d *= inv_var[ch];
+    if (inv_var) d *= inv_var_full ? inv_var[i] : inv_var[ch];
     acc += d * lat_w[n / num_lon];
   }
 #pragma unroll
@@ -837,9 +837,9 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices, 3);
 }
 
-int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,
-                              int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, float* loss_out,
-                              void* stream) {
+int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var, int32_t inv_var_full,
+                              const float* lat_weights, int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels,
+                              float* loss_out, void* stream) {
   if (!pred || !target || !lat_weights || !loss_out || num_unique_lat <= 0 || batch <= 0 || nodes <= 0 || channels <= 0)
     return fail(GW_E_BADARG, "gw_normalized_mse_forward: bad arguments");
   const int num_lon = nodes / num_unique_lat;
@@ -849,7 +849,7 @@ int gw_normalized_mse_forward(const float* pred, const float* target, const floa
   const float scale = 1.0f / ((float)channels * (float)batch * (float)nodes);
   int grid = (int)((total + 1023) / 1024);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(nmse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, inv_var, lat_weights, num_lon, nodes,
+  hipLaunchKernelGGL(nmse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, inv_var, inv_var_full, lat_weights, num_lon, nodes,
                      channels, total, scale, loss_out);
   return check_launch("nmse_kernel launch");
 }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void segment_sum_kernel(int 
 
 // ---- loss backward, optimiser ---------------------------------------------------------------------------------------
 __global__ void nmse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
-                                const float* __restrict__ inv_var, const float* __restrict__ lat_w, int num_lon, int nodes,
+                                const float* __restrict__ inv_var, int inv_var_full, const float* __restrict__ lat_w, int num_lon, int nodes,
                                 int channels, size_t total, float scale, const float* __restrict__ dloss,
                                 float* __restrict__ dpred) {
   const float g = dloss[0] * scale;
@@ -320,7 +320,7 @@ __global__ void nmse_bwd_kernel(const float* __restrict__ pred, const float* __r
     const int ch = (int)(i - row * channels);
     const int n = (int)(row % nodes);
     float d = 2.0f * (pred[i] - target[i]) * lat_w[n / num_lon] * g;
-    if (inv_var) d *= inv_var[ch];
+    if (inv_var) d *= inv_var_full ? inv_var[i] : inv_var[ch];
     dpred[i] = d;
   }
 }
@@ -422,8 +422,8 @@ int gw_segment_sum_rows(int32_t batch, int32_t batch_out, int32_t n_seg, const f
   return check_launch("segment_sum_kernel launch");
 }
 
-int gw_normalized_mse_backward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,
-                               int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, const float* dloss,
+int gw_normalized_mse_backward(const float* pred, const float* target, const float* inv_var, int32_t inv_var_full,
+                               const float* lat_weights, int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, const float* dloss,
                                float* dpred, void* stream) {
   if (!pred || !target || !lat_weights || !dloss || !dpred || num_unique_lat <= 0 || batch <= 0 || nodes <= 0 || channels <= 0)
     return fail(GW_E_BADARG, "gw_normalized_mse_backward: bad arguments");
@@ -433,8 +433,8 @@ int gw_normalized_mse_backward(const float* pred, const float* target, const flo
   const float scale = 1.0f / ((float)channels * (float)batch * (float)nodes);
   int grid = (int)((total + 1023) / 1024);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(nmse_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, inv_var, lat_weights, num_lon,
-                     nodes, channels, total, scale, dloss, dpred);
+  hipLaunchKernelGGL(nmse_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, target, inv_var, inv_var_full, lat_weights,
+                     num_lon, nodes, channels, total, scale, dloss, dpred);
   return check_launch("nmse_bwd_kernel launch");
 }
 

@@ -26,9 +26,10 @@ class NormalizedMSELoss(torch.nn.Module):
         inv_var = None
         if self.normalize:
             fv = self.feature_variance
-            if fv.numel() != pred.shape[-1]:
-                raise NotImplementedError("graph_weather_amd: feature_variance must be per-channel [C] on the HIP path")
-            inv_var = (1.0 / fv.reshape(-1)).contiguous()
+            if fv.numel() == pred.shape[-1]:
+                inv_var = (1.0 / fv.reshape(-1)).contiguous()
+            else:  # anything that broadcasts against [B, G, C] (losses.py:69; the reference's own test passes [B, G, C])
+                inv_var = (1.0 / torch.broadcast_to(fv, pred.shape)).contiguous()
         if torch.is_grad_enabled() and pred.requires_grad:
             from .autograd import NormalizedMSEFunction
 

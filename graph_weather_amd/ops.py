@@ -240,13 +240,16 @@ def normalized_mse_forward(pred: torch.Tensor, target: torch.Tensor, lat_weights
     b = int(pred.shape[0])
     c = int(pred.shape[-1])
     nodes = pred.numel() // (b * c)
+    full = 0
     if inv_var is not None:
         _require(inv_var, "inv_var")
-        if inv_var.numel() != c:
-            raise RuntimeError("graph_weather_amd: feature_variance must have one entry per channel")
+        if inv_var.numel() == pred.numel():
+            full = 1
+        elif inv_var.numel() != c:
+            raise RuntimeError("graph_weather_amd: 1 / feature_variance must be per channel [C] or shaped like pred")
     loss = torch.zeros((), dtype=torch.float32, device=pred.device)
     _lib.check(_lib.lib().gw_normalized_mse_forward(pred.data_ptr(), target.data_ptr(),
-                                                    None if inv_var is None else inv_var.data_ptr(), lat_weights.data_ptr(),
+                                                    None if inv_var is None else inv_var.data_ptr(), full, lat_weights.data_ptr(),
                                                     int(lat_weights.numel()), b, nodes, c, loss.data_ptr(), _stream(pred)),
                "gw_normalized_mse_forward")
     return loss

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 3
+#define GW_ABI_VERSION 4
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -130,8 +130,9 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
 
 /* ---- NormalizedMSELoss.forward (losses.py:66-94, normalize on/off) ---------------------------------------
  * loss = mean_{b,n}( w_lat[n / num_lon] * mean_c( (pred-target)^2 [/ var_c] ) ); *loss_out must be zeroed. */
-int gw_normalized_mse_forward(const float* pred, const float* target, const float* inv_var /* NULL or [c] */,
-                              const float* lat_weights, int32_t num_unique_lat, int32_t batch, int32_t nodes,
+int gw_normalized_mse_forward(const float* pred, const float* target,
+                              const float* inv_var /* NULL, [c] (inv_var_full 0) or [batch, nodes, c] (inv_var_full 1) */,
+                              int32_t inv_var_full, const float* lat_weights, int32_t num_unique_lat, int32_t batch, int32_t nodes,
                               int32_t channels, float* loss_out, void* stream);
 
 /* =====================================================================================================================
@@ -172,7 +173,8 @@ int gw_gather_rows(int32_t batch, int32_t n_idx, const float* table, int32_t row
 int gw_segment_sum_rows(int32_t batch, int32_t batch_out, int32_t n_seg, const float* rows, int32_t rows_per_batch_in,
                         const int32_t* perm, const int32_t* ptr, float* out, int32_t accumulate, void* stream);
 /* NormalizedMSELoss backward (losses.py:66-94): dpred = dloss * d loss / d pred. */
-int gw_normalized_mse_backward(const float* pred, const float* target, const float* inv_var, const float* lat_weights,
+int gw_normalized_mse_backward(const float* pred, const float* target, const float* inv_var, int32_t inv_var_full,
+                               const float* lat_weights,
                                int32_t num_unique_lat, int32_t batch, int32_t nodes, int32_t channels, const float* dloss,
                                float* dpred, void* stream);
 /* torch.optim.AdamW step (decoupled weight decay, bias correction with `step` >= 1) on a flat fp32 buffer. */

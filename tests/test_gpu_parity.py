@@ -36,7 +36,7 @@ def _golden(golden_dir, name):
 
 def test_extension_is_loaded():
     L = _lib.lib()
-    assert L.gw_version() == 3
+    assert L.gw_version() == 4
     assert torch.cuda.is_available()
 
 
@@ -192,6 +192,17 @@ def test_loss_closed_form():
     pred = torch.sqrt(var)[None, None, :].expand(2, len(lat_lons), 78).contiguous().to(DEV)
     loss = gw.NormalizedMSELoss(var.tolist(), lat_lons, normalize=True)(pred, torch.zeros_like(pred))
     assert abs(loss.item() - np.cos(np.arange(-90, 90, 5) * np.pi / 180.0).mean()) < 1e-4
+
+
+def test_loss_with_full_shape_variance():
+    """The reference's own known-answer test (tests/test_model.py:236-271): feature_variance = out**2 shaped like the
+    prediction, target 0, normalize=True -> every error term is 1 and the loss is the mean latitude weight."""
+    lat_lons = [(lat, lon) for lat in range(-90, 90, 5) for lon in range(0, 360, 5)]
+    out = torch.rand((2, len(lat_lons), 78)) + 0.0001
+    crit = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=out**2, normalize=True)
+    loss = crit(out.to(DEV), torch.zeros_like(out).to(DEV))
+    expected = np.cos(np.arange(-90, 90, 5) * np.pi / 180.0).mean()
+    assert abs(loss.item() - expected) < 1e-4
 
 
 def test_full_size_1deg_properties_and_oracle_sample():

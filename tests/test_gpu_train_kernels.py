@@ -165,6 +165,6 @@ def test_nmse_backward_matches_autograd():
     iv = (1.0 / var).float().to(DEV)
     dl = torch.full((1,), 1.0, device=DEV)
     dp = torch.empty_like(pd)
-    _lib.check(L.gw_normalized_mse_backward(pd.data_ptr(), td.data_ptr(), iv.data_ptr(), w.data_ptr(), len(lats), 2, len(lat_lons), 78,
+    _lib.check(L.gw_normalized_mse_backward(pd.data_ptr(), td.data_ptr(), iv.data_ptr(), 0, w.data_ptr(), len(lats), 2, len(lat_lons), 78,
                                             dl.data_ptr(), dp.data_ptr(), _st()), "nmse bwd")
     assert _rel(dp, pred.grad) < 1e-5
