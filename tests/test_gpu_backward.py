@@ -122,3 +122,30 @@ def test_forecaster_training_step_gradients_10deg():
     opt.zero_grad()
     for p, b in zip(model.parameters(), before):
         assert torch.isfinite(p).all() and not torch.equal(p, b)
+
+
+@pytest.mark.parametrize("irregular,checkpoint", [(False, False), (True, False), (False, True)])
+def test_forecaster_and_loss_like_the_reference_tests(irregular, checkpoint):
+    """tests/test_model.py:157-172 (regular 5 degree grid), :174-191 (jittered lat/lons: every latitude unique) and
+    :220-234 (use_checkpointing=True): forward, NormalizedMSELoss, loss.backward() - here also checked against the oracle."""
+    rs = np.random.RandomState(11)
+    lat_lons = [(float(lat), float(lon)) for lat in range(-90, 90, 5) for lon in range(0, 360, 5)]
+    if irregular:
+        lat_lons = [(lat + rs.random_sample(), lon + rs.random_sample()) for lat, lon in lat_lons]
+    var = torch.from_numpy(rs.standard_normal(78).astype(np.float32))
+    model = gw.GraphWeatherForecaster(lat_lons, use_checkpointing=checkpoint)
+    deterministic_fill_(model, seed=2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    feats = torch.from_numpy(rs.standard_normal((2, len(lat_lons), 78 + 24)).astype(np.float32))
+    target = torch.from_numpy(rs.random_sample((2, len(lat_lons), 78)).astype(np.float32))
+    y_ref = om.forecaster_forward(sd, model.encoder.graphs.as_oracle_dict(), feats)
+    loss_ref = om.normalized_mse_loss(y_ref, target, lat_lons, var)
+    criterion = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=var)
+    model = model.to(DEV)
+    out = model(feats.to(DEV))
+    loss = criterion(out, target.to(DEV))
+    assert not torch.isnan(loss) and not torch.isnan(out).any()
+    assert _rel(out.cpu() - feats[..., :78], y_ref - feats[..., :78]) < 2e-4
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
