@@ -37,15 +37,16 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, n: int, b_col0: int = 0, out: Opti
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     _lib.check(_L().gw_gemm_f32(_lib.GEMM_NN, m, n, k, a.data_ptr(), int(a.stride(0)), b.data_ptr() + 4 * b_col0,
-                                int(b.stride(0)), out.data_ptr(), int(out.stride(0)), _st(a)), "gw_gemm_f32 NN")
+                                int(b.stride(0)), out.data_ptr(), int(out.stride(0)), None, _st(a)), "gw_gemm_f32 NN")
     return out
 
 
-def gemm_tn_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, c_col0: int = 0) -> None:
-    """c[:ma, c_col0:c_col0+nb] += a^T @ b   (a [rows, ma], b [rows, nb])."""
+def gemm_tn_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, c_col0: int = 0, colsum: Optional[torch.Tensor] = None) -> None:
+    """c[:ma, c_col0:c_col0+nb] += a^T @ b   (a [rows, ma], b [rows, nb]);  colsum[:ma] += column sums of a."""
     rows, ma, nb = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
     _lib.check(_L().gw_gemm_f32(_lib.GEMM_TN, ma, nb, rows, a.data_ptr(), int(a.stride(0)), b.data_ptr(), int(b.stride(0)),
-                                c.data_ptr() + 4 * c_col0, int(c.stride(0)), _st(a)), "gw_gemm_f32 TN")
+                                c.data_ptr() + 4 * c_col0, int(c.stride(0)), None if colsum is None else colsum.data_ptr(), _st(a)),
+               "gw_gemm_f32 TN")
 
 
 def relu_backward(dh: torch.Tensor, h: Optional[torch.Tensor], db: Optional[torch.Tensor]) -> torch.Tensor:
@@ -100,13 +101,18 @@ def _packed_transposed(mlp, layer: int, lo: int, hi: int):
     return cache[key][1]
 
 
-def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
-    """d @ W[:, lo:hi]  ([rows, hi-lo]): fused single-layer kernel for 256 x 256 blocks, generic GEMM otherwise."""
+def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: int,
+               relu_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(d @ W[:, lo:hi]) [* (relu_of > 0)]  ([rows, hi-lo]): fused single-layer kernel for 256 x 256 blocks (the ReLU
+    backward rides in its epilogue), generic GEMM + mask kernel otherwise."""
     pt = _packed_transposed(mlp, layer, lo, hi) if (d.shape[1] == 256 and d.stride(0) % 4 == 0) else None
-    if pt is None:
-        return gemm_nn(d, W, hi - lo, b_col0=lo)
-    rows = int(d.shape[0])
-    return ops.project_forward([pt], Operand(d, rows, 256), rows, rows, weight_dtype=_lib.DTYPE_F32)[0]
+    if pt is not None and (relu_of is None or (relu_of.shape[1] == 256 and relu_of.stride(0) == 256)):
+        rows = int(d.shape[0])
+        return ops.project_forward([pt], Operand(d, rows, 256), rows, rows, weight_dtype=_lib.DTYPE_F32, relu_mask=relu_of)[0]
+    out = gemm_nn(d, W, hi - lo, b_col0=lo)
+    if relu_of is not None:
+        relu_backward(out, relu_of, None)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -129,20 +135,20 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1])
     else:
         d = dout.contiguous()
-    # bias gradient of the last Linear = column sums of d
-    grads[2 * (n_lin - 1) + 1] = torch.zeros_like(weights[2 * (n_lin - 1) + 1])
-    relu_backward(d, None, grads[2 * (n_lin - 1) + 1])
+    # Every Linear_l (l >= 1) gets its weight gradient d_l^T h_{l-1} and, from the same GEMM, its bias gradient (column
+    # sums of d_l); the input gradient d_l W_l is masked by the ReLU that produced h_{l-1} in the product's epilogue.
     for l in range(n_lin - 1, 0, -1):
         W = weights[2 * l]
         h_prev = saved.hidden[l - 1]  # relu output feeding Linear_l, [rows, in_l]
         gW = torch.zeros_like(W)
-        gemm_tn_acc(d, h_prev, gW)  # dW_l = d^T h_prev
-        grads[2 * l] = gW
-        dh = input_grad(mlp, l, d, W, 0, int(W.shape[1])) if mlp is not None else gemm_nn(d, W, int(W.shape[1]))  # [rows, in_l]
-        # through the ReLU that produced h_prev; the column sums of the result are Linear_{l-1}'s bias gradient
-        grads[2 * (l - 1) + 1] = torch.zeros_like(weights[2 * (l - 1) + 1])
-        relu_backward(dh, h_prev, grads[2 * (l - 1) + 1])
-        d = dh
+        gb = torch.zeros_like(weights[2 * l + 1])
+        gemm_tn_acc(d, h_prev, gW, colsum=gb)
+        grads[2 * l], grads[2 * l + 1] = gW, gb
+        d = (input_grad(mlp, l, d, W, 0, int(W.shape[1]), relu_of=h_prev) if mlp is not None
+             else relu_backward(gemm_nn(d, W, int(W.shape[1])), h_prev, None))
+    # Linear_0's bias gradient: column sums of dz0 (its weight gradient is the caller's: it depends on the operands)
+    grads[1] = torch.zeros_like(weights[1])
+    relu_backward(d, None, grads[1])
     return d, d.device
 
 

@@ -50,6 +50,8 @@ struct ChainArgs {
   float* agg;
   const int* agg_idx;
   int agg_rows_pb;
+  // single-layer mode: rows [n_cols, 256] whose sign masks the output (ReLU backward fused into an input-gradient product)
+  const float* relu_mask;
   // training: activations saved for the backward (gw_activation_save), NULL in inference
   float* save_h;
   long long save_stride;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 // K-step (4 rows of A and B) costs 8 dword loads per lane for 16 MFMAs.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                                                      int k_slab) {
+                                                      int k_slab, float* __restrict__ colsum_a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int M, int N, int K, const
     m_ok[t] = m0 + 16 * t + i < M;
     n_ok[t] = n0 + 16 * t + i < N;
   }
+  // column sums of A (the bias gradient when A = dZ): taken once per m, by the waves of the first n-block column
+  const bool do_sum = colsum_a != nullptr && blockIdx.y == 0 && (wave & 1) == 0;
+  float asum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
   for (int k0 = k_begin; k0 < k_end; k0 += 4) {
     const int k = k0 + kq;
@@ -107,11 +110,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int M, int N, int K, const
     for (int t = 0; t < 4; ++t) {
       a[t] = (k_ok && m_ok[t]) ? ldg1(arow + 16 * t) : 0.f;
       b[t] = (k_ok && n_ok[t]) ? ldg1(brow + 16 * t) : 0.f;
+      asum[t] += a[t];
     }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  }
+  if (do_sum) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = asum[t];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0 && m_ok[t])
+        __hip_atomic_fetch_add((GW_AS1 float*)(colsum_a + m0 + 16 * t + i), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
@@ -348,11 +362,12 @@ int fail(int code, const char* msg) { return set_error(code, msg); }
 extern "C" {
 
 int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
-                float* c, int32_t ldc, void* stream) {
+                float* c, int32_t ldc, float* colsum_a, void* stream) {
   if (!a || !b || !c || m < 0 || n < 0 || k < 0 || (mode != GW_GEMM_NN && mode != GW_GEMM_TN))
     return fail(GW_E_BADARG, "gw_gemm_f32: bad arguments");
   if (m == 0 || n == 0) return GW_OK;
   if (m >= ((int64_t)1 << 31) || k >= ((int64_t)1 << 31)) return fail(GW_E_UNSUPPORTED, "gw_gemm_f32: dimension exceeds int32");
+  if (colsum_a && mode != GW_GEMM_TN) return fail(GW_E_UNSUPPORTED, "gw_gemm_f32: colsum_a is a TN-mode extra");
   const dim3 block(256);
   if (mode == GW_GEMM_TN) {
     if (k == 0) return GW_OK;  // nothing to add
@@ -363,7 +378,7 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     if (k_slab < 256) k_slab = 256;
     if (k_slab > 4096) k_slab = 4096;
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
   } else {
     const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), 1);
     hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, 0);

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 4
+#define GW_ABI_VERSION 5
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -105,7 +105,10 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
  * out_s[c, :] = x[c, :256] . W_s^T for s < n_slices (<= 4); W_s = packed [256, 256] slices from gw_pack_linear. */
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
                        const float* const* w_slices, float* const* outs, int32_t out_ld,
-                       int32_t weight_dtype /* GW_DTYPE_* of the slices */, void* stream);
+                       int32_t weight_dtype /* GW_DTYPE_* of the slices */,
+                       const float* relu_mask /* NULL, or [n_rows, 256]: out *= (relu_mask > 0) - ReLU backward fused into an
+                                                  input-gradient product (backward pass; single fp32 slice) */,
+                       void* stream);
 
 /* ---- EdgeProcessor.forward + scatter_sum (graph_net_block.py:131-137 and :188) --------------------------
  * For every batch element b and edge e (dst-sorted):
@@ -155,7 +158,8 @@ typedef struct gw_activation_save {
 #define GW_GEMM_NN 0 /* C[m][n]  = sum_k A[m][k] * B[k][n]   (input gradients:  dX = dZ . W)                         */
 #define GW_GEMM_TN 1 /* C[m][n] += sum_k A[k][m] * B[k][n]   (weight gradients: dW += dZ^T . X; C must hold the sum) */
 int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
-                float* c, int32_t ldc, void* stream);
+                float* c, int32_t ldc, float* colsum_a /* TN only, may be NULL: colsum_a[m] += sum_k A[k][m] (bias gradient) */,
+                void* stream);
 /* nn.ReLU backward fused with the nn.Linear bias gradient: dz = dh * (h > 0) (h NULL: dz = dh), db[c] += sum_r dz[r][c].
  * dz may alias dh or be NULL (bias gradient only); db may be NULL. width <= 256. */
 int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,

@@ -28,7 +28,7 @@ def test_gemm_nn(m, n, k):
     c = torch.full((m, n + 5), 7.0, device=DEV)
     ad, bd = a.to(DEV), b.to(DEV)
     L = _lib.lib()
-    _lib.check(L.gw_gemm_f32(_lib.GEMM_NN, m, n, k, ad.data_ptr(), k, bd.data_ptr(), n + 3, c.data_ptr(), n + 5, _st()), "gemm")
+    _lib.check(L.gw_gemm_f32(_lib.GEMM_NN, m, n, k, ad.data_ptr(), k, bd.data_ptr(), n + 3, c.data_ptr(), n + 5, None, _st()), "gemm")
     ref = a.double() @ b[:, :n].double()
     assert _rel(c[:, :n], ref) < 2e-6
     assert torch.all(c[:, n:] == 7.0)  # nothing written outside
@@ -43,9 +43,11 @@ def test_gemm_tn_accumulates(m, n, k):
     c = c0.to(DEV)
     ad, bd = a.to(DEV), b.to(DEV)
     L = _lib.lib()
-    _lib.check(L.gw_gemm_f32(_lib.GEMM_TN, m, n, k, ad.data_ptr(), m, bd.data_ptr(), n, c.data_ptr(), n, _st()), "gemm")
+    cs = torch.ones(m, device=DEV)
+    _lib.check(L.gw_gemm_f32(_lib.GEMM_TN, m, n, k, ad.data_ptr(), m, bd.data_ptr(), n, c.data_ptr(), n, cs.data_ptr(), _st()), "gemm")
     ref = c0.double() + a.double().t() @ b.double()
     assert _rel(c, ref) < 1e-5
+    assert _rel(cs, 1.0 + a.double().sum(0)) < 1e-5  # fused column sums of A (bias gradient)
 
 
 def test_relu_backward_and_bias_grad():
