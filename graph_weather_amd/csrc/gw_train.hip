@@ -141,6 +141,101 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int M, int N, int K, const
     }
 }
 
+// TN for the common aligned case (M, N multiples of 128; lda, ldb multiples of 4): both operand tiles are staged through
+// LDS with coalesced 16-byte loads (double buffered, 16 rows of k per stage), MFMA operands come from LDS.
+constexpr int kTnKC = 16;     // k rows per stage
+constexpr int kTnLd = 144;    // LDS row stride in floats (128 + 16: the 4 k-rows of an MFMA step hit disjoint banks)
+__global__ __launch_bounds__(256) void gemm_tn_lds_kernel(int K, const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                          int k_slab, float* __restrict__ colsum_a) {
+  __shared__ __attribute__((aligned(16))) float sm[2][2][kTnKC * kTnLd];  // [stage][A|B]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int mB = blockIdx.x * 128, nB = blockIdx.y * 128;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int k_begin = blockIdx.z * k_slab;
+  const int k_end = k_begin + k_slab < K ? k_begin + k_slab : K;
+  const int lrow = threadIdx.x >> 5;        // 0..7 (+8): k row inside a stage
+  const int lcol = (threadIdx.x & 31) * 4;  // float offset inside the 128-wide tile
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = colsum_a != nullptr && blockIdx.y == 0 && (wave & 1) == 0;
+  float asum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[2], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + lrow + 8 * h;
+      if (k < k_end) {
+        ra[h] = ldg4(A + (size_t)k * lda + mB + lcol);
+        rb[h] = ldg4(B + (size_t)k * ldb + nB + lcol);
+      } else {
+        ra[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto stash = [&](int st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *(f32x4*)(&sm[st][0][(lrow + 8 * h) * kTnLd + lcol]) = ra[h];
+      *(f32x4*)(&sm[st][1][(lrow + 8 * h) * kTnLd + lcol]) = rb[h];
+    }
+  };
+  fetch(k_begin);
+  stash(0);
+  __syncthreads();
+  int st = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += kTnKC) {
+    const bool more = k0 + kTnKC < k_end;
+    if (more) fetch(k0 + kTnKC);  // global loads of the next stage fly under this stage's MFMAs
+    const float* as = &sm[st][0][kq * kTnLd + wm + i];
+    const float* bs = &sm[st][1][kq * kTnLd + wn + i];
+#pragma unroll
+    for (int ks = 0; ks < kTnKC / 4; ++ks) {
+      float a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = as[ks * 4 * kTnLd + 16 * t];
+        b[t] = bs[ks * 4 * kTnLd + 16 * t];
+        asum[t] += a[t];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (more) stash(st ^ 1);
+    __syncthreads();
+    st ^= 1;
+  }
+  if (do_sum) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = asum[t];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0) __hip_atomic_fetch_add((GW_AS1 float*)(colsum_a + mB + wm + 16 * t + i), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = nB + wn + 16 * tn + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = mB + wm + 16 * tm + 4 * kq + r;
+        __hip_atomic_fetch_add((GW_AS1 float*)(C + (size_t)mm * ldc + n), acc[tm][tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+}
+
 // ---- ReLU backward + bias gradient ----------------------------------------------------------------------------------
 // thread t owns column t of a strip of rows: dz = dh * (h > 0) (h == nullptr: no mask), db[t] += sum of dz over the strip
 __global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t rows, int width, const float* __restrict__ dh, int ld_dh,
@@ -378,6 +473,10 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     if (k_slab < 256) k_slab = 256;
     if (k_slab > 4096) k_slab = 4096;
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
+    if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
+      hipLaunchKernelGGL(gemm_tn_lds_kernel, grid, block, 0, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
+      return check_launch("gemm_tn_lds_kernel launch");
+    }
     hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
   } else {
     const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), 1);
