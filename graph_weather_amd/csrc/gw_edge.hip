@@ -73,6 +73,11 @@ struct EdgeArgs {
   int res_ld;
   float* e_out;
   float* agg;
+  // training: activations saved for the backward (gw_activation_save; NULL in inference); n_mid == 1 only
+  float* save_h;
+  long long save_stride;
+  int save_ld;
+  float* save_y;
 };
 
 template <int N>
@@ -298,6 +303,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
       in8[r] = fmaxf(v0_[r], 0.f);                                             \
       in8[4 + r] = fmaxf(v1_[r], 0.f);                                         \
     }                                                                          \
+    if (a.save_h != nullptr && valid) { /* relu output of layer 1, features 32 slice + 4q.. and + 16 */ \
+      float* sr_ = a.save_h + (size_t)c * (size_t)a.save_ld + 32 * (slice) + 4 * q;                     \
+      stg4(sr_, f32x4{in8[0], in8[1], in8[2], in8[3]});                        \
+      stg4(sr_ + 16, f32x4{in8[4], in8[5], in8[6], in8[7]});                   \
+    }                                                                          \
   }
 
   f32x4 a_cur[4];  // A fragments of the next K-step to run
@@ -408,6 +418,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) hin[4 * t + r] = fmaxf(acc2[t][r], 0.f);
+  if (a.save_h != nullptr && valid) {
+    float* sr = a.save_h + (size_t)a.n_mid * (size_t)a.save_stride + (size_t)c * (size_t)a.save_ld + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) stg4(sr + 16 * t, f32x4{hin[4 * t], hin[4 * t + 1], hin[4 * t + 2], hin[4 * t + 3]});
+  }
   f32x4 o[16];
   f32x4 rres[16];
 #pragma unroll
@@ -434,6 +449,11 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
   {
 #pragma unroll
     for (int t = 0; t < 16; ++t) o[t] += ldg4(a.b_out + 16 * t + 4 * q);
+    if (a.save_y != nullptr && valid) {
+      float* sr = a.save_y + (size_t)c * 256 + 4 * q;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) stg4(sr + 16 * t, o[t]);
+    }
     constexpr float inv_n = 1.0f / 256.0f;
     float s = 0.f;
 #pragma unroll
@@ -568,7 +588,7 @@ bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const 
 
 int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                      const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                     float* e_out, float* agg, int32_t n_dst, void* stream) {
+                     float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, void* stream) {
   EdgeArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;
@@ -608,6 +628,12 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
   a.res_ld = e_res->ld;
   a.e_out = e_out;
   a.agg = agg;
+  if (save) {
+    a.save_h = save->hidden;
+    a.save_stride = save->hidden_stride;
+    a.save_ld = save->hidden_ld;
+    a.save_y = save->pre_norm;
+  }
   if (g_dbg != nullptr && g_dbg_kind == 1) {
     a.dbg = g_dbg;
     a.dbg_cap = g_dbg_cap;

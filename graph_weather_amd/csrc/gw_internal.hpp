@@ -75,7 +75,7 @@ int check_launch(const char* what);
 bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w);
 int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                      const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                     float* e_out, float* agg, int32_t n_dst, void* stream);
+                     float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, void* stream);
 
 }  // namespace gw
 

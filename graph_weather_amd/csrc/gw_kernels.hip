@@ -770,8 +770,11 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
   if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
-  if (!save && w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w))
-    return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, stream);
+  if (w->weight_dtype == GW_DTYPE_F32 && (!save || w->n_mid == 1) && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) {
+    if (save && (!save->hidden || !save->pre_norm || save->hidden_ld < 256 || save->hidden_ld % 4 != 0))
+      return fail(GW_E_BADARG, "gw_edge_update_forward: bad gw_activation_save");
+    return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, save, stream);
+  }
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;
