@@ -164,11 +164,15 @@ __device__ __forceinline__ void lds_barrier() {
 
 extern __shared__ __attribute__((aligned(16))) float gw_edge_lds[];
 __device__ __forceinline__ float* lds_base() { return gw_edge_lds; }
+// LDS byte address of the dynamic segment (0 unless the kernel also had static LDS; taken from the pointer, not assumed)
+__device__ __forceinline__ unsigned lds_base_bytes() {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) float*)gw_edge_lds;
+}
 
 // Each wave DMAs its 8 KiB share of one 32 KiB weight chunk into an LDS buffer: exactly 8 x global_load_lds (1 KiB
 // each), no branches - the vmcnt(N) bookkeeping of the kernel counts on that.
 __device__ __forceinline__ void issue_chunk32k(const float* __restrict__ g, float* ldsbuf, int lane, int wave) {
-  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(ldsbuf - lds_base()) * 4u + (unsigned)wave * 1024u);
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_base_bytes() + (unsigned)(ldsbuf - lds_base()) * 4u + (unsigned)wave * 1024u);
 #pragma unroll
   for (int i = 0; i < 8; ++i) glds16_asm_s(g + (size_t)(wave + 4 * i) * 256, (unsigned)lane * 16u, base + (unsigned)i * 4096u);
 }
@@ -177,7 +181,7 @@ __device__ __forceinline__ void issue_chunk32k(const float* __restrict__ g, floa
 constexpr int kDmaSteps = 4;  // the 8 pieces of the next chunk are issued 2 per K-step during the first 4 steps of a chunk
 template <int N>
 __device__ __forceinline__ void issue_pieces(const float* __restrict__ g, int buf_floats, int first, int lane, int wave) {
-  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)buf_floats * 4u + (unsigned)wave * 1024u);
+  const unsigned base = __builtin_amdgcn_readfirstlane(lds_base_bytes() + (unsigned)buf_floats * 4u + (unsigned)wave * 1024u);
 #pragma unroll
   for (int i = 0; i < N; ++i)
     glds16_asm_s(g + (size_t)(wave + 4 * (first + i)) * 256, (unsigned)lane * 16u, base + (unsigned)(first + i) * 4096u);
@@ -232,7 +236,7 @@ __device__ __forceinline__ const float* chunk_src(const EdgeArgs& a, int i) {
 
 template <bool RAW, int NPROJ>
 __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
-  float* const lds = lds_base();  // dynamic LDS starts at byte address 0 (the kernel has no static LDS)
+  float* const lds = lds_base();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
