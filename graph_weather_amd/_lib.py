@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 EXPORTS = [
@@ -99,7 +99,7 @@ def lib():
                                          POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]
     L.gw_project_forward.restype = c_int
     L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
-                                     c_int32, c_int32, c_void_p, c_void_p]
+                                     c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     L.gw_normalized_mse_forward.restype = c_int
     L.gw_normalized_mse_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                             c_void_p, c_void_p]

@@ -52,6 +52,9 @@ struct ChainArgs {
   int agg_rows_pb;
   // single-layer mode: rows [n_cols, 256] whose sign masks the output (ReLU backward fused into an input-gradient product)
   const float* relu_mask;
+  // single-layer mode: rows [n_cols, 256] to fill with zeros on the side (the aggregate buffer of the edge update that
+  // consumes these products: saves a separate fill launch per block)
+  float* zero_rows;
   // training: activations saved for the backward (gw_activation_save), NULL in inference
   float* save_h;
   long long save_stride;

@@ -332,6 +332,11 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     static_assert(!SINGLE || HT == OT, "single-layer mode stores the layer-1 accumulator");
 #pragma unroll
     for (int t = 0; t < OT; ++t) o[t] = acc[t < HT ? t : 0];
+    if (a.zero_rows != nullptr && valid && blockIdx.y == 0) {
+      float* zrow = a.zero_rows + (size_t)c * 256;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) stg4(zrow + 16 * t + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
     if (a.relu_mask != nullptr) {  // out *= (mask > 0): the ReLU backward of the layer whose output gradient this product is
       const float* mrow = a.relu_mask + (size_t)c * 256;
 #pragma unroll
@@ -828,7 +833,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
 
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
                        const float* const* w_slices, float* const* outs, int32_t out_ld, int32_t weight_dtype,
-                       const float* relu_mask, void* stream) {
+                       const float* relu_mask, float* zero_rows, void* stream) {
   if (!x || !w_slices || !outs || n_rows < 0 || rows_per_batch <= 0 || n_slices <= 0 || n_slices > 4)
     return fail(GW_E_BADARG, "gw_project_forward: bad arguments (1..4 slices)");
   if (n_rows == 0) return GW_OK;
@@ -849,6 +854,8 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   if (relu_mask && (weight_dtype != GW_DTYPE_F32 || n_slices != 1))
     return fail(GW_E_UNSUPPORTED, "gw_project_forward: relu_mask needs fp32 weights and a single slice");
   a.relu_mask = relu_mask;
+  if (zero_rows && weight_dtype != GW_DTYPE_F32) return fail(GW_E_UNSUPPORTED, "gw_project_forward: zero_rows needs fp32 weights");
+  a.zero_rows = zero_rows;
   if (weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(3, a, 256, 256, 256, n_slices, stream);
   return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices, 3);
 }

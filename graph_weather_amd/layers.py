@@ -171,9 +171,10 @@ class GraphNetBlock(nn.Module):
 
     def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
             x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
-            tag: Optional[str] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+            tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
-        Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``)."""
+        Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``).
+        ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch)."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
         if _autograd_on(self):
             agg, e_out = ag.edge_update(self.edge_model.edge_mlp, plan, batch, (x_src.spec(), x_dst.spec(), e_in.spec()),
@@ -181,7 +182,7 @@ class GraphNetBlock(nn.Module):
             x_new = ag.node_update(self.node_model.node_mlp, batch * n_dst, n_dst, x_node.spec(), x_node.tensor, x_res,
                                    x_res_rows_pb, agg)
             return x_new, e_out
-        agg = torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
+        agg = agg_zeroed if agg_zeroed is not None else torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
         e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
                                 e_in.operand(), Operand(e_res, e_res_rows_pb, 256), n_dst, agg, e_out, tag=tag)
@@ -242,7 +243,10 @@ class GraphProcessor(nn.Module):
                 ps, pd = ag.project(mlp_e, (0, 1), x, batch * n, n)
             else:
                 pm_e = mlp_e.packed()
-                ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n)
+                agg_buf = None
+                if mlp_e.compute_dtype == torch.float32:  # the projection launch also zero-fills this block's aggregate
+                    agg_buf = torch.empty((batch * n, 256), dtype=torch.float32, device=x.device)
+                ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n, zero_rows=agg_buf)
             if shared:
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
@@ -256,7 +260,8 @@ class GraphProcessor(nn.Module):
             else:
                 e_in = Feed(e_cur, n_edges, "raw")
             x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_cur, 0 if shared else n_edges,
-                               Feed(x, n, "raw"), x, n, want_edges or not last, x.device, tag="processor_edge")
+                               Feed(x, n, "raw"), x, n, want_edges or not last, x.device, tag="processor_edge",
+                               agg_zeroed=None if train else agg_buf)
             if e_new is not None:
                 e_cur, shared = e_new, False
         return x, (e_cur if want_edges else None)

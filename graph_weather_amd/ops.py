@@ -178,7 +178,8 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
 
 
 def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, rows_per_batch: int,
-                    weight_dtype: Optional[int] = None, relu_mask: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                    weight_dtype: Optional[int] = None, relu_mask: Optional[torch.Tensor] = None,
+                    zero_rows: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """out_s = x . W_s^T for up to four packed [256, 256] layer-1 slices in one launch (layer-1 split of
     graph_net_block.py:131-134 / :189: products over node tables are shared by all incident edges)."""
     import ctypes
@@ -191,7 +192,8 @@ def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, r
     if weight_dtype is None:
         weight_dtype = _lib.DTYPE_BF16 if w_slices[0].dtype == torch.bfloat16 else _lib.DTYPE_F32
     _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, weight_dtype,
-                                             None if relu_mask is None else relu_mask.data_ptr(), _stream(outs[0])),
+                                             None if relu_mask is None else relu_mask.data_ptr(),
+                                             None if zero_rows is None else zero_rows.data_ptr(), _stream(outs[0])),
                "gw_project_forward")
     return outs
 

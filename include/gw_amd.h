@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 5
+#define GW_ABI_VERSION 6
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -108,6 +108,8 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
                        int32_t weight_dtype /* GW_DTYPE_* of the slices */,
                        const float* relu_mask /* NULL, or [n_rows, 256]: out *= (relu_mask > 0) - ReLU backward fused into an
                                                   input-gradient product (backward pass; single fp32 slice) */,
+                       float* zero_rows /* NULL, or [n_rows, 256] filled with zeros on the side: the aggregate buffer of the
+                                           edge update that consumes these products (saves a fill launch; fp32) */,
                        void* stream);
 
 /* ---- EdgeProcessor.forward + scatter_sum (graph_net_block.py:131-137 and :188) --------------------------
