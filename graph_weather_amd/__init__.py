@@ -4,6 +4,7 @@ Mirrors the import surface of the reference for that path (``graph_weather/__ini
 ``graph_weather/models/__init__.py:13-15``): ``GraphWeatherForecaster``, ``Encoder``, ``Processor``, ``Decoder``,
 ``GraphProcessor``, ``MLP``, ``NormalizedMSELoss``.
 """
+from .analysis import AssimilatorEncoder, GraphWeatherAssimilator, GraphWeatherAssimilatorConfig  # noqa: F401
 from .forecast import GraphWeatherForecaster, GraphWeatherForecasterConfig  # noqa: F401
 from .layers import (  # noqa: F401
     MLP,

@@ -28,7 +28,7 @@ import torch
 
 from . import mesh as _mesh
 
-__all__ = ["GraphPlan", "ForecastGraphs", "build_forecast_graphs", "plan_from_coo"]
+__all__ = ["GraphPlan", "ForecastGraphs", "build_forecast_graphs", "plan_from_coo", "build_observation_graph", "build_latent_graph"]
 
 
 @dataclass
@@ -194,3 +194,34 @@ def build_forecast_graphs(lat_lons, resolution: int = 2, provider=None) -> Forec
         lat_plan=plan_from_coo(ls, ld, M, M, la),
         dec_plan=plan_from_coo(ds, dd - M, M, G, da),
     )
+
+
+
+def build_latent_graph(resolution: int = 2):
+    """Latent mesh graph alone (assimilator_encoder.py:221-242 = encoder.py:244-268): (edge_index [2, E] int64 in reference
+    order, edge_attr [E, 2], dst-sorted plan)."""
+    m = _mesh.get_mesh(resolution)
+    M = m.num
+    ptr, idx = m.disk1_csr()
+    src = np.repeat(np.arange(M, dtype=np.int64), np.diff(ptr))
+    dst = idx
+    d = _mesh.haversine_rads(m.lat[src], m.lon[src], m.lat[dst], m.lon[dst])
+    attr = _sincos(d)
+    return (torch.from_numpy(np.stack([src, dst]).astype(np.int64)), torch.from_numpy(attr), plan_from_coo(src, dst, M, M, attr))
+
+
+def build_observation_graph(lat_lon_heights, resolution: int = 2):
+    """Bipartite observation -> mesh graph of the assimilation encoder (assimilator_encoder.py:166-219): observation i is
+    connected to the cell that contains it, at row ``N + (M - 1 - rank(cell))`` of the [observations ; mesh] table;
+    edge attributes [sin d, cos d, height].  Returns (edge_index [2, N] int64 in reference order, edge_attr [N, 3],
+    dst-sorted plan over (observation rows, mesh rows))."""
+    llh = np.asarray(lat_lon_heights, dtype=np.float64).reshape(-1, 3)
+    m = _mesh.get_mesh(resolution)
+    N, M = llh.shape[0], m.num
+    cell = m.locate(llh[:, 0], llh[:, 1])
+    d = _mesh.haversine_rads(llh[:, 0], llh[:, 1], m.lat[cell], m.lon[cell])
+    attr = np.stack([np.sin(d), np.cos(d), llh[:, 2]], axis=1).astype(np.float32)
+    src = np.arange(N, dtype=np.int64)
+    dst_row = (M - 1 - cell).astype(np.int64)
+    edge_index = torch.from_numpy(np.stack([src, dst_row + N]).astype(np.int64))
+    return edge_index, torch.from_numpy(attr), plan_from_coo(src, dst_row, N, M, attr)

@@ -139,8 +139,14 @@ class PackedMLP:
             self.b_mid = torch.cat([pad(b) for b in biases[1:-1]])
         else:
             self.w_mid = self.b_mid = None
-        self.w_out = pack(weights[-1], 0, self.hidden)
-        self.b_out = pad(biases[-1])
+        w_last, b_last = weights[-1], biases[-1]
+        if self.n_out < 80:
+            # output heads run on a fixed 5-tile (80 row) kernel variant: pad the last Linear with zero rows so that the
+            # packed stream has the tile count that kernel walks (n_out itself still masks the stores)
+            w_last = torch.cat([w_last.detach().float(), w_last.new_zeros((80 - self.n_out, w_last.shape[1]), dtype=torch.float32)])
+            b_last = torch.cat([b_last.detach().float(), b_last.new_zeros(80 - self.n_out, dtype=torch.float32)])
+        self.w_out = pack(w_last, 0, self.hidden)
+        self.b_out = pad(b_last)
         self.gamma = pad(ln[0]) if ln is not None else None
         self.beta = pad(ln[1]) if ln is not None else None
 

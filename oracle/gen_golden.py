@@ -106,6 +106,28 @@ def mlp_case(ns):
         print("mlp", tag, tuple(y.shape))
 
 
+def assimilator_observations(n: int = 300, seed: int = 13):
+    """Observation positions (lat, lon, height) and features used by the assimilator golden case and its tests."""
+    rs = np.random.RandomState(seed)
+    llh = np.stack([rs.uniform(-89.0, 89.0, n), rs.uniform(0.0, 359.0, n), rs.random_sample(n)], axis=1).astype(np.float32)
+    feats = rs.standard_normal((1, n, 2)).astype(np.float32)
+    return torch.from_numpy(llh), torch.from_numpy(feats)
+
+
+def assimilator_case(ns):
+    """GraphWeatherAssimilator (analysis.py:52-150): 300 scattered observations -> analysis on the 10 degree grid."""
+    out_lat_lons = regular_lat_lons(10.0)
+    model = ns.GraphWeatherAssimilator(output_lat_lons=out_lat_lons, analysis_dim=24)
+    deterministic_fill_(model, seed=6)
+    model.eval()
+    llh, feats = assimilator_observations()
+    with torch.no_grad():
+        y = model(feats, llh)
+    np.savez_compressed(os.path.join(OUT, "assimilator_10deg.npz"), y=y.numpy(),
+                        obs_edge_index=model.encoder.create_input_graph(feats, llh).edge_index.numpy())
+    print("assimilator_10deg", tuple(y.shape), float(y.abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = load_reference()
@@ -114,6 +136,7 @@ def main():
     block_case(ns)
     forecaster_case(ns, 10.0, 2, "10deg_b2")
     forecaster_case(ns, 5.0, 1, "5deg_b1")
+    assimilator_case(ns)
 
 
 if __name__ == "__main__":

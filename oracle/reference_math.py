@@ -206,6 +206,27 @@ def forecaster_forward(p: Params, g: dict, features: Tensor, feature_dim: int = 
     return y
 
 
+def assimilator_forward(p: Params, g: dict, features: Tensor, analysis_dim: int) -> Tensor:
+    """``GraphWeatherAssimilator.forward`` - analysis.py:136-150: AssimilatorEncoder.forward (assimilator_encoder.py:119-164),
+    Processor, AssimilatorDecoder.forward.  ``g``: ``obs_edge_index`` [2, N] (targets N + (M-1-rank)), ``obs_edge_attr``
+    [N, 3], ``lat_edge_index``, ``lat_edge_attr``, ``dec_edge_index``, ``dec_edge_attr``, ``num_mesh``, ``num_grid``.
+    The encoder's mesh inputs are zeros (``h3_nodes`` is a plain zero tensor there, not a parameter, :80)."""
+    B, N, F = features.shape
+    M = g["num_mesh"]
+    feats = torch.cat([features, torch.zeros((B, M, F), dtype=features.dtype)], dim=1).reshape(B * (N + M), F)  # :139-143
+    out = mlp(p, "encoder.node_encoder", feats)  # :144
+    edge_attr = mlp(p, "encoder.edge_encoder", g["obs_edge_attr"]).repeat(B, 1)  # :145-147
+    edge_index = _replicate_index(g["obs_edge_index"], B, N + M)  # :149-152 (literal max+1 == N+M when the last cell is hit)
+    out, _ = graph_processor(p, "encoder.graph_processor", out, edge_index, edge_attr)  # :153
+    out = out.reshape(B, N + M, -1)[:, N:, :].reshape(B * M, -1)  # :155-157
+    lat_index = _replicate_index(g["lat_edge_index"], B, M)
+    lat_attr = mlp(p, "encoder.latent_edge_encoder", g["lat_edge_attr"].repeat(B, 1))  # :158-163
+    xp = processor_forward(p, out, lat_index, lat_attr)
+    # AssimilatorDecoder.forward (assimilator_decoder.py:145-200): as the forecaster's decoder without the residual add
+    zeros = torch.zeros((B, g["num_grid"], analysis_dim), dtype=features.dtype)
+    return decoder_forward(p, g, xp, zeros)
+
+
 # ----------------------------------------------------------------------------------------
 # losses.py
 # ----------------------------------------------------------------------------------------

@@ -142,6 +142,9 @@ def load_reference():
     _load("graph_weather.models.layers.constraint_layer", base + "layers/constraint_layer.py")
     models = sys.modules["graph_weather.models"]
     models.Encoder, models.Processor, models.Decoder = enc.Encoder, proc.Processor, dec.Decoder
+    aenc = _load("graph_weather.models.layers.assimilator_encoder", base + "layers/assimilator_encoder.py")
+    models.AssimilatorEncoder, models.AssimilatorDecoder = aenc.AssimilatorEncoder, adec.AssimilatorDecoder
+    ana = _load("graph_weather.models.analysis", base + "analysis.py")
     fc = _load("graph_weather.models.forecast", base + "forecast.py")
     losses = _load("graph_weather.models.losses", base + "losses.py")
     ns = types.SimpleNamespace(
@@ -149,6 +152,7 @@ def load_reference():
         NodeProcessor=gnb.NodeProcessor, Encoder=enc.Encoder, Processor=proc.Processor, Decoder=dec.Decoder,
         AssimilatorDecoder=adec.AssimilatorDecoder, GraphWeatherForecaster=fc.GraphWeatherForecaster,
         GraphWeatherForecasterConfig=fc.GraphWeatherForecasterConfig, NormalizedMSELoss=losses.NormalizedMSELoss,
+        AssimilatorEncoder=aenc.AssimilatorEncoder, GraphWeatherAssimilator=ana.GraphWeatherAssimilator,
     )
     # leave the stubs registered under their names only while the reference modules need them at call
     # time (h3 is used in __init__ of Encoder/Decoder) - they shadow nothing real in this image.

@@ -75,6 +75,19 @@ def test_mlp_ragged_row_counts(rows):
     _close(y, ref, what=f"mlp rows={rows}")
 
 
+@pytest.mark.parametrize("n_out,hidden", [(24, 128), (1, 128), (64, 256), (80, 128)])
+def test_mlp_small_output_heads(n_out, hidden):
+    """Heads narrower than 65 outputs need zero-padded packs (the head kernel walks 5 row tiles): analysis_dim=24 of the
+    assimilator test (tests/test_model.py:146), single-variable heads."""
+    m = gw.MLP(256, n_out, hidden, 2, None)
+    deterministic_fill_(m, seed=n_out)
+    x = torch.from_numpy(np.random.RandomState(n_out).standard_normal((333, 256)).astype(np.float32))
+    ref = om.mlp({"m." + k: v for k, v in m.state_dict().items()}, "m", x)
+    with torch.no_grad():
+        y = m.to(DEV)(x.to(DEV))
+    _close(y, ref, what=f"head 256->{n_out}")
+
+
 def test_mlp_more_hidden_layers():
     m = gw.MLP(64, 256, 256, 4, "LayerNorm")
     deterministic_fill_(m, seed=4)
@@ -368,3 +381,28 @@ def test_graphcast_wrapper_matches_oracle_and_rollout_runs():
     with torch.no_grad():
         y2 = model(outs[0])
     _close(outs[1], y2, rel=1e-5, what="rollout step 1 = model(model(x))")
+
+
+def test_assimilator_matches_reference_golden_and_oracle(golden_dir):
+    """GraphWeatherAssimilator (analysis.py:52-150): scattered observations -> analysis on a grid, against the golden
+    vector produced by the reference's own files and the oracle; pattern of tests/test_model.py:133-152."""
+    from .test_oracle import _assimilator_setup
+
+    gold = _golden(golden_dir, "assimilator_10deg.npz")
+    out_lat_lons, llh, feats, g = _assimilator_setup()
+    model = gw.GraphWeatherAssimilator(output_lat_lons=out_lat_lons, analysis_dim=24)
+    deterministic_fill_(model, seed=6)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y = model(feats.to(DEV), llh.to(DEV))
+        y_again = model(feats.to(DEV), llh.to(DEV))
+    assert y.shape == (1, 648, 24) and not torch.isnan(y).any()
+    _close(y, torch.from_numpy(gold["y"]), what="assimilator vs reference golden")
+    _close(y, om.assimilator_forward(p, g, feats, 24), what="assimilator vs oracle")
+    _close(y_again, y, rel=1e-6, what="cached observation graph")
+    # compositional API: encoder output in reference order feeds Processor / AssimilatorDecoder like analysis.py:147-149
+    with torch.no_grad():
+        x, ei, ea = model.encoder(feats.to(DEV), llh.to(DEV))
+        y2 = model.decoder(model.processor(x, ei, ea), 1)
+    _close(y2, y, rel=1e-5, what="compositional assimilator")

@@ -131,3 +131,34 @@ def test_oracle_matches_live_reference_small():
     assert set(p.keys()) == set(forecaster_param_shapes(graphs.num_mesh).keys())
     y = om.forecaster_forward(p, graphs.as_oracle_dict(), feats)
     assert torch.allclose(y, y_ref, rtol=1e-5, atol=1e-5)
+
+
+def _assimilator_setup():
+    """Shared by the oracle (CPU) and HIP (GPU) tests of GraphWeatherAssimilator: graphs, weights, inputs of the golden case."""
+    from graph_weather_amd.graphs import build_forecast_graphs, build_latent_graph, build_observation_graph
+    from oracle.gen_golden import assimilator_observations
+
+    out_lat_lons = regular_lat_lons(10.0)
+    llh, feats = assimilator_observations()
+    obs_ei, obs_attr, _ = build_observation_graph(llh.numpy(), 2)
+    lat_ei, lat_attr, _ = build_latent_graph(2)
+    fg = build_forecast_graphs(out_lat_lons, 2)
+    g = {"obs_edge_index": obs_ei, "obs_edge_attr": obs_attr, "lat_edge_index": lat_ei, "lat_edge_attr": lat_attr,
+         "dec_edge_index": fg.dec_edge_index, "dec_edge_attr": fg.dec_edge_attr, "num_mesh": fg.num_mesh, "num_grid": fg.num_grid}
+    return out_lat_lons, llh, feats, g
+
+
+def test_assimilator_matches_reference_golden(golden_dir):
+    """analysis.py:52-150 executed from the reference's own files (oracle/gen_golden.py: assimilator_case)."""
+    import graph_weather_amd as gw
+
+    gold = np.load(os.path.join(golden_dir, "assimilator_10deg.npz"))
+    out_lat_lons, llh, feats, g = _assimilator_setup()
+    assert np.array_equal(g["obs_edge_index"].numpy(), gold["obs_edge_index"])  # same graph as the reference built
+    model = gw.GraphWeatherAssimilator(output_lat_lons=out_lat_lons, analysis_dim=24)  # module mirror: same state_dict keys
+    deterministic_fill_(model, seed=6)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    y = om.assimilator_forward(p, g, feats, 24)
+    assert y.shape == (1, 648, 24)
+    err = (y - torch.from_numpy(gold["y"])).abs().max().item()
+    assert err < 2e-5, err
