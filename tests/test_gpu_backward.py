@@ -149,3 +149,18 @@ def test_forecaster_and_loss_like_the_reference_tests(irregular, checkpoint):
     assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_example_script_runs():
+    """examples/switch_from_reference.py: checkpoint round trip, two training steps with a decreasing loss, inference, rollout."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "switch_from_reference.py"), "--grid", "10", "--train-steps", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    losses = [float(l.split("loss")[1]) for l in out.stdout.splitlines() if l.startswith("train step")]
+    assert len(losses) == 3 and losses[-1] < losses[0], losses
+    assert "finite: True" in out.stdout and "rollout steps: 3" in out.stdout
