@@ -128,6 +128,22 @@ def assimilator_case(ns):
     print("assimilator_10deg", tuple(y.shape), float(y.abs().mean()))
 
 
+def graphcast_case(ns):
+    """GraphCast wrapper (graphcast/model.py:21-286), efficient_batching on and off must agree; 10 degree grid, B=2."""
+    lat_lons = regular_lat_lons(10.0)
+    feats = seeded_features(2, len(lat_lons), 78, seed=9)
+    ys = []
+    for eff in (False, True):
+        model = ns.GraphCast(lat_lons, efficient_batching=eff)
+        deterministic_fill_(model, seed=5)
+        model.eval()
+        with torch.no_grad():
+            ys.append(model(feats))
+    assert torch.allclose(ys[0], ys[1], atol=1e-4)
+    np.savez_compressed(os.path.join(OUT, "graphcast_10deg_b2.npz"), y=ys[0].numpy(), y_efficient=ys[1].numpy())
+    print("graphcast_10deg_b2", tuple(ys[0].shape), float((ys[0] - ys[1]).abs().max()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = load_reference()
@@ -137,6 +153,7 @@ def main():
     forecaster_case(ns, 10.0, 2, "10deg_b2")
     forecaster_case(ns, 5.0, 1, "5deg_b1")
     assimilator_case(ns)
+    graphcast_case(ns)
 
 
 if __name__ == "__main__":

@@ -145,6 +145,10 @@ def load_reference():
     aenc = _load("graph_weather.models.layers.assimilator_encoder", base + "layers/assimilator_encoder.py")
     models.AssimilatorEncoder, models.AssimilatorDecoder = aenc.AssimilatorEncoder, adec.AssimilatorDecoder
     ana = _load("graph_weather.models.analysis", base + "analysis.py")
+    gc_shell = types.ModuleType("graph_weather.models.graphcast")
+    gc_shell.__path__ = []
+    sys.modules["graph_weather.models.graphcast"] = gc_shell
+    gcast = _load("graph_weather.models.graphcast.model", base + "graphcast/model.py")
     fc = _load("graph_weather.models.forecast", base + "forecast.py")
     losses = _load("graph_weather.models.losses", base + "losses.py")
     ns = types.SimpleNamespace(
@@ -153,6 +157,7 @@ def load_reference():
         AssimilatorDecoder=adec.AssimilatorDecoder, GraphWeatherForecaster=fc.GraphWeatherForecaster,
         GraphWeatherForecasterConfig=fc.GraphWeatherForecasterConfig, NormalizedMSELoss=losses.NormalizedMSELoss,
         AssimilatorEncoder=aenc.AssimilatorEncoder, GraphWeatherAssimilator=ana.GraphWeatherAssimilator,
+        GraphCast=gcast.GraphCast, GraphCastConfig=getattr(gcast, "GraphCastConfig", None),
     )
     # leave the stubs registered under their names only while the reference modules need them at call
     # time (h3 is used in __init__ of Encoder/Decoder) - they shadow nothing real in this image.

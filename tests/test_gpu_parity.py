@@ -19,6 +19,7 @@ from .helpers import pack_linear_ref  # noqa: E402
 
 DEV = "cuda:0"
 REL = 2e-4
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _close(a: torch.Tensor, ref: torch.Tensor, rel=REL, what=""):
@@ -375,6 +376,8 @@ def test_graphcast_wrapper_matches_oracle_and_rollout_runs():
     with torch.no_grad():
         y = model(feats.to(DEV))
     _close(y.cpu() - feats, y_ref - feats, what="GraphCast delta")
+    gold = np.load(os.path.join(GOLDEN_DIR, "graphcast_10deg_b2.npz"))  # the reference's own GraphCast class
+    _close(y.cpu() - feats, torch.from_numpy(gold["y"]) - feats, what="GraphCast delta vs reference golden")
     outs = gw.rollout(model, feats.to(DEV), steps=3)
     assert len(outs) == 3 and all(torch.isfinite(o).all() for o in outs)
     _close(outs[0], y, rel=1e-6, what="rollout step 0")

@@ -162,3 +162,19 @@ def test_assimilator_matches_reference_golden(golden_dir):
     assert y.shape == (1, 648, 24)
     err = (y - torch.from_numpy(gold["y"])).abs().max().item()
     assert err < 2e-5, err
+
+
+def test_graphcast_wrapper_matches_reference_golden(golden_dir):
+    """graphcast/model.py executed from the reference's own files (efficient_batching on and off agree there to 0.0):
+    the oracle's forecaster composition with the input as residual reproduces it."""
+    import graph_weather_amd as gw
+
+    gold = np.load(os.path.join(golden_dir, "graphcast_10deg_b2.npz"))
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphCast(lat_lons, efficient_batching=True)  # module mirror: same state_dict keys as the reference class
+    deterministic_fill_(model, seed=5)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    feats = seeded_features(2, len(lat_lons), 78, seed=9)
+    y = om.forecaster_forward(p, model.encoder.graphs.as_oracle_dict(), feats, feature_dim=78)
+    assert (y - torch.from_numpy(gold["y"])).abs().max().item() < 2e-5
+    assert (y - torch.from_numpy(gold["y_efficient"])).abs().max().item() < 2e-5
