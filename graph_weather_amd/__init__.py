@@ -20,6 +20,12 @@ from .layers import (  # noqa: F401
 )
 from .graphcast import GraphCast, GraphCastConfig  # noqa: F401
 from .losses import NormalizedMSELoss  # noqa: F401
+from .regional import (  # noqa: F401
+    BoundaryNudgingLayer,
+    DynamicGraphBuilder,
+    RegionalForecaster,
+    RegionalForecasterConfig,
+)
 from .rollout import rollout  # noqa: F401
 from .optim import AdamW  # noqa: F401
 

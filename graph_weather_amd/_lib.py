@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 EXPORTS = [
@@ -23,7 +23,7 @@ EXPORTS = [
     "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector",
     "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_node_update_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
-    "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step",
+    "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step", "gw_nudging_forward", "gw_nudging_backward",
 ]
 
 GEMM_NN, GEMM_TN = 0, 1
@@ -109,7 +109,7 @@ def lib():
     L.gw_relu_backward.restype = c_int
     L.gw_relu_backward.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]
     L.gw_layernorm_backward.restype = c_int
-    L.gw_layernorm_backward.argtypes = [c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+    L.gw_layernorm_backward.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                         c_void_p, c_void_p]
     L.gw_gather_rows.restype = c_int
     L.gw_gather_rows.argtypes = [c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -121,6 +121,12 @@ def lib():
     L.gw_adamw_step.restype = c_int
     L.gw_adamw_step.argtypes = [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
                                 c_int32, c_void_p]
+    L.gw_nudging_forward.restype = c_int
+    L.gw_nudging_forward.argtypes = [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]
+    L.gw_nudging_backward.restype = c_int
+    L.gw_nudging_backward.argtypes = [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
     if L.gw_version() != ABI_VERSION:
         raise RuntimeError("graph_weather_amd: libgw_amd.so ABI version mismatch")
     _lib = L

@@ -66,7 +66,7 @@ class AssimilatorEncoder(nn.Module):
         key = (lat_lon_heights.data_ptr(), lat_lon_heights._version, tuple(lat_lon_heights.shape), str(device))
         if self._obs_cache is None or self._obs_cache[0] != key:
             _, _, plan = build_observation_graph(llh.detach().cpu().numpy(), self.resolution)
-            self._obs_cache = (key, plan.to(device))
+            self._obs_cache = (key, plan.to(device), lat_lon_heights)  # holds the tensor: its address stays taken
         return self._obs_cache[1]
 
     def _cached(self, name, params, fn):

@@ -59,8 +59,10 @@ def relu_backward(dh: torch.Tensor, h: Optional[torch.Tensor], db: Optional[torc
 
 
 def layernorm_backward(dn: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor) -> torch.Tensor:
-    dy = torch.empty_like(y)
-    _lib.check(_L().gw_layernorm_backward(int(y.shape[0]), dn.data_ptr(), int(dn.stride(0)), y.data_ptr(), int(y.stride(0)),
+    """``y``: saved pre-norm rows [rows, >= width] (heads are saved zero padded to 80 columns); width = gamma.numel()."""
+    width = int(gamma.numel())
+    dy = torch.empty((int(y.shape[0]), width), dtype=torch.float32, device=y.device)
+    _lib.check(_L().gw_layernorm_backward(int(y.shape[0]), width, dn.data_ptr(), int(dn.stride(0)), y.data_ptr(), int(y.stride(0)),
                                           gamma.data_ptr(), dy.data_ptr(), int(dy.stride(0)), dgamma.data_ptr(), dbeta.data_ptr(),
                                           _st(y)), "gw_layernorm_backward")
     return dy

@@ -403,7 +403,10 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
       for (int t = 0; t < OT; ++t) stg4(srow + 16 * t + 4 * q, o[t]);
     }
-    constexpr float inv_n = 1.0f / (OT * 16);
+    // heads (EPI_DEC) normalise over their n_out <= OT*16 real features: the padding rows of the last Linear are zero, so
+    // they drop out of the sum and are masked out of the variance
+    const int nfeat = (EPI == EPI_DEC) ? a.out_cols : OT * 16;
+    const float inv_n = (EPI == EPI_DEC) ? 1.0f / (float)nfeat : 1.0f / (OT * 16);
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < OT; ++t) s += (o[t].x + o[t].y) + (o[t].z + o[t].w);
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     for (int t = 0; t < OT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = o[t][r] - mean;
+        const float d = (EPI == EPI_DEC && 16 * t + 4 * q + r >= nfeat) ? 0.f : o[t][r] - mean;
         v += d * d;
       }
     v += __shfl_xor(v, 16);
@@ -736,6 +739,7 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
     if (w->n_out == 256 && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
     if (x->k == 256 && x->ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input ld must be a multiple of 4");
     if (x->k > 128 && x->k != 256) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=128 or ==256");
+    if (w->n_out != 256 && w->ln_gamma) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: LayerNorm on an output head is implemented for float32 weights only");
     return gw::chain16_launch(0, a, x->k, w->hidden, w->n_out, 1, stream);
   }
   if (w->hidden == 256 && w->n_out == 256) {
@@ -746,11 +750,11 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
     if (x->k == 256 && x->ld % 4 == 0) return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS>, a, stream);
     return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=112 or ==256 for hidden 256");
   }
-  if (w->hidden == 256 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
+  if (w->hidden == 256 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0) {
     // head with 256 hidden units (GraphCast wrapper: hidden_dim_decoder = hidden_dim, graphcast/model.py:100-114)
     return launch_chain(chain_kernel<64, true, 1, 16, 5, EPI_DEC>, a, stream);
   }
-  if (w->hidden == 128 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0 && !w->ln_gamma) {
+  if (w->hidden == 128 && w->n_out <= 80 && x->k == 256 && x->ld % 4 == 0) {
     return launch_chain(chain_kernel<64, true, 1, 8, 5, EPI_DEC>, a, stream);
   }
   return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: unsupported (hidden, n_out, k) combination");

@@ -353,6 +353,83 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int64_t rows, const float* 
   }
 }
 
+// LayerNorm backward for widths other than 256 (output heads: LayerNorm(n_out), regional_forecast.py:223-230): one wave per
+// row, lane l owns columns l, l+64, l+128, l+192 (scalar accesses: no alignment requirement on the row strides).
+__global__ __launch_bounds__(256) void ln_bwd_narrow_kernel(int64_t rows, int width, const float* __restrict__ dn, int ld_dn,
+                                                            const float* __restrict__ y, int ld_y, const float* __restrict__ gamma,
+                                                            float* __restrict__ dy, int ld_dy, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int strip) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * strip;
+  const int64_t r1 = r0 + strip < rows ? r0 + strip : rows;
+  const float inv_n = 1.0f / (float)width;
+  float gm[4], dg[4], dbt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = lane + 64 * j;
+    gm[j] = c < width ? gamma[c] : 0.f;
+    dg[j] = dbt[j] = 0.f;
+  }
+  for (int64_t r = r0 + wave; r < r1; r += 4) {
+    float yv[4], dv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      yv[j] = c < width ? y[r * ld_y + c] : 0.f;
+      dv[j] = c < width ? dn[r * ld_dn + c] : 0.f;
+      s += yv[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * inv_n;
+    float d[4], v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      d[j] = (lane + 64 * j < width) ? yv[j] - mean : 0.f;
+      v += d[j] * d[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
+    float xh[4], g[4], sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = d[j] * rstd;
+      g[j] = dv[j] * gm[j];
+      sg += g[j];
+      sgx += g[j] * xh[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sg += __shfl_xor(sg, off);
+      sgx += __shfl_xor(sgx, off);
+    }
+    const float mg = sg * inv_n, mgx = sgx * inv_n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = lane + 64 * j;
+      if (c < width) dy[r * ld_dy + c] = (g[j] - mg - xh[j] * mgx) * rstd;
+      dg[j] += dv[j] * xh[j];
+      dbt[j] += dv[j];
+    }
+  }
+  __shared__ float red[2][4][256];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][wave][lane + 64 * j] = dg[j];
+    red[1][wave][lane + 64 * j] = dbt[j];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < width) {
+    const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    if (dgamma) __hip_atomic_fetch_add(dgamma + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dbeta) __hip_atomic_fetch_add(dbeta + c, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- gather / segment sum of 256-float rows --------------------------------------------------------------------------
 // out[b * n_idx + k] = table[(b * rows_pb + idx[k])] (+ add[b * n_idx + k]);  one wave per output row
 __global__ __launch_bounds__(256) void gather_rows_kernel(int batch, int n_idx, const float* __restrict__ table, int rows_pb,
@@ -452,6 +529,94 @@ __global__ void adamw_kernel(size_t n, float* __restrict__ p, const float* __res
 
 int fail(int code, const char* msg) { return set_error(code, msg); }
 
+// ---- boundary nudging (regional_forecast.py:44-132) -------------------------------------------------------------------
+// alpha = clamp(prior + W2.relu(W1.[regional | context | prior] + b1) + b2, 0, 1); out = (1 - alpha) regional + alpha context.
+// One wave per row; lane l owns hidden units l, l+64, l+128, l+192 (hidden <= 256) and feature columns l, l+64, ...
+__device__ __forceinline__ float nudging_alpha_raw(const float* __restrict__ x, int kin, int h, const float* __restrict__ w1t,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2,
+                                                   const float* __restrict__ b2, int lane, float (&z)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) z[j] = (lane + 64 * j < h) ? b1[lane + 64 * j] : 0.f;
+  for (int i = 0; i < kin; ++i) {
+    const float xi = x[i];  // same address in every lane: one broadcast load
+    const float* wrow = w1t + (size_t)i * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < h) z[j] = fmaf(wrow[lane + 64 * j], xi, z[j]);
+  }
+  float corr = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lane + 64 * j < h) corr = fmaf(w2[lane + 64 * j], fmaxf(z[j], 0.f), corr);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) corr += __shfl_xor(corr, off);
+  return x[kin - 1] + (corr + b2[0]);
+}
+
+__global__ __launch_bounds__(256) void nudging_fwd_kernel(int64_t rows, int f, int h, const float* __restrict__ in, int ld_in,
+                                                          const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;  // no barrier below
+  const float* x = in + row * ld_in;
+  float z[4];
+  const float raw = nudging_alpha_raw(x, 2 * f + 1, h, w1t, b1, w2, b2, lane, z);
+  const float alpha = fminf(fmaxf(raw, 0.f), 1.f);
+  for (int c = lane; c < f; c += 64) out[row * f + c] = (1.f - alpha) * x[c] + alpha * x[f + c];
+}
+
+// writes d_in[:, 0:f] (gradient of the regional columns), dz = gradient at the hidden pre-activations, hid = relu(hidden),
+// dcorr = gradient at the MLP output; the weight gradients are dz^T.in and dcorr^T.hid (gw_gemm_f32 TN).
+__global__ __launch_bounds__(256) void nudging_bwd_kernel(int64_t rows, int f, int h, const float* __restrict__ in, int ld_in,
+                                                          const float* __restrict__ w1, const float* __restrict__ w1t,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, const float* __restrict__ dout,
+                                                          float* __restrict__ d_in, int ld_din, float* __restrict__ dz,
+                                                          float* __restrict__ hid, float* __restrict__ dcorr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;  // whole waves leave together: the shuffles below always see 64 active lanes
+  const int kin = 2 * f + 1;
+  const float* x = in + row * ld_in;
+  float z[4];
+  const float raw = nudging_alpha_raw(x, kin, h, w1t, b1, w2, b2, lane, z);
+  const float alpha = fminf(fmaxf(raw, 0.f), 1.f);
+  float da = 0.f;
+  for (int c = lane; c < f; c += 64) da = fmaf(dout[row * f + c], x[f + c] - x[c], da);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) da += __shfl_xor(da, off);
+  const float dc = (raw >= 0.f && raw <= 1.f) ? da : 0.f;  // clamp passes the gradient on [min, max] (ATen clamp_backward)
+  if (lane == 0) dcorr[row] = dc;
+  float dzj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int hj = lane + 64 * j;
+    dzj[j] = 0.f;
+    if (hj < h) {
+      dzj[j] = z[j] > 0.f ? dc * w2[hj] : 0.f;
+      hid[row * h + hj] = fmaxf(z[j], 0.f);
+      dz[row * h + hj] = dzj[j];
+    }
+  }
+  for (int c0 = 0; c0 < f; c0 += 64) {  // uniform trip count: every lane takes part in the shuffles
+    const int c = c0 + lane;
+    const bool ok = c < f;
+    float g = ok ? (1.f - alpha) * dout[row * f + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (64 * j >= h) break;
+      const int lim = h - 64 * j < 64 ? h - 64 * j : 64;
+      for (int l = 0; l < lim; ++l) {
+        const float dzv = __shfl(dzj[j], l);
+        if (ok) g = fmaf(dzv, w1[(size_t)(64 * j + l) * kin + c], g);
+      }
+    }
+    if (ok) d_in[row * ld_din + c] = g;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -495,15 +660,21 @@ int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh
   return check_launch("relu_bwd_kernel launch");
 }
 
-int gw_layernorm_backward(int64_t rows, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y, const float* gamma,
-                          float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream) {
-  if (!dn || !y || !gamma || !dy || rows < 0 || (ld_dn | ld_y | ld_dy) % 4 != 0)
-    return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments (width 256, strides multiple of 4)");
+int gw_layernorm_backward(int64_t rows, int32_t width, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y,
+                          const float* gamma, float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream) {
+  if (!dn || !y || !gamma || !dy || rows < 0 || width <= 0 || width > 256 || ld_dn < width || ld_y < width || ld_dy < width)
+    return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments (width 1..256)");
   if (rows == 0) return GW_OK;
   const int strip = 512;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, dn, ld_dn,
-                     y, ld_y, gamma, dy, ld_dy, dgamma, dbeta, strip);
-  return check_launch("ln_bwd_kernel launch");
+  const dim3 grid((unsigned)((rows + strip - 1) / strip));
+  if (width == 256 && (ld_dn | ld_y | ld_dy) % 4 == 0) {
+    hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, dn, ld_dn, y, ld_y, gamma, dy, ld_dy, dgamma,
+                       dbeta, strip);
+    return check_launch("ln_bwd_kernel launch");
+  }
+  hipLaunchKernelGGL(ln_bwd_narrow_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, width, dn, ld_dn, y, ld_y, gamma, dy, ld_dy,
+                     dgamma, dbeta, strip);
+  return check_launch("ln_bwd_narrow_kernel launch");
 }
 
 int gw_gather_rows(int32_t batch, int32_t n_idx, const float* table, int32_t rows_per_batch, const int32_t* idx,
@@ -563,6 +734,29 @@ int gw_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (size_t)n, param, grad, exp_avg, exp_avg_sq, lr,
                      beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
   return check_launch("adamw_kernel launch");
+}
+
+int gw_nudging_forward(int64_t rows, int32_t feat, int32_t hidden, const float* in, int32_t ld_in, const float* w1t, const float* b1,
+                       const float* w2, const float* b2, float* out, void* stream) {
+  if (!in || !w1t || !b1 || !w2 || !b2 || !out || rows < 0 || feat <= 0 || feat > 256 || hidden <= 0 || hidden > 256 ||
+      ld_in < 2 * feat + 1)
+    return fail(GW_E_BADARG, "gw_nudging_forward: bad arguments (feat, hidden in 1..256; ld_in >= 2 feat + 1)");
+  if (rows == 0) return GW_OK;
+  hipLaunchKernelGGL(nudging_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, feat, hidden, in,
+                     ld_in, w1t, b1, w2, b2, out);
+  return check_launch("nudging_fwd_kernel launch");
+}
+
+int gw_nudging_backward(int64_t rows, int32_t feat, int32_t hidden, const float* in, int32_t ld_in, const float* w1, const float* w1t,
+                        const float* b1, const float* w2, const float* b2, const float* dout, float* d_in, int32_t ld_din, float* dz,
+                        float* hid, float* dcorr, void* stream) {
+  if (!in || !w1 || !w1t || !b1 || !w2 || !b2 || !dout || !d_in || !dz || !hid || !dcorr || rows < 0 || feat <= 0 || feat > 256 ||
+      hidden <= 0 || hidden > 256 || ld_in < 2 * feat + 1 || ld_din < feat)
+    return fail(GW_E_BADARG, "gw_nudging_backward: bad arguments");
+  if (rows == 0) return GW_OK;
+  hipLaunchKernelGGL(nudging_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, feat, hidden, in,
+                     ld_in, w1, w1t, b1, w2, b2, dout, d_in, ld_din, dz, hid, dcorr);
+  return check_launch("nudging_bwd_kernel launch");
 }
 
 }  // extern "C"

@@ -254,7 +254,7 @@ class GraphProcessor(nn.Module):
                     key = (e_cur.data_ptr(), e_cur._version, blk.params_key())
                     if self._e0_cache is None or self._e0_cache[0] != key:
                         pe = ops.project_forward([mlp_e.packed().w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
-                        self._e0_cache = (key, pe)
+                        self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
                     pe = self._e0_cache[1]
                 e_in = Feed(pe, 0, "proj")
             else:
@@ -277,7 +277,7 @@ class GraphProcessor(nn.Module):
         dst_sorted, perm = torch.sort(edge_index[1], stable=True)
         plan = GraphPlan(num_nodes, num_nodes, edge_index[0][perm].to(torch.int32).contiguous(),
                          dst_sorted.to(torch.int32).contiguous(), perm, None)
-        self._plan_cache = (key, plan)
+        self._plan_cache = (key, plan, edge_index)  # holds edge_index: its address cannot be reused while the entry lives
         return plan
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -82,7 +82,9 @@ class SavedActivations:
 
     def __init__(self, pm: "PackedMLP", n_rows: int, device):
         self.hidden = torch.empty((pm.n_mid + 1, n_rows, pm.hidden), dtype=torch.float32, device=device)
-        self.pre_norm = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=device) if pm.gamma is not None else None
+        # heads (n_out <= 80) are saved as zero-padded 80-column rows (the 5-tile kernel variant stores whole tiles)
+        width = pm.n_out if pm.n_out == 256 else 80
+        self.pre_norm = torch.empty((n_rows, width), dtype=torch.float32, device=device) if pm.gamma is not None else None
 
     def c(self) -> GwActivationSave:
         return GwActivationSave(self.hidden.data_ptr(), int(self.hidden.stride(0)), int(self.hidden.stride(1)),
@@ -147,8 +149,12 @@ class PackedMLP:
             b_last = torch.cat([b_last.detach().float(), b_last.new_zeros(80 - self.n_out, dtype=torch.float32)])
         self.w_out = pack(w_last, 0, self.hidden)
         self.b_out = pad(b_last)
-        self.gamma = pad(ln[0]) if ln is not None else None
-        self.beta = pad(ln[1]) if ln is not None else None
+        def pad_head(v):  # LayerNorm on a head: the kernel reads affine parameters for all 80 rows of its 5 tiles
+            v = v.detach().float()
+            return torch.cat([v, v.new_zeros(80 - self.n_out)]) if self.n_out < 80 else v
+
+        self.gamma = pad(pad_head(ln[0])) if ln is not None else None
+        self.beta = pad(pad_head(ln[1])) if ln is not None else None
 
     def c(self, active: Sequence[bool] = (True, True, True)) -> GwMlpWeights:
         w = GwMlpWeights()

@@ -47,3 +47,12 @@ def regular_lat_lons(step: float):
     lats = np.arange(-90.0, 90.0, step)
     lons = np.arange(0.0, 360.0, step)
     return [(float(lat), float(lon)) for lat in lats for lon in lons]
+
+
+def validate_lat_lons(lat_lons) -> None:
+    """``graph_weather/utils.py:6-13``: non-empty sequence of (lat, lon) with latitudes in [-90, 90]."""
+    if lat_lons is None or len(lat_lons) == 0:
+        raise ValueError("lat_lons must not be empty.")
+    for index, (lat, _lon) in enumerate(lat_lons):
+        if not (-90.0 <= lat <= 90.0):
+            raise ValueError(f"Coordinate {index}: latitude {lat} is outside [-90, 90].")

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 6
+#define GW_ABI_VERSION 7
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -154,7 +154,7 @@ typedef struct gw_activation_save {
   float* hidden;        /* [(n_mid + 1), n_rows, hidden_ld] */
   int64_t hidden_stride; /* floats between consecutive hidden layers */
   int32_t hidden_ld;
-  float* pre_norm;      /* [n_rows, 256] or NULL */
+  float* pre_norm;      /* [n_rows, 256] ([n_rows, 80] for an output head with n_out <= 80, zero padded) or NULL */
 } gw_activation_save;
 
 #define GW_GEMM_NN 0 /* C[m][n]  = sum_k A[m][k] * B[k][n]   (input gradients:  dX = dZ . W)                         */
@@ -166,9 +166,10 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
  * dz may alias dh or be NULL (bias gradient only); db may be NULL. width <= 256. */
 int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
                      int32_t ld_dz, float* db, void* stream);
-/* nn.LayerNorm(256, eps 1e-5) backward from the saved pre-norm rows y: dy; dgamma += , dbeta += (may be NULL). */
-int gw_layernorm_backward(int64_t rows, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y, const float* gamma,
-                          float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream);
+/* nn.LayerNorm(width, eps 1e-5) backward from the saved pre-norm rows y: dy; dgamma += , dbeta += (may be NULL).
+ * width 1..256 (256: the message-passing MLPs; other widths: LayerNorm on an output head, regional_forecast.py:223-230). */
+int gw_layernorm_backward(int64_t rows, int32_t width, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y,
+                          const float* gamma, float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream);
 /* Dual of the segment sum (graph_net_block.py:188): out[b, k, :] = table[b, idx[k], :] (+ add[b, k, :]); 256-float rows;
  * idx NULL = identity; rows_per_batch 0 = table shared by the batch. */
 int gw_gather_rows(int32_t batch, int32_t n_idx, const float* table, int32_t rows_per_batch, const int32_t* idx,
@@ -186,6 +187,19 @@ int gw_normalized_mse_backward(const float* pred, const float* target, const flo
 /* torch.optim.AdamW step (decoupled weight decay, bias correction with `step` >= 1) on a flat fp32 buffer. */
 int gw_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* BoundaryNudgingLayer (regional_forecast.py:44-132) on rows of in = [regional (feat) | global context (feat) | prior (1)]:
+ * alpha = clamp(prior + w2 . relu(W1 . in + b1) + b2, 0, 1); out = (1 - alpha) regional + alpha context.
+ * w1t = W1^T ([2 feat + 1, hidden] row-major), w2 [hidden], b2 [1]; feat, hidden <= 256. */
+int gw_nudging_forward(int64_t rows, int32_t feat, int32_t hidden, const float* in, int32_t ld_in, const float* w1t, const float* b1,
+                       const float* w2, const float* b2, float* out, void* stream);
+/* Its backward for dout [rows, feat]: d_in[:, 0:feat] = gradient of the regional columns (other columns untouched),
+ * dz [rows, hidden] = gradient at the hidden pre-activations, hid [rows, hidden] = relu(hidden), dcorr [rows] = gradient at the
+ * MLP output; the parameter gradients are then dW1 += dz^T in, db1 += colsum dz, dw2 += dcorr^T hid, db2 += sum dcorr
+ * (gw_gemm_f32 TN).  w1 = W1 ([hidden, 2 feat + 1] row-major). */
+int gw_nudging_backward(int64_t rows, int32_t feat, int32_t hidden, const float* in, int32_t ld_in, const float* w1, const float* w1t,
+                        const float* b1, const float* w2, const float* b2, const float* dout, float* d_in, int32_t ld_din, float* dz,
+                        float* hid, float* dcorr, void* stream);
 
 #ifdef __cplusplus
 }

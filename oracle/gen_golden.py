@@ -144,6 +144,31 @@ def graphcast_case(ns):
     print("graphcast_10deg_b2", tuple(ys[0].shape), float((ys[0] - ys[1]).abs().max()))
 
 
+def regional_inputs(batch: int = 2, seed: int = 21):
+    """Coordinates (0.5 degree patch over western Europe), features and global context of the regional golden case."""
+    lat_lons = [(float(lat), float(lon)) for lat in np.arange(44.0, 56.0, 0.5) for lon in np.arange(-8.0, 8.0, 0.5)]
+    rs = np.random.RandomState(seed)
+    feats = rs.standard_normal((batch, len(lat_lons), 102)).astype(np.float32)
+    ctx = rs.standard_normal((batch, len(lat_lons), 78)).astype(np.float32)
+    return lat_lons, torch.from_numpy(feats), torch.from_numpy(ctx)
+
+
+def regional_case(ns):
+    """RegionalForecaster (regional_forecast.py:135-298) with default widths, with and without boundary nudging."""
+    lat_lons, feats, ctx = regional_inputs()
+    model = ns.RegionalForecasterConfig(enable_nudging=True).build()
+    deterministic_fill_(model, seed=8)
+    model.eval()
+    with torch.no_grad():
+        y = model(feats, lat_lons)
+        y_nudged = model(feats, lat_lons, global_context=ctx)
+    enc, dec, lat, h3_idx = model.graph_builder(lat_lons)
+    np.savez_compressed(os.path.join(OUT, "regional_eu_b2.npz"), y=y.numpy(), y_nudged=y_nudged.numpy(),
+                        enc_edge_index=enc.edge_index.numpy(), lat_edge_index=lat.edge_index.numpy(),
+                        dec_edge_index=dec.edge_index.numpy(), h3_indices=np.asarray(h3_idx))
+    print("regional_eu_b2", tuple(y.shape), float(y.abs().mean()), float((y - y_nudged).abs().mean()), len(h3_idx))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = load_reference()
@@ -154,6 +179,7 @@ def main():
     forecaster_case(ns, 5.0, 1, "5deg_b1")
     assimilator_case(ns)
     graphcast_case(ns)
+    regional_case(ns)
 
 
 if __name__ == "__main__":

@@ -227,6 +227,45 @@ def assimilator_forward(p: Params, g: dict, features: Tensor, analysis_dim: int)
     return decoder_forward(p, g, xp, zeros)
 
 
+def nudging_weights(lat_lons) -> Tensor:
+    """``BoundaryNudgingLayer._compute_relaxation_weights`` - regional_forecast.py:92-132 ([N, 1], float32 arithmetic)."""
+    lats = torch.tensor([ll[0] for ll in lat_lons], dtype=torch.float32) * (np.pi / 180.0)
+    lons = torch.tensor([ll[1] for ll in lat_lons], dtype=torch.float32) * (np.pi / 180.0)
+    c_lat, c_lon = lats.mean(), lons.mean()
+    a = torch.sin((lats - c_lat) / 2) ** 2 + torch.cos(lats) * torch.cos(c_lat) * torch.sin((lons - c_lon) / 2) ** 2
+    dist = 2 * torch.asin(torch.sqrt(torch.clamp(a, 0.0, 1.0)))
+    top = dist.max()
+    return (dist / top if top > 0 else torch.zeros_like(dist)).unsqueeze(-1)
+
+
+def regional_forward(p: Params, g: dict, features: Tensor, output_dim: int, global_context: Optional[Tensor] = None,
+                     lat_lons=None) -> Tensor:
+    """``RegionalForecaster.forward`` - regional_forecast.py:234-298.  ``g``: ``enc_edge_index`` [2, N] (coordinate i ->
+    row N + index of its cell among the region's sorted unique cells), ``enc_edge_attr`` [N, 2], ``lat_edge_index`` /
+    ``lat_edge_attr`` between those cells, ``h3_indices`` (rows of ``h3_embeddings``) - dynamic_graph_builder.py:41-130."""
+    B, N, _ = features.shape
+    regional_h3 = p["h3_embeddings"][torch.as_tensor(g["h3_indices"], dtype=torch.long)]  # :256
+    enc_e = mlp(p, "edge_encoder", g["enc_edge_attr"])  # :258
+    lat_e = mlp(p, "latent_edge_encoder", g["lat_edge_attr"])  # :259
+    dec_index = g["enc_edge_index"].flip(0)  # :261 reversed encoder edges
+    dec_e = mlp(p, "decoder_edge_encoder", g["enc_edge_attr"])  # :262
+    outs = []
+    for i in range(B):  # :264-281
+        nodes = mlp(p, "node_encoder", torch.cat([features[i], regional_h3], dim=0))
+        nodes, _ = graph_processor(p, "encoder_gnn", nodes, g["enc_edge_index"], enc_e)
+        h3f = processor_forward(p, nodes[N:], g["lat_edge_index"], lat_e)
+        dec_nodes = torch.cat([torch.zeros((N, h3f.shape[1]), dtype=features.dtype), h3f], dim=0)
+        dec_nodes, _ = graph_processor(p, "decoder_gnn", dec_nodes, dec_index, dec_e)
+        outs.append(mlp(p, "node_decoder", dec_nodes[:N]))
+    out = torch.stack(outs, dim=0) + features[..., :output_dim]  # :283-284
+    if global_context is not None and "nudging.blend_mlp.model.0.weight" in p:  # :287-289, :85-90
+        prior = nudging_weights(lat_lons).to(features.dtype).unsqueeze(0).expand(B, -1, -1)
+        corr = mlp(p, "nudging.blend_mlp", torch.cat([out, global_context, prior], dim=-1))
+        alpha = torch.clamp(prior + corr, 0.0, 1.0)
+        out = (1 - alpha) * out + alpha * global_context
+    return out
+
+
 # ----------------------------------------------------------------------------------------
 # losses.py
 # ----------------------------------------------------------------------------------------

@@ -149,6 +149,9 @@ def load_reference():
     gc_shell.__path__ = []
     sys.modules["graph_weather.models.graphcast"] = gc_shell
     gcast = _load("graph_weather.models.graphcast.model", base + "graphcast/model.py")
+    sys.modules["graph_weather.utils"] = _load("graph_weather.utils", "graph_weather/utils.py")
+    dgb = _load("graph_weather.models.layers.dynamic_graph_builder", base + "layers/dynamic_graph_builder.py")
+    reg = _load("graph_weather.models.regional_forecast", base + "regional_forecast.py")
     fc = _load("graph_weather.models.forecast", base + "forecast.py")
     losses = _load("graph_weather.models.losses", base + "losses.py")
     ns = types.SimpleNamespace(
@@ -158,6 +161,8 @@ def load_reference():
         GraphWeatherForecasterConfig=fc.GraphWeatherForecasterConfig, NormalizedMSELoss=losses.NormalizedMSELoss,
         AssimilatorEncoder=aenc.AssimilatorEncoder, GraphWeatherAssimilator=ana.GraphWeatherAssimilator,
         GraphCast=gcast.GraphCast, GraphCastConfig=getattr(gcast, "GraphCastConfig", None),
+        DynamicGraphBuilder=dgb.DynamicGraphBuilder, RegionalForecaster=reg.RegionalForecaster,
+        RegionalForecasterConfig=reg.RegionalForecasterConfig, BoundaryNudgingLayer=reg.BoundaryNudgingLayer,
     )
     # leave the stubs registered under their names only while the reference modules need them at call
     # time (h3 is used in __init__ of Encoder/Decoder) - they shadow nothing real in this image.

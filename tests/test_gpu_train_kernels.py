@@ -83,7 +83,7 @@ def test_layernorm_backward():
     dy = torch.empty(rows, 256, device=DEV)
     dg = torch.zeros(256, device=DEV)
     dbt = torch.zeros(256, device=DEV)
-    _lib.check(L.gw_layernorm_backward(rows, dnd.data_ptr(), 256, yd.data_ptr(), 256, gd.data_ptr(), dy.data_ptr(), 256,
+    _lib.check(L.gw_layernorm_backward(rows, 256, dnd.data_ptr(), 256, yd.data_ptr(), 256, gd.data_ptr(), dy.data_ptr(), 256,
                                        dg.data_ptr(), dbt.data_ptr(), _st()), "ln")
     assert _rel(dy, y.grad) < 1e-5
     assert _rel(dg, gamma.grad) < 1e-5
