@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 EXPORTS = [
@@ -37,7 +37,7 @@ class GwOperand(Structure):
 class GwMlpWeights(Structure):
     _fields_ = [("w1", c_void_p * 3), ("b1", c_void_p), ("w_mid", c_void_p), ("b_mid", c_void_p), ("w_out", c_void_p),
                 ("b_out", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("hidden", c_int32),
-                ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32)]
+                ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32), ("ln_width", c_int32)]
 
 
 class GwActivationSave(Structure):

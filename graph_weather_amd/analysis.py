@@ -41,12 +41,13 @@ class AssimilatorEncoder(nn.Module):
         self.num_h3 = self._lat_plan.n_dst
         # assimilator_encoder.py:80: a plain zero tensor, neither a parameter nor a buffer (so not in the state_dict)
         self.h3_nodes = torch.zeros((self.num_h3, input_dim), dtype=torch.float)
+        self.output_edge_dim = output_edge_dim
         self.node_encoder = MLP(input_dim, output_dim, hidden_dim_processor_node, hidden_layers_processor_node, mlp_norm_type,
-                                use_checkpointing)
+                                use_checkpointing).as_table()
         self.edge_encoder = MLP(3, output_edge_dim, hidden_dim_processor_edge, hidden_layers_processor_edge, mlp_norm_type,
-                                use_checkpointing)  # [sin d, cos d, height]
+                                use_checkpointing).as_table()  # [sin d, cos d, height]
         self.latent_edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, hidden_layers_processor_edge,
-                                       mlp_norm_type, use_checkpointing)
+                                       mlp_norm_type, use_checkpointing).as_table()
         self.graph_processor = GraphProcessor(1, output_dim, output_edge_dim, hidden_dim_processor_node,
                                               hidden_dim_processor_edge, hidden_layers_processor_node,
                                               hidden_layers_processor_edge, mlp_norm_type)
@@ -79,7 +80,7 @@ class AssimilatorEncoder(nn.Module):
         return self._cache[name][1]
 
     def latent_edge_embedding(self, plan) -> torch.Tensor:
-        return self._cached("lat_e", list(self.latent_edge_encoder.parameters()), lambda: self.latent_edge_encoder(plan.edge_attr))
+        return self._cached("lat_e", list(self.latent_edge_encoder.parameters()), lambda: self.latent_edge_encoder.table(plan.edge_attr))
 
     def encode(self, features: torch.Tensor, lat_lon_heights: torch.Tensor) -> torch.Tensor:
         """assimilator_encoder.py:137-157 -> mesh node features [(B*M), D] (reversed-rank order)."""
@@ -92,10 +93,10 @@ class AssimilatorEncoder(nn.Module):
             raise RuntimeError("features and lat_lon_heights disagree on the number of observations")
         _check_native_dims(*self.graph_processor._dims)
         feats = features.contiguous().reshape(B * N, F)
-        xo = self.node_encoder(feats)  # observation rows
+        xo = self.node_encoder.table(feats)  # observation rows
         zeros_in = self.h3_nodes.to(dev)
-        xm = self._cached("mesh", list(self.node_encoder.parameters()), lambda: self.node_encoder(zeros_in))
-        e = self.edge_encoder(plan.edge_attr)  # depends on the observation positions: not cached across graphs
+        xm = self._cached("mesh", list(self.node_encoder.parameters()), lambda: self.node_encoder.table(zeros_in))
+        e = self.edge_encoder.table(plan.edge_attr)  # depends on the observation positions: not cached across graphs
         blk = self.graph_processor.blocks[0]
         train = _autograd_on(self)
         M = self.num_h3
@@ -123,6 +124,10 @@ class AssimilatorEncoder(nn.Module):
         e_sorted = self.latent_edge_embedding(plan)
         e_ref = torch.empty_like(e_sorted)
         e_ref[plan.perm] = e_sorted
+        if self.output_dim != 256:
+            x = x[:, :self.output_dim]
+        if self.output_edge_dim != 256:
+            e_ref = e_ref[:, :self.output_edge_dim]
         ei = self.lat_edge_index.to(features.device)
         M = self.num_h3
         return x, torch.cat([ei + i * M for i in range(B)], dim=1), e_ref.repeat(B, 1)

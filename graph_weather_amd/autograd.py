@@ -58,10 +58,15 @@ def relu_backward(dh: torch.Tensor, h: Optional[torch.Tensor], db: Optional[torc
     return dh
 
 
-def layernorm_backward(dn: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor) -> torch.Tensor:
-    """``y``: saved pre-norm rows [rows, >= width] (heads are saved zero padded to 80 columns); width = gamma.numel()."""
-    width = int(gamma.numel())
-    dy = torch.empty((int(y.shape[0]), width), dtype=torch.float32, device=y.device)
+def layernorm_backward(dn: torch.Tensor, y: torch.Tensor, gamma: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                       width: int = 0) -> torch.Tensor:
+    """``y``: saved pre-norm rows [rows, >= width] (heads are saved zero padded to 80 columns).  ``width`` = features the
+    LayerNorm spans (default: ``gamma.numel()``); for zero-padded narrow models gamma / dn / the result are 256 wide and
+    only the first ``width`` columns carry values (the rest of dy is zero)."""
+    cols = int(gamma.numel())
+    width = cols if width <= 0 else width
+    alloc = torch.empty if width == cols else torch.zeros
+    dy = alloc((int(y.shape[0]), cols), dtype=torch.float32, device=y.device)
     _lib.check(_L().gw_layernorm_backward(int(y.shape[0]), width, dn.data_ptr(), int(dn.stride(0)), y.data_ptr(), int(y.stride(0)),
                                           gamma.data_ptr(), dy.data_ptr(), int(dy.stride(0)), dgamma.data_ptr(), dbeta.data_ptr(),
                                           _st(y)), "gw_layernorm_backward")
@@ -84,15 +89,14 @@ def segment_sum_rows(rows: torch.Tensor, rows_pb_in: int, batch: int, batch_out:
     return out
 
 
-def _packed_transposed(mlp, layer: int, lo: int, hi: int):
-    """Packed stream of W[:, lo:hi]^T of Linear ``layer`` (cached per weight version) for the fast input-gradient
-    product d @ W[:, lo:hi] through the forward's single-layer kernel; only for 256 x 256 blocks, else None."""
-    W = [m for m in mlp.model if isinstance(m, torch.nn.Linear)][layer].weight
+def _packed_transposed(mlp, layer: int, W: torch.Tensor, lo: int, hi: int):
+    """Packed stream of W[:, lo:hi]^T of (kernel-shaped) Linear ``layer`` (cached per weight version) for the fast
+    input-gradient product d @ W[:, lo:hi] through the forward's single-layer kernel; only for 256 x 256 blocks, else None."""
     if W.shape[0] != 256 or hi - lo != 256:
         return None
     cache = mlp.__dict__.setdefault("_packed_t", {})
     key = (layer, lo, hi)
-    ver = (W.data_ptr(), W._version)
+    ver = mlp.native_key()  # versions of the parameters W was derived from (W itself may be a fresh zero-padded copy)
     hit = cache.get(key)
     if hit is None or hit[0] != ver:
         Wt = W.detach()[:, lo:hi].t().contiguous()  # [256 (k), 256 (f)]: "Linear" that maps gradients back
@@ -107,7 +111,7 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
                relu_of: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(d @ W[:, lo:hi]) [* (relu_of > 0)]  ([rows, hi-lo]): fused single-layer kernel for 256 x 256 blocks (the ReLU
     backward rides in its epilogue), generic GEMM + mask kernel otherwise."""
-    pt = _packed_transposed(mlp, layer, lo, hi) if (d.shape[1] == 256 and d.stride(0) % 4 == 0) else None
+    pt = _packed_transposed(mlp, layer, W, lo, hi) if (d.shape[1] == 256 and d.stride(0) % 4 == 0) else None
     if pt is not None and (relu_of is None or (relu_of.shape[1] == 256 and relu_of.stride(0) == 256)):
         rows = int(d.shape[0])
         return ops.project_forward([pt], Operand(d, rows, 256), rows, rows, weight_dtype=_lib.DTYPE_F32, relu_mask=relu_of)[0]
@@ -121,7 +125,7 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
 # backward of the Linear/ReLU chain shared by all fused ops
 # ---------------------------------------------------------------------------------------------------------------------
 def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
-                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None):
+                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None, ln_width: int = 0):
     """Backward through [LayerNorm] <- Linear_L <- ReLU <- ... <- Linear_1 <- ReLU, down to the output of Linear_0.
 
     ``weights`` = [W0, b0, W1, b1, ..., WL, bL, (gamma, beta)] (state_dict order of the reference ``MLP.model``);
@@ -134,7 +138,7 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     if has_norm:
         grads[-2] = torch.zeros_like(weights[-2])
         grads[-1] = torch.zeros_like(weights[-1])
-        d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1])
+        d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1], ln_width)
     else:
         d = dout.contiguous()
     # Every Linear_l (l >= 1) gets its weight gradient d_l^T h_{l-1} and, from the same GEMM, its bias gradient (column
@@ -161,7 +165,7 @@ class MLPRowsFunction(torch.autograd.Function):
     def forward(ctx, mlp, x2, residual_op, n_rows, rows_per_batch, *params):
         pm = mlp.packed()
         save = SavedActivations(pm, n_rows, x2.device)
-        y = ops.mlp_forward(pm, Operand(x2, rows_per_batch, mlp.in_dim), n_rows, rows_per_batch, residual=residual_op, save=save)
+        y = ops.mlp_forward(pm, Operand(x2, rows_per_batch, mlp.native_k()), n_rows, rows_per_batch, residual=residual_op, save=save)
         ctx.mlp, ctx.save, ctx.has_norm = mlp, save, pm.gamma is not None
         ctx.save_for_backward(x2, *params)
         return y
@@ -170,7 +174,8 @@ class MLPRowsFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x2, *params = ctx.saved_tensors
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp)
+        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
+                                     ctx.mlp.out_dim)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         gemm_tn_acc(dz0, x2, gW0)
@@ -180,7 +185,7 @@ class MLPRowsFunction(torch.autograd.Function):
 
 
 def mlp_rows(mlp, x2: torch.Tensor, n_rows: int, rows_per_batch: int, residual_op: Optional[Operand] = None) -> torch.Tensor:
-    params = list(mlp.model.parameters())
+    params = mlp.native_params()
     return MLPRowsFunction.apply(mlp, x2, residual_op, n_rows, rows_per_batch, *params)
 
 
@@ -203,7 +208,7 @@ class ProjectFunction(torch.autograd.Function):
         for s, d in zip(ctx.slice_ids, douts):
             if d is None:
                 continue
-            lo, hi = ctx.mlp._splits[s]
+            lo, hi = ctx.mlp.native_splits()[s]
             d = d.contiguous()
             gemm_tn_acc(d, x, gW, c_col0=lo)  # dW[:, lo:hi] += d^T x
             if ctx.needs_input_grad[2]:
@@ -213,7 +218,7 @@ class ProjectFunction(torch.autograd.Function):
 
 
 def project(mlp, slice_ids: Sequence[int], x: torch.Tensor, n_rows: int, rows_per_batch: int) -> Tuple[torch.Tensor, ...]:
-    return ProjectFunction.apply(mlp, tuple(slice_ids), x, n_rows, rows_per_batch, mlp.model[0].weight)
+    return ProjectFunction.apply(mlp, tuple(slice_ids), x, n_rows, rows_per_batch, mlp.native_params()[0])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -274,7 +279,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
         add = de_out.contiguous() if (ctx.want_edges and de_out is not None and de_out.numel()) else None
         dn = gather_rows(dagg.contiguous(), plan.n_dst, plan.dst, B, E, add)
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, True, params[-2], grads, mlp)
+        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, True, params[-2], grads, mlp, mlp.out_dim)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         tensors = (x_src, x_dst, e_in)
@@ -283,7 +288,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
         for i, (t, sp) in enumerate(zip(tensors, specs)):
             if sp.mode == "zero":
                 continue
-            lo, hi = mlp._splits[i]
+            lo, hi = mlp.native_splits()[i]
             if sp.mode == "proj":
                 if ctx.needs_input_grad[5 + i]:
                     dts[i] = _scatter_rows(dz0, i, plan, B, sp.rows_pb, n_rows_tab[i])
@@ -302,7 +307,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
 
 
 def edge_update(mlp, plan, batch: int, specs, want_edges: bool, x_src, x_dst, e_in, e_res, e_res_rows_pb: int):
-    params = list(mlp.model.parameters())
+    params = mlp.native_params()
     dummy = e_res.new_zeros(0)
     ts = [t if t is not None else dummy for t in (x_src, x_dst, e_in)]
     agg, e_out = EdgeUpdateFunction.apply(mlp, plan, batch, tuple(specs), want_edges, ts[0], ts[1], ts[2], e_res, e_res_rows_pb, *params)
@@ -331,10 +336,10 @@ class NodeUpdateFunction(torch.autograd.Function):
         batch = n // rpb
         dout = dout.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, True, params[-2], grads, ctx.mlp)
+        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, True, params[-2], grads, ctx.mlp, ctx.mlp.out_dim)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
-        (xlo, xhi), (alo, ahi) = mlp._splits
+        (xlo, xhi), (alo, ahi) = mlp.native_splits()
         gemm_tn_acc(dz0, agg, gW0, c_col0=alo)
         dagg = input_grad(mlp, 0, dz0, W0, alo, ahi) if ctx.needs_input_grad[7] else None
         dx = None
@@ -361,7 +366,7 @@ class NodeUpdateFunction(torch.autograd.Function):
 
 
 def node_update(mlp, n_rows: int, rows_per_batch: int, x_spec: OperandSpec, x, x_res, res_rows_pb: int, agg):
-    params = list(mlp.model.parameters())
+    params = mlp.native_params()
     dummy = agg.new_zeros(0)
     return NodeUpdateFunction.apply(mlp, n_rows, rows_per_batch, x_spec, res_rows_pb, x if x is not None else dummy,
                                     x_res if x_res is not None else dummy, agg, *params)

@@ -585,6 +585,7 @@ bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const 
   }
   if (n_raw > 1 || n_proj < 1) return false;
   if (w->n_mid < 1) return false;
+  if (w->ln_width > 0 && w->ln_width != 256) return false;  // zero-padded narrow models: masked statistics live in the general kernel
   static int impl = -1;  // GW_EDGE_IMPL=0 forces the general chain kernel (A/B measurements, tests of both paths)
   if (impl < 0) impl = env_int("GW_EDGE_IMPL", 1);
   return impl != 0;

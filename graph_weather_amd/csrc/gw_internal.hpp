@@ -47,6 +47,7 @@ struct ChainArgs {
   float* out;
   int out_ld;
   int out_cols;
+  int ln_width;  // features the LayerNorm statistics span (<= tile width; the rest is zero padding)
   float* agg;
   const int* agg_idx;
   int agg_rows_pb;

@@ -403,10 +403,11 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
       for (int t = 0; t < OT; ++t) stg4(srow + 16 * t + 4 * q, o[t]);
     }
-    // heads (EPI_DEC) normalise over their n_out <= OT*16 real features: the padding rows of the last Linear are zero, so
-    // they drop out of the sum and are masked out of the variance
-    const int nfeat = (EPI == EPI_DEC) ? a.out_cols : OT * 16;
-    const float inv_n = (EPI == EPI_DEC) ? 1.0f / (float)nfeat : 1.0f / (OT * 16);
+    // heads and zero-padded narrow models normalise over their ln_width <= OT*16 real features: the padding rows of the
+    // last Linear are zero, so they drop out of the sum and are masked out of the variance
+    const int nfeat = a.ln_width;
+    const bool narrow = nfeat != OT * 16;  // uniform: heads and zero-padded narrow models
+    const float inv_n = narrow ? 1.0f / (float)nfeat : 1.0f / (OT * 16);
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < OT; ++t) s += (o[t].x + o[t].y) + (o[t].z + o[t].w);
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     for (int t = 0; t < OT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = (EPI == EPI_DEC && 16 * t + 4 * q + r >= nfeat) ? 0.f : o[t][r] - mean;
+        const float d = (narrow && 16 * t + 4 * q + r >= nfeat) ? 0.f : o[t][r] - mean;
         v += d * d;
       }
     v += __shfl_xor(v, 16);
@@ -631,6 +632,7 @@ void fill_weights(ChainArgs& a, const gw_mlp_weights* w) {
   a.gamma = w->ln_gamma;
   a.beta = w->ln_beta;
   a.n_mid = w->n_mid;
+  a.ln_width = (w->ln_width > 0 && w->ln_width < w->n_out) ? w->ln_width : w->n_out;
 }
 
 void fill_operand(ChainArgs& a, int i, const gw_operand* op) {
@@ -739,7 +741,8 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
     if (w->n_out == 256 && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
     if (x->k == 256 && x->ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input ld must be a multiple of 4");
     if (x->k > 128 && x->k != 256) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=128 or ==256");
-    if (w->n_out != 256 && w->ln_gamma) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: LayerNorm on an output head is implemented for float32 weights only");
+    if (w->ln_gamma && (w->n_out != 256 || (w->ln_width > 0 && w->ln_width != w->n_out)))
+      return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: LayerNorm over fewer than 256 features is implemented for float32 weights only");
     return gw::chain16_launch(0, a, x->k, w->hidden, w->n_out, 1, stream);
   }
   if (w->hidden == 256 && w->n_out == 256) {
@@ -802,7 +805,10 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg_idx = dst;
   a.agg_rows_pb = n_dst;
   if (int rc = fill_save(a, save, w, "gw_edge_update_forward")) return rc;
-  if (w->weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(1, a, 256, 256, 256, 1, stream);
+  if (w->weight_dtype == GW_DTYPE_BF16) {
+    if (a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
+    return gw::chain16_launch(1, a, 256, 256, 256, 1, stream);
+  }
   return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream, 1, 1);
 }
 
@@ -831,7 +837,10 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.out_ld = out_ld;
   a.out_cols = 256;
   if (int rc = fill_save(a, save, w, "gw_node_update_forward")) return rc;
-  if (w->weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(2, a, 256, 256, 256, 1, stream);
+  if (w->weight_dtype == GW_DTYPE_BF16) {
+    if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
+    return gw::chain16_launch(2, a, 256, 256, 256, 1, stream);
+  }
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }
 

@@ -82,7 +82,14 @@ def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
 
 
 class MLP(nn.Module):
-    """``MLP`` - graph_net_block.py:17-77.  ``model`` is the same nn.Sequential layout (Linear/ReLU.../[LayerNorm])."""
+    """``MLP`` - graph_net_block.py:17-77.  ``model`` is the same nn.Sequential layout (Linear/ReLU.../[LayerNorm]).
+
+    The HIP kernels come in three shapes: hidden 256 -> 256 outputs (+ LayerNorm), and output heads of up to 80 features
+    behind 128 or 256 hidden units.  An MLP of any other width up to 256 (the reference's own defaults are 128,
+    graph_net_block.py:20-28,234-244) runs on those kernels zero-padded: padded hidden units are relu(0) = 0, padded
+    outputs are 0, LayerNorm statistics span the real ``out_dim`` features only (``gw_mlp_weights.ln_width``), and an MLP
+    with a single hidden layer gets an identity middle layer (relu(I h) = h for h >= 0) - all exact.  MLPs whose output
+    feeds a 256-wide node / edge table (``as_table``) keep the padded layout between kernels; ``forward`` slices it off."""
 
     def __init__(self, in_dim: int, out_dim: int = 128, hidden_dim: int = 128, hidden_layers: int = 2,
                  norm_type: Optional[str] = "LayerNorm", use_checkpointing: bool = False):
@@ -101,6 +108,7 @@ class MLP(nn.Module):
         self._packed: Optional[PackedMLP] = None
         self._packed_key = None
         self._splits: Tuple[Tuple[int, int], ...] = ((0, in_dim),)
+        self._table = False
         # dtype of the matrix products: float32 (fp32 MFMA, bitwise an fmaf chain) or bfloat16 (bf16 MFMA, fp32
         # accumulate); parameters and activations stay fp32 either way.  Set through set_compute_dtype().
         self.compute_dtype = torch.float32
@@ -110,34 +118,119 @@ class MLP(nn.Module):
         self._splits = tuple(splits)
         self._packed = None
 
+    def as_table(self) -> "MLP":
+        """The output of this MLP is a node / edge table consumed by the message-passing kernels (256 floats per row)."""
+        self._table = True
+        self._packed = None
+        return self
+
     def _linears(self):
         return [m for m in self.model if isinstance(m, nn.Linear)]
 
+    def _norm(self):
+        return self.model[-1] if isinstance(self.model[-1], nn.LayerNorm) else None
+
+    # ---- mapping onto a kernel variant -----------------------------------------------------------------------------
+    def _layout(self):
+        """(hidden units, outputs, layer-1 slice widths, identity layer inserted?, any padding?) of the kernel variant."""
+        hid, out = self.hidden_dim, self.out_dim
+        if hid > 256 or out > 256:
+            raise NotImplementedError("graph_weather_amd: the HIP kernels are built for MLP widths up to 256")
+        if self._table or out > 80:
+            H, O = 256, 256
+        else:
+            H, O = (128 if hid <= 128 else 256), out
+        single = len(self._splits) == 1
+        kp = []
+        for lo, hi in self._splits:
+            k = hi - lo
+            if k > 256:
+                raise NotImplementedError("graph_weather_amd: MLP inputs wider than 256 features are not implemented")
+            kp.append(k if (single and O == 256 and k <= 112) else 256)
+        identity = len(self._linears()) == 2
+        padded = identity or hid != H or O != out or any(k != hi - lo for k, (lo, hi) in zip(kp, self._splits))
+        return H, O, tuple(kp), identity, padded
+
+    def native_k(self) -> int:
+        return self._layout()[2][0]
+
+    def native_out(self) -> int:
+        return self._layout()[1]
+
+    def native_splits(self) -> Tuple[Tuple[int, int], ...]:
+        kp = self._layout()[2]
+        offs = [0]
+        for k in kp:
+            offs.append(offs[-1] + k)
+        return tuple((offs[i], offs[i + 1]) for i in range(len(kp)))
+
+    def native_key(self) -> tuple:
+        return _version_key(list(self.model.parameters()))
+
+    def native_params(self) -> List[torch.Tensor]:
+        """Parameters in the shapes the kernels and the backward products work on, in ``model.parameters()`` order.  With
+        kernel-native widths these are the parameters themselves; otherwise zero-padded copies made with differentiable
+        torch ops (pad / cat = data movement), so autograd hands the slices of their gradients back to the parameters."""
+        H, O, kp, identity, padded = self._layout()
+        if not padded:
+            return list(self.model.parameters())
+        import torch.nn.functional as F
+
+        lin, norm = self._linears(), self._norm()
+        hid, out = self.hidden_dim, self.out_dim
+        parts = [F.pad(lin[0].weight[:, lo:hi], (0, k - (hi - lo))) for (lo, hi), k in zip(self._splits, kp)]
+        ps = [F.pad(torch.cat(parts, dim=1), (0, 0, 0, H - hid)), F.pad(lin[0].bias, (0, H - hid))]
+        for m in lin[1:-1]:
+            ps += [F.pad(m.weight, (0, H - hid, 0, H - hid)), F.pad(m.bias, (0, H - hid))]
+        if identity:
+            w = lin[0].weight
+            ps += [torch.eye(H, dtype=w.dtype, device=w.device), torch.zeros(H, dtype=w.dtype, device=w.device)]
+        ps += [F.pad(lin[-1].weight, (0, H - hid, 0, O - out)), F.pad(lin[-1].bias, (0, O - out))]
+        if norm is not None:
+            ps += [F.pad(norm.weight, (0, O - out)), F.pad(norm.bias, (0, O - out))]
+        return ps
+
     def packed(self) -> PackedMLP:
-        lin = self._linears()
-        norm = self.model[-1] if isinstance(self.model[-1], nn.LayerNorm) else None
-        params = [p for m in lin for p in (m.weight, m.bias)] + ([norm.weight, norm.bias] if norm is not None else [])
-        key = (_version_key(params), self.compute_dtype)
+        norm = self._norm()
+        key = (self.native_key(), self.compute_dtype)
         if self._packed is None or key != self._packed_key:
-            if not lin[0].weight.is_cuda:
+            if not self.model[0].weight.is_cuda:
                 raise RuntimeError("graph_weather_amd: module parameters must be on a HIP device (no CPU path exists)")
             if norm is not None and abs(norm.eps - 1e-5) > 0:
                 raise RuntimeError("graph_weather_amd: LayerNorm eps must be 1e-5")
-            self._packed = PackedMLP([m.weight for m in lin], [m.bias for m in lin],
-                                     (norm.weight, norm.bias) if norm is not None else None, self._splits,
-                                     self.compute_dtype)
+            with torch.no_grad():
+                ps = [p.detach() for p in self.native_params()]
+            n_lin = (len(ps) - (2 if norm is not None else 0)) // 2
+            self._packed = PackedMLP([ps[2 * i] for i in range(n_lin)], [ps[2 * i + 1] for i in range(n_lin)],
+                                     (ps[-2], ps[-1]) if norm is not None else None, self.native_splits(), self.compute_dtype,
+                                     ln_width=self.out_dim if norm is not None else 0)
             self._packed_key = key
         return self._packed
+
+    def run(self, x2: torch.Tensor, n_rows: int, rows_per_batch: int, residual: Optional[Operand] = None) -> torch.Tensor:
+        """Rows through the kernel variant: [n_rows, in_dim] -> [n_rows, native_out()] (the padded table layout for
+        narrow ``as_table`` MLPs); differentiable when grad mode is on."""
+        k = self.native_k()
+        if k > x2.shape[1]:
+            x2 = torch.nn.functional.pad(x2, (0, k - x2.shape[1]))  # inputs of 113..255 features: zero columns
+        if residual is not None and self.native_out() != self.out_dim:
+            raise NotImplementedError("graph_weather_amd: a fused residual needs an output head of at most 80 features")
+        if _autograd_on(self) or (torch.is_grad_enabled() and x2.requires_grad):
+            return ag.mlp_rows(self, x2, n_rows, rows_per_batch, residual_op=residual)
+        return ops.mlp_forward(self.packed(), Operand(x2, rows_per_batch, k), n_rows, rows_per_batch, residual=residual)
+
+    def table(self, x: torch.Tensor) -> torch.Tensor:
+        """``forward`` without slicing the padding off: [rows, in_dim] -> [rows, 256] for ``as_table`` MLPs."""
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        n = int(x2.shape[0])
+        return self.run(x2, n, max(n, 1))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """graph_net_block.py:63-77."""
         lead = x.shape[:-1]
-        x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        n = int(x2.shape[0])
-        if _autograd_on(self) or (torch.is_grad_enabled() and x2.requires_grad):
-            y = ag.mlp_rows(self, x2, n, n)
-        else:
-            y = ops.mlp_forward(self.packed(), Operand(x2, n, self.in_dim), n, n)
+        y = self.table(x)
+        if y.shape[1] != self.out_dim:
+            y = y[:, :self.out_dim]
         return y.reshape(*lead, self.out_dim)
 
 
@@ -146,7 +239,7 @@ class EdgeProcessor(nn.Module):
 
     def __init__(self, in_dim_node=128, in_dim_edge=128, hidden_dim=128, hidden_layers=2, norm_type="LayerNorm"):
         super().__init__()
-        self.edge_mlp = MLP(2 * in_dim_node + in_dim_edge, in_dim_edge, hidden_dim, hidden_layers, norm_type)
+        self.edge_mlp = MLP(2 * in_dim_node + in_dim_edge, in_dim_edge, hidden_dim, hidden_layers, norm_type).as_table()
         self.edge_mlp.set_input_splits(((0, in_dim_node), (in_dim_node, 2 * in_dim_node),
                                         (2 * in_dim_node, 2 * in_dim_node + in_dim_edge)))
 
@@ -156,7 +249,7 @@ class NodeProcessor(nn.Module):
 
     def __init__(self, in_dim_node=128, in_dim_edge=128, hidden_dim=128, hidden_layers=2, norm_type="LayerNorm"):
         super().__init__()
-        self.node_mlp = MLP(in_dim_node + in_dim_edge, in_dim_node, hidden_dim, hidden_layers, norm_type)
+        self.node_mlp = MLP(in_dim_node + in_dim_edge, in_dim_node, hidden_dim, hidden_layers, norm_type).as_table()
         self.node_mlp.set_input_splits(((0, in_dim_node), (in_dim_node, in_dim_node + in_dim_edge)))
 
 
@@ -205,10 +298,16 @@ def build_graph_processor_block(in_dim_node=128, in_dim_edge=128, hidden_dim_nod
 
 
 def _check_native_dims(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge, norm_type):
-    if not (in_dim_node == in_dim_edge == hidden_dim_node == hidden_dim_edge == 256) or norm_type != "LayerNorm":
+    if max(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge) > 256 or norm_type != "LayerNorm":
         raise NotImplementedError(
-            "graph_weather_amd: the HIP message-passing kernels are built for node/edge/hidden width 256 with "
-            "LayerNorm (the reference defaults, forecast.py:64-84); other widths are not implemented yet")
+            "graph_weather_amd: the HIP message-passing kernels handle node / edge / hidden widths up to 256 (narrower "
+            "models run zero-padded to 256) with LayerNorm; wider models and norm_type=None are not implemented")
+
+
+def _pad256(t: torch.Tensor) -> torch.Tensor:
+    """A [rows, width <= 256] tensor in the 256-float table layout of the kernels (zero columns appended)."""
+    t = t.contiguous()
+    return t if t.shape[1] == 256 else torch.nn.functional.pad(t, (0, 256 - t.shape[1]))
 
 
 class GraphProcessor(nn.Module):
@@ -284,11 +383,12 @@ class GraphProcessor(nn.Module):
         """graph_net_block.py:279-301 for an arbitrary COO graph (the reference's random-graph test,
         tests/models/test_gradient_checkpointing.py:62-86): edges are dst-sorted once per edge_index tensor."""
         plan = self._plan_for(edge_index, int(x.shape[0]))
-        e_sorted = edge_attr.contiguous()[plan.perm].contiguous()
-        x_out, e_out = self.run_plan(x.contiguous(), plan, e_sorted, False, 1, True)
+        dn, de = int(x.shape[1]), int(edge_attr.shape[1])
+        e_sorted = _pad256(edge_attr)[plan.perm].contiguous()
+        x_out, e_out = self.run_plan(_pad256(x), plan, e_sorted, False, 1, True)
         e_ref = torch.empty_like(e_out)
         e_ref[plan.perm] = e_out
-        return x_out, e_ref
+        return (x_out if dn == 256 else x_out[:, :dn]), (e_ref if de == 256 else e_ref[:, :de])
 
 
 class Encoder(nn.Module):
@@ -308,12 +408,13 @@ class Encoder(nn.Module):
         self.num_h3 = self.graphs.num_mesh
         # encoder.py:112-114 - zero-initialised learnable mesh-node inputs
         self.h3_nodes = nn.Parameter(torch.zeros((self.num_h3, input_dim), dtype=torch.float))
+        self.output_edge_dim = output_edge_dim
         self.node_encoder = MLP(input_dim, output_dim, hidden_dim_processor_node, hidden_layers_processor_node,
-                                mlp_norm_type, use_checkpointing)
+                                mlp_norm_type, use_checkpointing).as_table()
         self.edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, hidden_layers_processor_edge,
-                                mlp_norm_type, use_checkpointing)
+                                mlp_norm_type, use_checkpointing).as_table()
         self.latent_edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, hidden_layers_processor_edge,
-                                       mlp_norm_type, use_checkpointing)
+                                       mlp_norm_type, use_checkpointing).as_table()
         self.graph_processor = GraphProcessor(1, output_dim, output_edge_dim, hidden_dim_processor_node,
                                               hidden_dim_processor_edge, hidden_layers_processor_node,
                                               hidden_layers_processor_edge, mlp_norm_type, use_checkpointing)
@@ -339,15 +440,15 @@ class Encoder(nn.Module):
     def mesh_embedding(self) -> torch.Tensor:
         """node_encoder(h3_nodes): batch independent (encoder.py:199-205 recomputes it for every sample)."""
         ps = list(self.node_encoder.parameters()) + [self.h3_nodes]
-        return self._cached("mesh", ps, lambda: self.node_encoder(self.h3_nodes if _autograd_on(self) else self.h3_nodes.detach()))
+        return self._cached("mesh", ps, lambda: self.node_encoder.table(self.h3_nodes if _autograd_on(self) else self.h3_nodes.detach()))
 
     def encoder_edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
-        return self._cached("enc_e", list(self.edge_encoder.parameters()), lambda: self.edge_encoder(plan.edge_attr))
+        return self._cached("enc_e", list(self.edge_encoder.parameters()), lambda: self.edge_encoder.table(plan.edge_attr))
 
     def latent_edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
         """latent_edge_encoder(attr) once on [E_lat, 2] in dst-sorted order (encoder.py:235-241 repeats B times)."""
         return self._cached("lat_e", list(self.latent_edge_encoder.parameters()),
-                            lambda: self.latent_edge_encoder(plan.edge_attr))
+                            lambda: self.latent_edge_encoder.table(plan.edge_attr))
 
     def encode(self, features: torch.Tensor) -> torch.Tensor:
         """encoder.py:199-223 -> mesh node features [(B*M), D] (batch-major, reversed-rank mesh order)."""
@@ -356,11 +457,7 @@ class Encoder(nn.Module):
         B, G, F = (int(s) for s in features.shape)
         feats = features.contiguous().reshape(B * G, F)
         enc_plan, _ = self._plans(features.device)
-        train = _autograd_on(self)
-        if train:
-            xg = ag.mlp_rows(self.node_encoder, feats, B * G, G)  # grid rows only
-        else:
-            xg = ops.mlp_forward(self.node_encoder.packed(), Operand(feats, G, F), B * G, G)
+        xg = self.node_encoder.run(feats, B * G, G)  # grid rows only
         xm = self.mesh_embedding()
         e = self.encoder_edge_embedding(enc_plan)
         blk = self.graph_processor.blocks[0]
@@ -400,6 +497,10 @@ class Encoder(nn.Module):
         e_sorted = self.latent_edge_embedding(lat_plan)
         e_ref = torch.empty_like(e_sorted)
         e_ref[lat_plan.perm] = e_sorted
+        if self.output_dim != 256:
+            x = x[:, :self.output_dim]
+        if self.output_edge_dim != 256:
+            e_ref = e_ref[:, :self.output_edge_dim]
         ei = self.graphs.lat_edge_index.to(features.device)
         if self.efficient_batching:
             return x, ei, e_ref
@@ -432,16 +533,18 @@ class Processor(nn.Module):
     def forward(self, x: torch.Tensor, edge_index, edge_attr, t: int = 0, batch_size: int = None,
                 efficient_batching: bool = False) -> torch.Tensor:
         """processor.py:83-128."""
+        dn = int(x.shape[1])
+        x, edge_attr = _pad256(x), _pad256(edge_attr)
         if efficient_batching and batch_size is not None and batch_size > 1:
             n = int(x.shape[0]) // batch_size
             plan = self.graph_processor._plan_for(edge_index, n)
-            e_sorted = edge_attr.contiguous()[plan.perm].contiguous()
-            out, _ = self.graph_processor.run_plan(x.contiguous(), plan, e_sorted, True, batch_size, False)
-            return out
-        plan = self.graph_processor._plan_for(edge_index, int(x.shape[0]))
-        e_sorted = edge_attr.contiguous()[plan.perm].contiguous()
-        out, _ = self.graph_processor.run_plan(x.contiguous(), plan, e_sorted, False, 1, False)
-        return out
+            e_sorted = edge_attr[plan.perm].contiguous()
+            out, _ = self.graph_processor.run_plan(x, plan, e_sorted, True, batch_size, False)
+        else:
+            plan = self.graph_processor._plan_for(edge_index, int(x.shape[0]))
+            e_sorted = edge_attr[plan.perm].contiguous()
+            out, _ = self.graph_processor.run_plan(x, plan, e_sorted, False, 1, False)
+        return out if dn == 256 else out[:, :dn]
 
 
 class AssimilatorDecoder(nn.Module):
@@ -461,7 +564,7 @@ class AssimilatorDecoder(nn.Module):
         self.num_h3 = self.graphs.num_mesh
         self.output_dim = output_dim
         # assimilator_decoder.py:108-110: hidden_layers of the edge encoder is the literal 2
-        self.edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, 2, mlp_norm_type, use_checkpointing)
+        self.edge_encoder = MLP(2, output_edge_dim, hidden_dim_processor_edge, 2, mlp_norm_type, use_checkpointing).as_table()
         self.graph_processor = GraphProcessor(mp_iterations=1, in_dim_node=input_dim, in_dim_edge=output_edge_dim,
                                               hidden_dim_node=hidden_dim_processor_node,
                                               hidden_dim_edge=hidden_dim_processor_edge,
@@ -480,11 +583,11 @@ class AssimilatorDecoder(nn.Module):
 
     def edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
         if _autograd_on(self):
-            return self.edge_encoder(plan.edge_attr)
+            return self.edge_encoder.table(plan.edge_attr)
         key = _version_key(list(self.edge_encoder.parameters()))
         hit = self._cache.get("dec_e")
         if hit is None or hit[0] != key:
-            self._cache["dec_e"] = (key, self.edge_encoder(plan.edge_attr))
+            self._cache["dec_e"] = (key, self.edge_encoder.table(plan.edge_attr))
         return self._cache["dec_e"][1]
 
     def decode(self, processor_features: torch.Tensor, batch_size: int,
@@ -494,6 +597,7 @@ class AssimilatorDecoder(nn.Module):
         if processor_features.shape[0] != B * M:
             raise RuntimeError("processor_features must have batch*num_h3 rows")
         dev = processor_features.device
+        processor_features = _pad256(processor_features)
         plan = self._plan(dev)
         e = self.edge_embedding(plan)
         blk = self.graph_processor.blocks[0]
@@ -520,10 +624,9 @@ class AssimilatorDecoder(nn.Module):
         res = None
         if residual is not None:
             res = Operand(residual, G, self.output_dim)
-        if train:
-            y = ag.mlp_rows(self.node_decoder, xg, B * G, G, residual_op=res)
-        else:
-            y = ops.mlp_forward(self.node_decoder.packed(), Operand(xg, G, 256), B * G, G, residual=res)
+        y = self.node_decoder.run(xg, B * G, G, residual=res)
+        if y.shape[1] != self.output_dim:
+            y = y[:, :self.output_dim]
         return y.reshape(B, G, self.output_dim)
 
     def forward(self, processor_features: torch.Tensor, batch_size: int) -> torch.Tensor:

@@ -96,7 +96,7 @@ class PackedMLP:
 
     def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
                  ln: Optional[Tuple[torch.Tensor, torch.Tensor]], splits: Sequence[Tuple[int, int]],
-                 compute_dtype: torch.dtype = torch.float32):
+                 compute_dtype: torch.dtype = torch.float32, ln_width: int = 0):
         L = _lib.lib()
         if compute_dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32 or torch.bfloat16")
@@ -109,6 +109,7 @@ class PackedMLP:
         self.n_out = int(weights[-1].shape[0])
         self.n_mid = n_lin - 2
         self.in_dim = int(weights[0].shape[1])
+        self.ln_width = int(ln_width) if (ln is not None and 0 < ln_width < self.n_out) else 0  # 0: all n_out features
         for w in weights[1:-1]:
             if tuple(w.shape) != (self.hidden, self.hidden):
                 raise RuntimeError("graph_weather_amd: hidden layers must be square")
@@ -169,6 +170,7 @@ class PackedMLP:
         w.ln_beta = self.beta.data_ptr() if self.beta is not None else None
         w.hidden, w.n_mid, w.n_out = self.hidden, self.n_mid, self.n_out
         w.weight_dtype = self.weight_dtype
+        w.ln_width = self.ln_width
         return w
 
 

@@ -304,18 +304,18 @@ class RegionalForecaster(nn.Module):
         self.graph_builder = DynamicGraphBuilder(resolution=c.resolution)
         self.h3_embeddings = nn.Parameter(torch.zeros(_mesh.num_cells(c.resolution), input_dim))
         mk = dict(norm_type=c.norm_type, use_checkpointing=c.use_checkpointing)
-        self.node_encoder = MLP(input_dim, c.node_dim, c.hidden_dim_processor_node, c.hidden_layers_processor_node, **mk)
-        self.edge_encoder = MLP(2, c.edge_dim, c.hidden_dim_processor_edge, c.hidden_layers_processor_edge, **mk)
+        self.node_encoder = MLP(input_dim, c.node_dim, c.hidden_dim_processor_node, c.hidden_layers_processor_node, **mk).as_table()
+        self.edge_encoder = MLP(2, c.edge_dim, c.hidden_dim_processor_edge, c.hidden_layers_processor_edge, **mk).as_table()
         self.encoder_gnn = GraphProcessor(1, c.node_dim, c.edge_dim, c.hidden_dim_processor_node, c.hidden_dim_processor_edge,
                                           c.hidden_layers_processor_node, c.hidden_layers_processor_edge, c.norm_type,
                                           use_checkpointing=c.use_checkpointing)
-        self.latent_edge_encoder = MLP(2, c.edge_dim, c.hidden_dim_processor_edge, c.hidden_layers_processor_edge, **mk)
+        self.latent_edge_encoder = MLP(2, c.edge_dim, c.hidden_dim_processor_edge, c.hidden_layers_processor_edge, **mk).as_table()
         self.processor = Processor(input_dim=c.node_dim, edge_dim=c.edge_dim, num_blocks=c.num_blocks,
                                    hidden_dim_processor_edge=c.hidden_dim_processor_edge,
                                    hidden_layers_processor_node=c.hidden_layers_processor_node,
                                    hidden_dim_processor_node=c.hidden_dim_processor_node,
                                    hidden_layers_processor_edge=c.hidden_layers_processor_edge, mlp_norm_type=c.norm_type)
-        self.decoder_edge_encoder = MLP(2, c.edge_dim, c.hidden_dim_processor_edge, c.hidden_layers_processor_edge, **mk)
+        self.decoder_edge_encoder = MLP(2, c.edge_dim, c.hidden_dim_processor_edge, c.hidden_layers_processor_edge, **mk).as_table()
         self.decoder_gnn = GraphProcessor(1, c.node_dim, c.edge_dim, c.hidden_dim_processor_node, c.hidden_dim_processor_edge,
                                           c.hidden_layers_processor_node, c.hidden_layers_processor_edge, c.norm_type,
                                           use_checkpointing=c.use_checkpointing)
@@ -352,14 +352,11 @@ class RegionalForecaster(nn.Module):
         feats = features.reshape(B * N, F)
 
         # ---- encode: coordinates + regional cells through the bipartite block (:258, :266-269) ----
-        if train:
-            xo = ag.mlp_rows(self.node_encoder, feats, B * N, N)
-        else:
-            xo = ops.mlp_forward(self.node_encoder.packed(), Operand(feats, N, F), B * N, N)
+        xo = self.node_encoder.run(feats, B * N, N)
         enc_params = list(self.node_encoder.parameters()) + [self.h3_embeddings]
         xm = self._cached("cells", enc_params, token,
-                          lambda: self.node_encoder(self.h3_embeddings[rows] if train else self.h3_embeddings.detach()[rows]))
-        e_enc = self._cached("enc_e", list(self.edge_encoder.parameters()), token, lambda: self.edge_encoder(enc_plan.edge_attr))
+                          lambda: self.node_encoder.table(self.h3_embeddings[rows] if train else self.h3_embeddings.detach()[rows]))
+        e_enc = self._cached("enc_e", list(self.edge_encoder.parameters()), token, lambda: self.edge_encoder.table(enc_plan.edge_attr))
         blk = self.encoder_gnn.blocks[0]
 
         def enc_projections():
@@ -378,12 +375,12 @@ class RegionalForecaster(nn.Module):
 
         # ---- process: message passing between the regional cells (:259, :272) ----
         e_lat = self._cached("lat_e", list(self.latent_edge_encoder.parameters()), token,
-                             lambda: self.latent_edge_encoder(lat_plan.edge_attr))
+                             lambda: self.latent_edge_encoder.table(lat_plan.edge_attr))
         x, _ = self.processor.graph_processor.run_plan(x, lat_plan, e_lat, True, B, False)
 
         # ---- decode: reversed encoder edges into zero placeholders (:262, :275-279), head, residual (:284) ----
         e_dec = self._cached("dec_e", list(self.decoder_edge_encoder.parameters()), token,
-                             lambda: self.decoder_edge_encoder(dec_plan.edge_attr))
+                             lambda: self.decoder_edge_encoder.table(dec_plan.edge_attr))
         dblk = self.decoder_gnn.blocks[0]
         mlp_e = dblk.edge_model.edge_mlp
         if train:
@@ -396,10 +393,7 @@ class RegionalForecaster(nn.Module):
         xg, _ = dblk.run(B, dec_plan, Feed(ps, C, "proj"), FEED_ZERO, Feed(pe_d, 0, "proj"), e_dec, 0, FEED_ZERO, None, 0, False, dev,
                          tag="regional_decoder_edge")
         res = Operand(feats, N, self.output_dim)
-        if train:
-            y = ag.mlp_rows(self.node_decoder, xg, B * N, N, residual_op=res)
-        else:
-            y = ops.mlp_forward(self.node_decoder.packed(), Operand(xg, N, 256), B * N, N, residual=res)
+        y = self.node_decoder.run(xg, B * N, N, residual=res)
         out = y.reshape(B, N, self.output_dim)
 
         # ---- boundary nudging (:287-289) ----

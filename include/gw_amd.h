@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 7
+#define GW_ABI_VERSION 8
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -86,6 +86,9 @@ typedef struct gw_mlp_weights {
   int32_t n_mid;       /* hidden_layers - 1 */
   int32_t n_out;       /* 256, or <= 80 for the decoder head */
   int32_t weight_dtype; /* GW_DTYPE_F32: streams from gw_pack_linear; GW_DTYPE_BF16: streams from gw_pack_linear_bf16 */
+  int32_t ln_width;    /* features LayerNorm normalises over; 0 = n_out.  Narrower models (node/edge width < 256,
+                          graph_net_block.py:234-244 defaults to 128) run zero-padded to 256: their statistics then span
+                          the first ln_width features only (fp32 weights) */
 } gw_mlp_weights;
 
 struct gw_activation_save; /* training only, defined with the backward entry points below; NULL in inference */
