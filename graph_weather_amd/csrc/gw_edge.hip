@@ -43,6 +43,11 @@ struct EdgeArgs {
   int n_dst;
   int stagger;
   int skip;  // tuning aid (GW_EDGE_SKIP): 1 = no segment sum, 2 = no staging either (results are then wrong)
+  // XCD-aware tile order: workgroup i is dispatched to XCD i % 8 (each XCD has its own L2); XCD x then walks the contiguous
+  // tile range [x * xcd_base + min(x, xcd_rem), ...) so that neighbouring destination-sorted tiles - which gather the
+  // same few mesh rows - share an L2.  xcd_base == 0: identity order.
+  int xcd_base;
+  int xcd_rem;
   unsigned long long* dbg;
   int dbg_cap;
   const int* src;
@@ -241,7 +246,12 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
   const int q = lane >> 4;
-  const int tile_c0 = blockIdx.x * kColsPerWG;
+  int tile = blockIdx.x;
+  if (a.xcd_base > 0) {
+    const int xcd = tile & 7, idx = tile >> 3;
+    tile = xcd * a.xcd_base + (xcd < a.xcd_rem ? xcd : a.xcd_rem) + idx;
+  }
+  const int tile_c0 = tile * kColsPerWG;
   const int c_raw = tile_c0 + wave * kColsPerWave + j;
   const bool valid = c_raw < a.n_cols;
   const int c = valid ? c_raw : a.n_cols - 1;
@@ -654,6 +664,13 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
     const int passes = 1 + a.n_mid + (raw ? 1 : 0);
     a.stagger = stagger_override >= 0 ? stagger_override * passes : 2 * passes + 2;
     if ((a.n_cols + kColsPerWG - 1) / kColsPerWG <= 256) a.stagger = 0;
+  }
+  {
+    static int xcd_map = -1;  // GW_XCD_MAP=0: workgroup i takes tile i (A/B measurements)
+    if (xcd_map < 0) xcd_map = env_int("GW_XCD_MAP", 1);
+    const int tiles = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
+    a.xcd_base = (xcd_map != 0 && tiles >= 64) ? tiles / 8 : 0;
+    a.xcd_rem = tiles % 8;
   }
   if (raw) {
     if (n_proj == 1) return launch(edge_kernel<true, 1>, a, stream);
