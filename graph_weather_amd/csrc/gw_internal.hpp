@@ -81,6 +81,13 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
                      const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
                      float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, void* stream);
 
+// bf16 edge update with register-resident weights (gw_edge16.hip)
+bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w);
+size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges);
+int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
+                  const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
+                  float* e_out, float* agg, int32_t n_dst, void* workspace, void* stream);
+
 }  // namespace gw
 
 #endif  // GW_INTERNAL_HPP

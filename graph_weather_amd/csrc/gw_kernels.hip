@@ -763,10 +763,16 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: unsupported (hidden, n_out, k) combination");
 }
 
+size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
+                                      const gw_operand* e_in, const gw_mlp_weights* w) {
+  if (batch <= 0 || n_edges <= 0 || !x_src || !x_dst || !e_in || !w) return 0;
+  return gw::edge16_eligible(x_src, x_dst, e_in, w) ? gw::edge16_workspace_bytes(batch, n_edges) : 0;
+}
+
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst,
-                           const gw_activation_save* save, void* stream) {
+                           const gw_activation_save* save, void* workspace, size_t workspace_bytes, void* stream) {
   if (batch <= 0 || n_edges < 0 || n_dst <= 0) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if (n_edges == 0) return GW_OK;  // nothing to add: agg stays as the caller zeroed it
   if (!src || !dst || !x_src || !x_dst || !e_in || !e_res || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
@@ -787,6 +793,9 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_BADARG, "gw_edge_update_forward: bad gw_activation_save");
     return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, save, stream);
   }
+  if (!save && workspace && gw::edge16_eligible(x_src, x_dst, e_in, w) &&
+      workspace_bytes >= gw::edge16_workspace_bytes(batch, n_edges))
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, workspace, stream);
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;

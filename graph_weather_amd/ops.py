@@ -223,10 +223,17 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
         _require(e_out, "e_out")
     n_edges = int(src.shape[0])
     wc = pm.c((x_src.k > 0 and not x_src.projected, x_dst.k > 0 and not x_dst.projected, e_in.k > 0 and not e_in.projected))
+    xs, xd, ei = x_src.c(), x_dst.c(), e_in.c()
+    ws, ws_bytes = None, 0
+    if save is None:  # scratch for the kernel the library would like to use (the library never allocates)
+        ws_bytes = int(_lib.lib().gw_edge_update_workspace_bytes(batch, n_edges, xs, xd, ei, wc))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=agg.device)
     ev = TIMER.start(tag) if TIMER is not None else None
-    _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), x_src.c(), x_dst.c(), e_in.c(),
+    _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), xs, xd, ei,
                                                  e_res.c(), wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(),
-                                                 n_dst, None if save is None else save.c(), _stream(agg)),
+                                                 n_dst, None if save is None else save.c(), None if ws is None else ws.data_ptr(),
+                                                 ws_bytes, _stream(agg)),
                "gw_edge_update_forward")
     if ev is not None:
         TIMER.stop(tag, ev)

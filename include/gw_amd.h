@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 8
+#define GW_ABI_VERSION 9
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -126,7 +126,14 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w,
                            float* e_out /* [batch*n_edges,256] or NULL */, float* agg /* [batch*n_dst,256] */,
-                           int32_t n_dst, const struct gw_activation_save* save /* may be NULL */, void* stream);
+                           int32_t n_dst, const struct gw_activation_save* save /* may be NULL */,
+                           void* workspace /* may be NULL */, size_t workspace_bytes, void* stream);
+/* Scratch device memory (16-byte aligned, contents irrelevant) that lets gw_edge_update_forward pick its fastest kernel
+ * for these operands - today the bf16 path with register-resident weights, which stages the layer-1 activations of all
+ * tiles (32 KiB per 64 edges and batch element).  0 = none needed; the library never allocates (the caller's allocator
+ * owns all device memory).  Without the workspace the call still works, on the streaming kernel. */
+size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
+                                      const gw_operand* e_in, const gw_mlp_weights* w);
 
 /* ---- NodeProcessor.forward after aggregation (graph_net_block.py:189-191) -------------------------------
  *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x_res[b, j]

@@ -1,0 +1,65 @@
+"""The bf16 edge update with register-resident weights (csrc/gw_edge16.hip) against a float64 emulation of exactly its
+arithmetic: bf16-rounded weights and activations (round to nearest even), exact products, fp32-style sums.  Layout or
+indexing mistakes show up as O(1) errors; what remains is summation order (~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from graph_weather_amd import ops  # noqa: E402
+from graph_weather_amd.ops import Operand, PackedMLP  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("case", ["decoder", "encoder", "tiny"])
+def test_edge16_matches_bf16_emulation(case):
+    rs = np.random.RandomState({"decoder": 1, "encoder": 2, "tiny": 3}[case])
+    B, n_src, n_dst, E = (3, 50, 40, 333) if case != "tiny" else (2, 4, 3, 5)
+    W0 = torch.from_numpy((rs.standard_normal((256, 768)) / 16).astype(np.float32))
+    W1 = torch.from_numpy((rs.standard_normal((256, 256)) / 16).astype(np.float32))
+    W2 = torch.from_numpy((rs.standard_normal((256, 256)) / 16).astype(np.float32))
+    b0, b1, b2 = (torch.from_numpy((0.1 * rs.standard_normal(256)).astype(np.float32)) for _ in range(3))
+    gamma = torch.from_numpy((1 + 0.1 * rs.standard_normal(256)).astype(np.float32))
+    beta = torch.from_numpy((0.1 * rs.standard_normal(256)).astype(np.float32))
+    dst = np.sort(np.where(rs.rand(E) < 0.4, n_dst // 2, rs.randint(0, n_dst, size=E)))  # one long segment spanning tiles
+    src = rs.randint(0, n_src, size=E)
+    ps = torch.from_numpy(rs.standard_normal((B * n_src, 256)).astype(np.float32))   # per-sample projected source rows
+    pd = torch.from_numpy(rs.standard_normal((n_dst, 256)).astype(np.float32))       # batch-shared projected destination rows
+    pe = torch.from_numpy(rs.standard_normal((E, 256)).astype(np.float32))           # batch-shared projected edge rows
+    e_res = torch.from_numpy(rs.standard_normal((E, 256)).astype(np.float32))
+    use_dst = case != "decoder"
+
+    # ---- emulation ----
+    z1 = b0.double() + ps.double().reshape(B, n_src, 256)[:, src] + pe.double()[None]
+    if use_dst:
+        z1 = z1 + pd.double()[dst][None]
+    h1 = _bf(torch.relu(z1).float())
+    h2 = _bf(torch.relu(h1 @ _bf(W1).t() + b1.double()).float())
+    o = h2 @ _bf(W2).t() + b2.double()
+    y = torch.nn.functional.layer_norm(o, (256,), gamma.double(), beta.double(), 1e-5) + e_res.double()[None]
+    agg_ref = torch.zeros(B, n_dst, 256, dtype=torch.float64)
+    agg_ref.index_add_(1, torch.from_numpy(dst), y)
+
+    # ---- kernel ----
+    pm = PackedMLP([W0.to(DEV), W1.to(DEV), W2.to(DEV)], [b0.to(DEV), b1.to(DEV), b2.to(DEV)], (gamma.to(DEV), beta.to(DEV)),
+                   ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+    agg = torch.zeros((B * n_dst, 256), device=DEV)
+    e_out = torch.empty((B * E, 256), device=DEV) if case != "decoder" else None
+    x_dst = Operand(pd.to(DEV), 0, 256, projected=True) if use_dst else ops.ZERO
+    ops.edge_update_forward(pm, B, torch.from_numpy(src.astype(np.int32)).to(DEV), torch.from_numpy(dst.astype(np.int32)).to(DEV),
+                            Operand(ps.to(DEV), n_src, 256, projected=True), x_dst, Operand(pe.to(DEV), 0, 256, projected=True),
+                            Operand(e_res.to(DEV), 0, 256), n_dst, agg, e_out)
+    torch.cuda.synchronize()
+    scale = agg_ref.abs().max().item()
+    err = (agg.cpu().double().reshape(B, n_dst, 256) - agg_ref).abs().max().item()
+    assert err < 3e-4 * scale, f"{case}: aggregate max err {err:.3e} vs scale {scale:.3e}"
+    if e_out is not None:
+        err_e = (e_out.cpu().double().reshape(B, E, 256) - y).abs().max().item()
+        # a bf16 rounding of one activation can fall the other way (fp32 sums here, float64 in the emulation): ~1e-3
+        assert err_e < 1.5e-3 * y.abs().max().item(), f"{case}: e' max err {err_e:.3e}"
