@@ -79,6 +79,7 @@ struct Edge16Args {
   float* e_out;
   float* agg;
   char* h1g;  // workspace: layer-1 activations, [batch * neb tiles][4 groups][8 K-steps][64 lanes][8 bf16]
+  int skip;                 // tuning aid (GW_EDGE16_SKIP): 1 = no aggregate writes (results are then wrong)
   unsigned long long* dbg;  // gw_debug_timestamps(kind 3): phase clocks of each workgroup's third tile
   int dbg_cap;
 };
@@ -377,35 +378,35 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
     if (stamp) ts[12] = gw_clock();
 
     // ---- per-feature segment sums over the 64 destination-sorted columns ----
-    // all 64 LDS reads first (independent), then the sequential walk over registers; destination ids are the same for
-    // every thread (lane i holds column i's), so the walk branches on scalars
+    // all 64 LDS reads first (independent), then a straight-line walk over registers.  Segment ends are the same for every
+    // thread: lane i compares column i's destination with column i + 1's, the ballot is a 64-bit scalar mask, and the walk
+    // tests one bit per column (a scalar branch that is rarely taken).
     {
       const int f = threadIdx.x;
       float vv[kTileCols];
 #pragma unroll
       for (int i = 0; i < kTileCols; ++i) vv[i] = stage[i * kStageLd + f];
       const int gdv = gdl[lane];
+      const int gdn = gdl[lane < kTileCols - 1 ? lane + 1 : lane];
+      const unsigned long long ends = __ballot(lane == kTileCols - 1 || gdn != gdv);  // bit i: a segment ends with column i
       if (stamp) ts[13] = gw_clock();
       float run = 0.f;
-      int cur = __builtin_amdgcn_readlane(gdv, 0);
       bool first = true;
 #pragma unroll
       for (int i = 0; i < kTileCols; ++i) {
-        const int gd = __builtin_amdgcn_readlane(gdv, i);
-        if (__builtin_expect(gd != cur, 0)) {  // segment boundary: the rare path, kept out of the straight-line walk
-          if (cur >= 0) {
+        run += vv[i];
+        if (__builtin_expect((ends >> i) & 1ull, 0)) {
+          const int cur = __builtin_amdgcn_readlane(gdv, i);
+          if (cur >= 0 && a.skip != 1) {
             float* dstp = a.agg + (size_t)cur * 256 + f;
-            if (first) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the first and the last segment of a tile may continue in the neighbouring tiles: atomics; the others are complete
+            if (first || i == kTileCols - 1) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else stg1(dstp, run);
           }
           first = false;
           run = 0.f;
-          cur = gd;
         }
-        run += vv[i];
       }
-      if (cur >= 0)
-        __hip_atomic_fetch_add((GW_AS1 float*)(a.agg + (size_t)cur * 256 + f), run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the next tile's barrier (1) separates these reads from the next Hbuf2 / staging writes
     if (stamp) {
@@ -477,6 +478,11 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.e_out = e_out;
   a.agg = agg;
   a.h1g = (char*)workspace;
+  {
+    static int skip = -1;
+    if (skip < 0) skip = env_int("GW_EDGE16_SKIP", 0);
+    a.skip = skip;
+  }
   if (g_dbg != nullptr && g_dbg_kind == 3) {
     a.dbg = g_dbg;
     a.dbg_cap = g_dbg_cap;
