@@ -359,28 +359,31 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
           }
       }
       __syncthreads();
+      // all 64 LDS reads first; run ends are a 64-bit scalar mask (lane i compares column i with column i + 1): the walk
+      // is straight-line code testing one bit per column (see gw_edge.hip)
       const int f = threadIdx.x;
+      float vv[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) vv[i] = stage[i * kStageLd16 + f];
+      const int gdv = gdl[lane];
+      const int gdn = gdl[lane < 63 ? lane + 1 : lane];
+      const unsigned long long ends = __ballot(lane == 63 || gdn != gdv);
       float run = 0.f;
-      int cur = gdl[0];
       bool first = true;
-#pragma unroll 8
-      for (int col = 0; col < 64; ++col) {
-        const int gd = gdl[col];
-        const float vv = stage[col * kStageLd16 + f];
-        if (gd != cur) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        run += vv[i];
+        if (__builtin_expect((ends >> i) & 1ull, 0)) {
+          const int cur = __builtin_amdgcn_readlane(gdv, i);
           if (cur >= 0) {
             float* dstp = a.agg + (size_t)cur * 256 + f;
-            if (first) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (first || i == 63) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else stg1(dstp, run);
           }
           first = false;
           run = 0.f;
-          cur = gd;
         }
-        run += vv;
       }
-      if (cur >= 0)
-        __hip_atomic_fetch_add((GW_AS1 float*)(a.agg + (size_t)cur * 256 + f), run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

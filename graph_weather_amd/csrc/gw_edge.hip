@@ -524,29 +524,33 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
   // segment sum: thread f owns feature f; columns are sorted by global destination id, so equal ids form runs.
   // Interior runs belong to this tile alone -> plain stores; the first and the last run may continue in the
   // neighbouring tiles -> atomics (agg is zero-filled by the caller).
+  // All 64 LDS reads are issued first; segment ends are the same for every thread, so lane i compares column i's
+  // destination with column i + 1's and the ballot gives a 64-bit scalar mask: the walk is straight-line code that tests
+  // one bit per column (a rarely taken scalar branch) instead of a data-dependent branch per column around an LDS read.
   {
     const int f = threadIdx.x;
+    float vv[kColsPerWG];
+#pragma unroll
+    for (int i = 0; i < kColsPerWG; ++i) vv[i] = lds[i * kStageLd + f];
+    const int gdv = gdl[lane];
+    const int gdn = gdl[lane < kColsPerWG - 1 ? lane + 1 : lane];
+    const unsigned long long ends = __ballot(lane == kColsPerWG - 1 || gdn != gdv);  // bit i: a run ends with column i
     float run = 0.f;
-    int cur = gdl[0];
     bool first = true;
-#pragma unroll 8
-    for (int col = 0; col < kColsPerWG; ++col) {
-      const int g = gdl[col];
-      const float vv = lds[col * kStageLd + f];
-      if (g != cur) {
+#pragma unroll
+    for (int i = 0; i < kColsPerWG; ++i) {
+      run += vv[i];
+      if (__builtin_expect((ends >> i) & 1ull, 0)) {
+        const int cur = __builtin_amdgcn_readlane(gdv, i);
         if (cur >= 0) {
           float* dstp = a.agg + (size_t)cur * 256 + f;
-          if (first) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (first || i == kColsPerWG - 1) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else stg1(dstp, run);
         }
         first = false;
         run = 0.f;
-        cur = g;
       }
-      run += vv;
     }
-    if (cur >= 0)
-      __hip_atomic_fetch_add((GW_AS1 float*)(a.agg + (size_t)cur * 256 + f), run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #undef GW_REQUEST_SLICE
 #undef GW_CONSUME_SLICE
