@@ -37,3 +37,42 @@ def test_edge_kernel_isa_has_no_scratch_and_no_hidden_load_hazards(tmp_path):
                          check=True, capture_output=True, text=True).stdout
     counts = [int(x) for x in re.findall(r"hidden-load register hazards: (\d+)", out)]
     assert len(counts) == 5 and all(c == 0 for c in counts), out[-2000:]
+
+
+@pytest.mark.timeout(600)
+def test_edge16_kernel_keeps_its_weights_in_accumulation_registers(tmp_path):
+    """csrc/gw_edge16.hip: the persistent bf16 kernel is only fast while all 256 weight registers stay in the AGPR half and
+    feed the MFMAs from there.  Checked on the generated ISA: no scratch, every MFMA takes its A
+    operand from an AGPR, no AGPR <-> VGPR copies anywhere in the tile loop, 2 layers x 4 groups x 32 MFMAs per tile, and
+    the explicit wait states around each asm MFMA batch are present (inline asm is invisible to the hazard recogniser)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graph_weather_amd", "csrc", "gw_edge16.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "e.o", "-save-temps"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+    text = (tmp_path / "gw_edge16-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    name = re.search(r"^(_Z\w*edge16_kernel\w*):", text, re.M).group(1)
+    meta = text[text.index(".amdhsa_kernel " + name):]
+    meta = meta[:meta.index(".end_amdhsa_kernel")]
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 512
+    body = text[text.index(name + ":"):]
+    body = body[:body.index(".end_amdhsa_kernel")]
+    lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+    mfma = [ln for ln in lines if ln.startswith("v_mfma_f32_16x16x32_bf16")]
+    assert len(mfma) == 256, len(mfma)
+    for ln in mfma:
+        ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
+        assert ops[1].startswith("a["), f"weight operand not in an AGPR: {ln}"
+    first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
+    loop = lines[first_barrier:]
+    assert not any(ln.startswith(("v_accvgpr_read", "v_accvgpr_write")) for ln in loop), "AGPR <-> VGPR copies in the tile loop"
+    # wait states: an s_nop directly before the first and after the last MFMA of every 32-MFMA batch
+    idx = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma")]
+    batches = [idx[i:i + 32] for i in range(0, 256, 32)]
+    for b in batches:
+        before = lines[max(0, b[0] - 3):b[0]]
+        after = lines[b[-1] + 1:b[-1] + 4]
+        assert any(ln.startswith("s_nop") for ln in before), f"no wait state before the MFMA batch at {b[0]}"
+        assert any(ln.startswith("s_nop") for ln in after), f"no wait state after the MFMA batch at {b[-1]}"
