@@ -63,3 +63,25 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_edge_update_workspace_query_is_host_logic():
+    """gw_edge_update_workspace_bytes: 32 KiB per 64-edge tile and batch element when the register-resident bf16 kernel
+    applies (bf16 weights, one middle layer, every non-zero operand pre-projected), 0 otherwise - no GPU involved."""
+    from graph_weather_amd._lib import DTYPE_BF16, DTYPE_F32, GwMlpWeights, GwOperand
+
+    L = _lib.lib()
+    proj = GwOperand(1, None, 10, 256, 256, 1)   # ptr only has to be non-null for the query
+    raw = GwOperand(1, None, 10, 256, 256, 0)
+    zero = GwOperand(None, None, 0, 0, 0, 0)
+    w = GwMlpWeights()
+    w.hidden, w.n_mid, w.n_out, w.weight_dtype, w.ln_width = 256, 1, 256, DTYPE_BF16, 0
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 3 * 3 * 32768  # ceil(130 / 64) = 3 tiles
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w) == 3 * 3 * 32768
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w) == 0   # a raw operand needs a third resident matrix
+    w.weight_dtype = DTYPE_F32
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0   # fp32: the streaming kernels, no scratch
+    w.weight_dtype, w.n_mid = DTYPE_BF16, 2
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0
+    w.n_mid, w.ln_width = 1, 128
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0   # zero-padded narrow models: general kernel
