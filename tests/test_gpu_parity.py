@@ -409,3 +409,34 @@ def test_assimilator_matches_reference_golden_and_oracle(golden_dir):
         x, ei, ea = model.encoder(feats.to(DEV), llh.to(DEV))
         y2 = model.decoder(model.processor(x, ei, ea), 1)
     _close(y2, y, rel=1e-5, what="compositional assimilator")
+
+
+def test_integration_md_operator_level_stub_runs_and_matches_the_oracle():
+    """the self-contained ctypes stub a reference maintainer would add (no dependency on the
+    graph_weather_amd Python package beyond the shared library) is executed verbatim on one message-passing block."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# graph_weather/models/layers/_gw_amd\.py.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("libgw_amd.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:_gw_amd.py", "exec"), ns)
+    gp = gw.GraphProcessor(mp_iterations=1, in_dim_node=256, in_dim_edge=256, hidden_dim_node=256, hidden_dim_edge=256)
+    deterministic_fill_(gp, seed=13)
+    p = {"gp." + k: v.clone() for k, v in gp.state_dict().items()}
+    gp = gp.to(DEV)
+    block = gp.blocks[0]  # same attribute layout as the reference's MetaLayer block: edge_model.edge_mlp / node_model.node_mlp
+    packed = (ns["pack_mlp"](block.edge_model.edge_mlp, [(0, 256), (256, 512), (512, 768)]),
+              ns["pack_mlp"](block.node_model.node_mlp, [(0, 256), (256, 512)]))
+    rs = np.random.RandomState(2)
+    n, e = 120, 700
+    x = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
+    ea = torch.from_numpy(rs.standard_normal((e, 256)).astype(np.float32))
+    ei = torch.from_numpy(np.stack([rs.randint(0, n, size=e), rs.randint(0, n, size=e)]).astype(np.int64))
+    xr, er = om.graph_processor(p, "gp", x, ei, ea)
+    with torch.no_grad():
+        xo, eo = ns["block_forward"](block, x.to(DEV), ei.to(DEV), ea.to(DEV), packed)
+    torch.cuda.synchronize()
+    _close(xo, xr, what="INTEGRATION.md stub: nodes")
+    _close(eo, er, what="INTEGRATION.md stub: edges")
