@@ -9,14 +9,14 @@ block with the layer-1 split, the processor on the latent graph, ``AssimilatorDe
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 from torch import nn
 
 from . import ops
 from .graphs import build_latent_graph, build_observation_graph
-from .layers import (FEED_ZERO, AssimilatorDecoder, Feed, GraphProcessor, MLP, Processor, _autograd_on, _check_native_dims,
+from .layers import (AssimilatorDecoder, Feed, GraphProcessor, MLP, Processor, _autograd_on, _check_native_dims,
                      _version_key)
 from .ops import Operand
 

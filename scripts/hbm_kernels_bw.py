@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from graph_weather_amd import _lib, autograd as ag
+from graph_weather_amd import autograd as ag
 from graph_weather_amd.graphs import build_forecast_graphs
 from graph_weather_amd.utils import regular_lat_lons
 

@@ -10,8 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import graph_weather_amd as gw  # noqa: E402
-from graph_weather_amd import _lib, ops  # noqa: E402
-from graph_weather_amd.graphs import build_forecast_graphs  # noqa: E402
+from graph_weather_amd import _lib  # noqa: E402
 from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features  # noqa: E402
 from oracle import reference_math as om  # noqa: E402
 
