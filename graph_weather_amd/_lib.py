@@ -49,13 +49,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "gw_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    # GW_TUNING=1 builds the A/B knobs in (env-selected kernel variants, skip switches that give wrong results - used by
+    # scripts/gpu_tune.sh / gpu_ab.sh only); the shipped library is built without them.  The flag set is recorded beside
+    # the library so that switching modes rebuilds.
+    flags = HIPCC_FLAGS + (["-DGW_TUNING"] if os.environ.get("GW_TUNING") == "1" else [])
+    stamp = LIB_PATH + ".flags"
+    want = " ".join(flags)
+    try:
+        have = open(stamp).read()
+    except OSError:
+        have = want if "-DGW_TUNING" not in want else ""
+    if (not force and os.path.exists(LIB_PATH) and have == want
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
+    cmd = [hipcc] + flags + srcs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(want)
     return LIB_PATH
 
 

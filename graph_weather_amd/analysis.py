@@ -16,7 +16,7 @@ from torch import nn
 
 from . import ops
 from .graphs import build_latent_graph, build_observation_graph
-from .layers import (AssimilatorDecoder, Feed, GraphProcessor, MLP, Processor, _autograd_on, _check_native_dims,
+from .layers import (AssimilatorDecoder, Feed, GraphProcessor, MLP, Processor, _autograd_on, _check_native_dims, _ver,
                      _version_key)
 from .ops import Operand
 
@@ -64,8 +64,8 @@ class AssimilatorEncoder(nn.Module):
     def _observation_plan(self, lat_lon_heights: torch.Tensor, device):
         """assimilator_encoder.py:166-219, once per distinct position tensor."""
         llh = lat_lon_heights.reshape(-1, 3) if lat_lon_heights.dim() == 2 else lat_lon_heights[0]
-        key = (lat_lon_heights.data_ptr(), lat_lon_heights._version, tuple(lat_lon_heights.shape), str(device))
-        if self._obs_cache is None or self._obs_cache[0] != key:
+        key = (lat_lon_heights.data_ptr(), _ver(lat_lon_heights), tuple(lat_lon_heights.shape), str(device))
+        if self._obs_cache is None or self._obs_cache[0] != key or self._obs_cache[2] is not lat_lon_heights:
             _, _, plan = build_observation_graph(llh.detach().cpu().numpy(), self.resolution)
             self._obs_cache = (key, plan.to(device), lat_lon_heights)  # holds the tensor: its address stays taken
         return self._obs_cache[1]
@@ -98,7 +98,7 @@ class AssimilatorEncoder(nn.Module):
         xm = self._cached("mesh", list(self.node_encoder.parameters()), lambda: self.node_encoder.table(zeros_in))
         e = self.edge_encoder.table(plan.edge_attr)  # depends on the observation positions: not cached across graphs
         blk = self.graph_processor.blocks[0]
-        train = _autograd_on(self)
+        train = _autograd_on(self, features)
         M = self.num_h3
         if train:
             from . import autograd as ag

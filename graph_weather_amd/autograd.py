@@ -159,20 +159,24 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
 
 
 class MLPRowsFunction(torch.autograd.Function):
-    """``MLP.forward`` on rows (graph_net_block.py:63-77) [+ a constant residual]."""
+    """``MLP.forward`` on rows (graph_net_block.py:63-77) [+ a residual: ``out + start_features``, decoder.py:93]."""
 
     @staticmethod
-    def forward(ctx, mlp, x2, residual_op, n_rows, rows_per_batch, *params):
+    def forward(ctx, mlp, x2, res, res_rows_pb, res_k, n_rows, rows_per_batch, *params):
         pm = mlp.packed()
         save = SavedActivations(pm, n_rows, x2.device)
+        residual_op = None if res is None else Operand(res, res_rows_pb, res_k)
         y = ops.mlp_forward(pm, Operand(x2, rows_per_batch, mlp.native_k()), n_rows, rows_per_batch, residual=residual_op, save=save)
         ctx.mlp, ctx.save, ctx.has_norm = mlp, save, pm.gamma is not None
-        ctx.save_for_backward(x2, *params)
+        ctx.has_res = res is not None
+        if res is not None and res.requires_grad and (res_rows_pb <= 0 or int(res.shape[0]) != n_rows):
+            raise NotImplementedError("graph_weather_amd: gradient of a residual table shared by the batch is not implemented")
+        ctx.save_for_backward(x2, res if res is not None else x2.new_zeros(0), *params)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, *params = ctx.saved_tensors
+        x2, res, *params = ctx.saved_tensors
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
                                      ctx.mlp.out_dim)
@@ -181,12 +185,67 @@ class MLPRowsFunction(torch.autograd.Function):
         gemm_tn_acc(dz0, x2, gW0)
         grads[0] = gW0
         dx = input_grad(ctx.mlp, 0, dz0, W0, 0, int(W0.shape[1])) if ctx.needs_input_grad[1] else None
-        return (None, dx, None, None, None, *grads)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[2]:
+            # y = MLP(x) + res[:, :n_out]: the identity term of d(out)/d(features) (multi-step rollouts feed the output back in)
+            n_out = int(dy.shape[1])
+            if res.shape[1] == n_out:
+                dres = dy
+            else:
+                dres = torch.zeros_like(res)
+                dres[:, :n_out] = dy
+        return (None, dx, dres, None, None, None, None, *grads)
 
 
 def mlp_rows(mlp, x2: torch.Tensor, n_rows: int, rows_per_batch: int, residual_op: Optional[Operand] = None) -> torch.Tensor:
     params = mlp.native_params()
-    return MLPRowsFunction.apply(mlp, x2, residual_op, n_rows, rows_per_batch, *params)
+    if residual_op is None:
+        return MLPRowsFunction.apply(mlp, x2, None, 0, 0, n_rows, rows_per_batch, *params)
+    return MLPRowsFunction.apply(mlp, x2, residual_op.tensor, residual_op.rows_per_batch, residual_op.k, n_rows, rows_per_batch,
+                                 *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# recomputation instead of saved activations (the reference's torch.utils.checkpoint calls: graph_net_block.py:73-74,
+# 294-297; graphcast/model.py:212-285)
+# ---------------------------------------------------------------------------------------------------------------------
+class RecomputeFunction(torch.autograd.Function):
+    """A segment of the model as ONE autograd node that keeps only its inputs: the forward runs the segment with grad mode
+    off - i.e. on the inference kernels, which save no activations - and the backward re-runs it with grad mode on (the
+    training kernels, with their activation saves, which live only until this node's backward returns) and backpropagates
+    through that replay.  Gradients of the segment's parameters are returned through autograd like any other."""
+
+    @staticmethod
+    def forward(ctx, fn, n_in, params, *tensors):
+        ctx.fn, ctx.n_in, ctx.params = fn, n_in, params
+        ctx.save_for_backward(*tensors[:n_in])
+        with torch.no_grad():
+            outs = fn(*tensors[:n_in])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n_in, params = ctx.n_in, ctx.params
+        ins = [t.detach().requires_grad_(bool(need)) for t, need in zip(ctx.saved_tensors, ctx.needs_input_grad[3:3 + n_in])]
+        with torch.enable_grad():
+            outs = ctx.fn(*ins)
+        pairs = [(o, d) for o, d in zip(outs, douts) if d is not None and o.requires_grad]
+        wanted = [t for t in ins if t.requires_grad] + [p for p in params if p.requires_grad]
+        got = iter(torch.autograd.grad([o for o, _ in pairs], wanted, [d for _, d in pairs], allow_unused=True)) if pairs and wanted \
+            else iter(())
+        g_in = [next(got, None) if t.requires_grad else None for t in ins]
+        g_par = [next(got, None) if p.requires_grad else None for p in params]
+        return (None, None, None, *g_in, *g_par)
+
+
+def recompute(fn, inputs: Sequence[torch.Tensor], module) -> Tuple[torch.Tensor, ...]:
+    """``fn(*inputs) -> tuple of tensors`` as a recomputed segment (see RecomputeFunction).  ``module`` names the parameters
+    the segment uses (an ``nn.Module`` or a list of them).  Without anything to differentiate the segment just runs."""
+    mods = module if isinstance(module, (list, tuple)) else [module]
+    params = [p for m in mods for p in m.parameters()]
+    if not torch.is_grad_enabled() or not (any(p.requires_grad for p in params) or any(t.requires_grad for t in inputs)):
+        return tuple(fn(*inputs))
+    return RecomputeFunction.apply(fn, len(inputs), params, *inputs, *params)
 
 
 class ProjectFunction(torch.autograd.Function):

@@ -406,11 +406,8 @@ __global__ void pack_linear_bf16_kernel(const float* __restrict__ w, int n_out, 
 
 template <typename K>
 int launch16(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes) {
-  static bool attr_done = false;  // per template instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEdge);
-    attr_done = true;
-  }
+  static DeviceOnce once;  // per template instantiation and device
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEdge);
   const int grid = (a.n_cols + kCols16 - 1) / kCols16;
   hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(256), lds_bytes, (hipStream_t)stream, a);
   return check_launch("chain16_kernel launch");

@@ -216,14 +216,14 @@ __device__ __forceinline__ const float* chunk_src(const EdgeArgs& a, int i) {
     const float* nsrc_ = chunk_src<RAW>(a, ci + 1);                                                            \
     _Pragma("unroll") for (int s_ = 0; s_ < kChunkSteps; ++s_) {                                               \
       f32x4 a_nxt_[4];                                                                                         \
-      if ((NEXT_EXISTS) && s_ < kDmaSteps && a.skip != 4) {                                                     \
+      if ((NEXT_EXISTS) && s_ < kDmaSteps && GW_SKIP(a) != 4) {                                                     \
         issue_pieces<8 / kDmaSteps>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, s_ * (8 / kDmaSteps), lane, wave);  \
       }                                                                                                        \
       if (s_ + 1 < kChunkSteps) {                                                                              \
         _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) a_nxt_[b4] = *(const f32x4*)(bl_ + (s_ + 1) * 1024 + b4 * 256); \
       } else if (NEXT_EXISTS) {                                                                                \
         WAIT_STMT;                                                                                             \
-        if (a.skip != 5) lds_barrier();                                                                        \
+        if (GW_SKIP(a) != 5) lds_barrier();                                                                        \
         const float* bn_ = lds + ((ci + 1) & 1) * kLdsBufFloats + lane * 4;                                    \
         _Pragma("unroll") for (int b4 = 0; b4 < 4; ++b4) a_nxt_[b4] = *(const f32x4*)(bn_ + b4 * 256);          \
       }                                                                                                        \
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     }
   }
 
-  if (a.skip >= 2) return;
+  if (GW_SKIP(a) >= 2) return;
   // ---- stage e' through LDS: [64 columns][260] + 64 global destination ids ----
   __syncthreads();  // every wave is done reading the weight buffers
   {
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     }
   }
 
-  if (a.skip >= 1) return;
+  if (GW_SKIP(a) >= 1) return;
   // segment sum: thread f owns feature f; columns are sorted by global destination id, so equal ids form runs.
   // Interior runs belong to this tile alone -> plain stores; the first and the last run may continue in the
   // neighbouring tiles -> atomics (agg is zero-filled by the caller).
@@ -571,13 +571,9 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
 
 template <typename K>
 int launch(K kernel, const EdgeArgs& a, void* stream) {
-  static bool attr_done = false;  // per template instantiation
-  static int lds_bytes = kEdgeLdsBytes;
-  if (!attr_done) {
-    lds_bytes = kEdgeLdsBytes + env_int("GW_EDGE_LDS_PAD", 0);  // tuning aid: > 15 KiB of padding forces one workgroup per CU
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    attr_done = true;
-  }
+  static DeviceOnce once;  // per template instantiation and device
+  static const int lds_bytes = kEdgeLdsBytes + GW_TUNE("GW_EDGE_LDS_PAD", 0);  // tuning aid: > 15 KiB of padding forces one workgroup per CU
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   const int grid = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, (hipStream_t)stream, a);
   return check_launch("edge_kernel launch");
@@ -601,7 +597,7 @@ bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const 
   if (w->n_mid < 1) return false;
   if (w->ln_width > 0 && w->ln_width != 256) return false;  // zero-padded narrow models: masked statistics live in the general kernel
   static int impl = -1;  // GW_EDGE_IMPL=0 forces the general chain kernel (A/B measurements, tests of both paths)
-  if (impl < 0) impl = env_int("GW_EDGE_IMPL", 1);
+  if (impl < 0) impl = GW_TUNE("GW_EDGE_IMPL", 1);
   return impl != 0;
 }
 
@@ -659,19 +655,19 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
   }
   {
     static int skip = -1;
-    if (skip < 0) skip = env_int("GW_EDGE_SKIP", 0);
+    if (skip < 0) skip = GW_TUNE("GW_EDGE_SKIP", 0);
     a.skip = skip;
   }
   {
     static int stagger_override = -2;
-    if (stagger_override == -2) stagger_override = env_int("GW_STAGGER", -1);
+    if (stagger_override == -2) stagger_override = GW_TUNE("GW_STAGGER", -1);
     const int passes = 1 + a.n_mid + (raw ? 1 : 0);
     a.stagger = stagger_override >= 0 ? stagger_override * passes : 2 * passes + 2;
     if ((a.n_cols + kColsPerWG - 1) / kColsPerWG <= 256) a.stagger = 0;
   }
   {
     static int xcd_map = -1;  // GW_XCD_MAP=0: workgroup i takes tile i (A/B measurements)
-    if (xcd_map < 0) xcd_map = env_int("GW_XCD_MAP", 1);
+    if (xcd_map < 0) xcd_map = GW_TUNE("GW_XCD_MAP", 1);
     const int tiles = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
     a.xcd_base = (xcd_map != 0 && tiles >= 64) ? tiles / 8 : 0;
     a.xcd_rem = tiles % 8;

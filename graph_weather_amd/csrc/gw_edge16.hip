@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
         run += vv[i];
         if (__builtin_expect((ends >> i) & 1ull, 0)) {
           const int cur = __builtin_amdgcn_readlane(gdv, i);
-          if (cur >= 0 && a.skip != 1) {
+          if (cur >= 0 && GW_SKIP(a) != 1) {
             float* dstp = a.agg + (size_t)cur * 256 + f;
             // the first and the last segment of a tile may continue in the neighbouring tiles: atomics; the others are complete
             if (first || i == kTileCols - 1) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -437,7 +437,7 @@ bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_
   }
   if (n_proj < 1) return false;
   static int impl = -1;  // GW_EDGE16_IMPL=0 forces the streaming kernel of gw_bf16.hip (A/B measurements, tests of both paths)
-  if (impl < 0) impl = env_int("GW_EDGE16_IMPL", 1);
+  if (impl < 0) impl = GW_TUNE("GW_EDGE16_IMPL", 1);
   return impl != 0;
 }
 
@@ -480,24 +480,21 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.h1g = (char*)workspace;
   {
     static int skip = -1;
-    if (skip < 0) skip = env_int("GW_EDGE16_SKIP", 0);
+    if (skip < 0) skip = GW_TUNE("GW_EDGE16_SKIP", 0);
     a.skip = skip;
   }
   if (g_dbg != nullptr && g_dbg_kind == 3) {
     a.dbg = g_dbg;
     a.dbg_cap = g_dbg_cap;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)edge16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
-    attr_done = true;
-  }
+  static DeviceOnce once;
+  if (once.first()) (void)hipFuncSetAttribute((const void*)edge16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
   // launch 1: one workgroup per tile, numbered like the persistent kernel walks them (XCD = workgroup & 7)
   const int units_max = (a.neb / 8 + (a.neb % 8 ? 1 : 0)) * batch;
   hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)(8 * units_max)), dim3(256), 0, (hipStream_t)stream, a);
   if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
   static int n_wg = -1;  // persistent workgroups: one per CU, a multiple of 8 (XCD round-robin)
-  if (n_wg < 0) n_wg = (env_int("GW_EDGE16_WGS", 256) + 7) / 8 * 8;
+  if (n_wg < 0) n_wg = (GW_TUNE("GW_EDGE16_WGS", 256) + 7) / 8 * 8;
   hipLaunchKernelGGL(edge16_kernel, dim3((unsigned)n_wg), dim3(256), kLdsTotal, (hipStream_t)stream, a);
   return check_launch("edge16_kernel launch");
 }

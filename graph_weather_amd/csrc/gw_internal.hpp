@@ -2,6 +2,7 @@
 #ifndef GW_INTERNAL_HPP
 #define GW_INTERNAL_HPP
 
+#include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
 #include "../../include/gw_amd.h"
@@ -70,7 +71,30 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
 extern unsigned long long* g_dbg;
 extern int g_dbg_cap;
 extern int g_dbg_kind;
+// Tuning / A-B knobs read from the environment (GW_EDGE_SKIP, GW_EDGE_IMPL, GW_STAGGER, GW_XCD_MAP, GW_EDGE_LDS_PAD, ...)
+// exist only in builds made with -DGW_TUNING (scripts/gpu_tune.sh); the shipped library has the defaults compiled in and
+// no code path that can produce wrong results.
+#ifdef GW_TUNING
 int env_int(const char* name, int fallback);
+#define GW_TUNE(name, fallback) gw::env_int(name, fallback)
+#define GW_SKIP(a) ((a).skip)
+#else
+#define GW_TUNE(name, fallback) (fallback)
+#define GW_SKIP(a) 0
+#endif
+
+// hipFuncSetAttribute is per device: one flag per (kernel instantiation, device) instead of one per process, so a second
+// GPU driven from the same process gets its dynamic-LDS limit raised too.
+struct DeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
 

@@ -579,10 +579,12 @@ int check_launch(const char* what) {
   return GW_OK;
 }
 
+#ifdef GW_TUNING
 int env_int(const char* name, int fallback) {
   const char* e = getenv(name);
   return e ? atoi(e) : fallback;
 }
+#endif
 }  // namespace gw
 
 namespace {
@@ -600,8 +602,7 @@ int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1, int kind 
   {
     static bool env_read = false;
     if (!env_read) {
-      const char* e = getenv("GW_STAGGER");
-      if (e) g_stagger_override = atoi(e);
+      g_stagger_override = GW_TUNE("GW_STAGGER", -1);
       env_read = true;
     }
     // number of 256-K passes this launch runs per tile -> about half a tile of delay (8k-cycle sleeps)
@@ -610,11 +611,8 @@ int launch_chain(K kernel, ChainArgs& a, void* stream, int grid_y = 1, int kind 
     a.stagger = g_stagger_override >= 0 ? g_stagger_override * passes : 2 * passes + 2;
     if ((a.n_cols + kColsPerWG - 1) / kColsPerWG <= 256) a.stagger = 0;
   }
-  static bool attr_done = false;  // per template instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    attr_done = true;
-  }
+  static DeviceOnce once;  // per template instantiation and device
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   const int grid = (a.n_cols + kColsPerWG - 1) / kColsPerWG;
   hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
   return check_launch("chain_kernel launch");

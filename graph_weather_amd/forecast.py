@@ -65,6 +65,11 @@ class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
         self.use_thermalizer = use_thermalizer
         if output_dim is None:
             output_dim = self.feature_dim
+        if output_dim != feature_dim:
+            # decoder.py:93 adds features[..., :feature_dim] to a [B, G, output_dim] tensor: the reference fails there with a
+            # shape error; fail at construction instead of reading the wrong residual columns
+            raise RuntimeError("graph_weather_amd: output_dim (%d) must equal feature_dim (%d): the decoder adds the input's "
+                               "first feature_dim channels to its output (decoder.py:93)" % (output_dim, feature_dim))
         self.output_dim = output_dim
         lat_lons = [tuple(ll) for ll in lat_lons]
         unique_lats = sorted(set(lat for lat, _ in lat_lons))
@@ -133,6 +138,8 @@ class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
             raise RuntimeError("graph_weather_amd: features must be on a HIP device - there is no CPU path")
         if features.dtype != torch.float32:
             raise RuntimeError("graph_weather_amd: features must be float32")
+        if features.dim() != 3 or features.shape[2] < self.output_dim:
+            raise RuntimeError("graph_weather_amd: features must be [B, nodes, >= %d channels]" % self.output_dim)
         features = features.contiguous()
         B = int(features.shape[0])
         x = self.encoder.encode(features)

@@ -3,14 +3,16 @@
 
 Same constructor arguments, sub-module names (``encoder`` / ``processor`` / ``decoder`` => same ``state_dict`` keys) and
 setters.  The forward runs the native fused path (one shared destination-sorted graph for the whole batch - what the
-reference calls ``efficient_batching`` - cached batch-independent embeddings, HIP kernels); the checkpointing flags
-trade memory for recompute in the reference and are recorded here for API parity: inference keeps no activations, and
-the training path's saved activations are documented in DESIGN.md section 6.
+reference calls ``efficient_batching`` - cached batch-independent embeddings, HIP kernels).  The checkpointing setters
+select, under autograd, which segments keep no activations and are recomputed in the backward (``autograd.recompute``:
+the segment's forward runs the inference kernels, its backward re-runs it with the activation saves) - the same
+memory-for-recompute trade as ``torch.utils.checkpoint`` in graphcast/model.py:212-285.  Inference keeps nothing anyway.
 """
 from __future__ import annotations
 
 import torch
 
+from . import autograd as ag
 from .graphs import build_forecast_graphs
 from .layers import Decoder, Encoder, Processor
 
@@ -62,19 +64,44 @@ class GraphCast(torch.nn.Module):
     def set_checkpoint_decoder(self, checkpoint_flag: bool):
         self._checkpoint_decoder = checkpoint_flag
 
+    def _encode(self, features: torch.Tensor) -> torch.Tensor:
+        return self.encoder.encode(features)
+
+    def _process(self, x: torch.Tensor, B: int, dev) -> torch.Tensor:
+        _, lat_plan = self.encoder._plans(dev)
+        e_lat = self.encoder.latent_edge_embedding(lat_plan)
+        return self.processor.graph_processor.run_plan(x, lat_plan, e_lat, True, B, False)[0]
+
+    def _decode(self, x: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
+        B, G = int(features.shape[0]), self.encoder.num_latlons
+        return self.decoder.decode(x, B, residual=features.reshape(B * G, features.shape[2]))
+
+    def _custom_forward(self, features: torch.Tensor) -> torch.Tensor:
+        """graphcast/model.py:212-262 (hierarchical checkpointing: encoder / processor / decoder segments; the processor's
+        -1 / N segments are handled inside ``GraphProcessor.run_plan``)."""
+        B, dev = int(features.shape[0]), features.device
+        grad = torch.is_grad_enabled()
+        if grad and self._checkpoint_encoder:
+            x = ag.recompute(lambda f: (self._encode(f),), (features,), self.encoder)[0]
+        else:
+            x = self._encode(features)
+        x = self._process(x, B, dev)
+        if grad and self._checkpoint_decoder:
+            return ag.recompute(lambda x_, f: (self._decode(x_, f),), (x, features), self.decoder)[0]
+        return self._decode(x, features)
+
     def forward(self, features: torch.Tensor) -> torch.Tensor:
-        """graphcast/model.py:212-286: ``decoder(processor(encoder(features)), features)`` - the input itself is the residual,
+        """graphcast/model.py:264-286: ``decoder(processor(encoder(features)), features)`` - the input itself is the residual,
         so ``input_dim`` must equal ``output_dim`` as in the reference (decoder.py:93)."""
         if not features.is_cuda:
             raise RuntimeError("graph_weather_amd: features must be on a HIP device - there is no CPU path")
+        if features.dim() != 3 or features.shape[2] != self.output_dim:
+            raise RuntimeError("graph_weather_amd: GraphCast adds its input to its output (decoder.py:93): features must be "
+                               "[B, nodes, output_dim = %d], got %s" % (self.output_dim, tuple(features.shape)))
         features = features.contiguous()
-        B = int(features.shape[0])
-        x = self.encoder.encode(features)
-        _, lat_plan = self.encoder._plans(features.device)
-        e_lat = self.encoder.latent_edge_embedding(lat_plan)
-        x, _ = self.processor.graph_processor.run_plan(x, lat_plan, e_lat, True, B, False)
-        G = self.encoder.num_latlons
-        return self.decoder.decode(x, B, residual=features.reshape(B * G, features.shape[2]))
+        if torch.is_grad_enabled() and self._checkpoint_model:  # graphcast/model.py:274-281: the whole model is one segment
+            return ag.recompute(lambda f: (self._custom_forward(f),), (features,), self)[0]
+        return self._custom_forward(features)
 
 
 class GraphCastConfig:
@@ -95,7 +122,7 @@ class GraphCastConfig:
     def balanced_checkpointing(model: GraphCast):
         model.set_checkpoint_model(False)
         model.set_checkpoint_encoder(True)
-        model.set_checkpoint_processor(3)
+        model.set_checkpoint_processor(-1)  # graphcast/model.py:318
         model.set_checkpoint_decoder(True)
 
     @staticmethod

@@ -28,7 +28,8 @@ import torch
 
 from . import mesh as _mesh
 
-__all__ = ["GraphPlan", "ForecastGraphs", "build_forecast_graphs", "plan_from_coo", "build_observation_graph", "build_latent_graph"]
+__all__ = ["GraphPlan", "ForecastGraphs", "build_forecast_graphs", "plan_from_coo", "build_observation_graph", "build_latent_graph",
+           "check_topology", "topology_hash", "provider_name"]
 
 
 @dataclass
@@ -112,6 +113,12 @@ class ForecastGraphs:
     enc_plan: GraphPlan  # src: grid rows,  dst: mesh rows (reversed rank)
     lat_plan: GraphPlan  # src/dst: mesh rows
     dec_plan: GraphPlan  # src: mesh rows (reversed rank), dst: grid rows
+    provider: str = "builtin"  # which mesh provider numbered the cells: "h3" (real h3 importable) or "builtin"
+
+    def topology_hash(self) -> str:
+        """Digest of the three edge lists: equal hashes = same mesh numbering and topology.  A checkpoint is only meaningful on
+        the topology it was trained on (real h3 for reference-trained weights); ``check_topology`` compares."""
+        return topology_hash(self.enc_edge_index, self.lat_edge_index, self.dec_edge_index)
 
     def as_oracle_dict(self) -> dict:
         return {
@@ -177,6 +184,39 @@ def _build_with_h3(lat_lons, resolution: int, h3):  # pragma: no cover - h3 abse
             np.array(ds), np.array(dd), _sincos(np.array(ddist)))
 
 
+def provider_name(provider=None) -> str:
+    provider = provider if provider is not None else _mesh.get_provider()
+    return "builtin" if isinstance(provider, _mesh.H3Like) else "h3"
+
+
+def topology_hash(*index_tensors) -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for t in index_tensors:
+        h.update(np.ascontiguousarray(t.cpu().numpy() if torch.is_tensor(t) else t, dtype=np.int64).tobytes())
+    return h.hexdigest()[:16]
+
+
+def check_topology(module, expected_hash: str, strict: bool = False) -> bool:
+    """Compare the mesh topology a model runs on with the one a checkpoint was made on (``expected_hash`` = the value of
+    ``model.encoder.graphs.topology_hash()`` when it was trained).  Mesh numbering depends on the provider: real h3 when
+    importable, the built-in geodesic mesh otherwise (mesh.get_provider) - weights trained on one are meaningless on the
+    other although the state_dict loads (the tensors have equal shapes).  Warns (or raises with ``strict``) on mismatch."""
+    import warnings
+
+    graphs = getattr(getattr(module, "encoder", module), "graphs", None)
+    have = graphs.topology_hash() if graphs is not None else None
+    if have == expected_hash:
+        return True
+    msg = ("graph_weather_amd: mesh topology %s (provider %r) differs from the checkpoint's %s - weights trained on another "
+           "mesh numbering (e.g. real h3 vs the built-in mesh) do not transfer" % (have, getattr(graphs, "provider", "?"), expected_hash))
+    if strict:
+        raise RuntimeError(msg)
+    warnings.warn(msg)
+    return False
+
+
 def build_forecast_graphs(lat_lons, resolution: int = 2, provider=None) -> ForecastGraphs:
     provider = provider if provider is not None else _mesh.get_provider()
     if isinstance(provider, _mesh.H3Like):
@@ -193,13 +233,30 @@ def build_forecast_graphs(lat_lons, resolution: int = 2, provider=None) -> Forec
         enc_plan=plan_from_coo(es, ed - G, G, M, ea),
         lat_plan=plan_from_coo(ls, ld, M, M, la),
         dec_plan=plan_from_coo(ds, dd - M, M, G, da),
+        provider=provider_name(provider),
     )
 
 
 
-def build_latent_graph(resolution: int = 2):
+def _h3_base(h3, resolution: int):  # pragma: no cover - h3 absent in this image
+    base = sorted(list(h3.uncompact_cells(h3.get_res0_cells(), resolution)))
+    return base, {c: i for i, c in enumerate(base)}
+
+
+def build_latent_graph(resolution: int = 2, provider=None):
     """Latent mesh graph alone (assimilator_encoder.py:221-242 = encoder.py:244-268): (edge_index [2, E] int64 in reference
-    order, edge_attr [E, 2], dst-sorted plan)."""
+    order, edge_attr [E, 2], dst-sorted plan).  Same mesh provider as ``build_forecast_graphs`` (real h3 when importable),
+    so that every graph of one model numbers the cells the same way."""
+    provider = provider if provider is not None else _mesh.get_provider()
+    if not isinstance(provider, _mesh.H3Like):  # pragma: no cover - literal loops of encoder.py:255-263 over real h3
+        base, rank = _h3_base(provider, resolution)
+        ls, ld, dl = [], [], []
+        for c in base:
+            for hcell in provider.grid_disk(c, 1):
+                ls.append(rank[c]); ld.append(rank[hcell])
+                dl.append(provider.great_circle_distance(provider.cell_to_latlng(c), provider.cell_to_latlng(hcell), unit="rads"))
+        src, dst, attr = np.array(ls, dtype=np.int64), np.array(ld, dtype=np.int64), _sincos(np.array(dl))
+        return (torch.from_numpy(np.stack([src, dst])), torch.from_numpy(attr), plan_from_coo(src, dst, len(base), len(base), attr))
     m = _mesh.get_mesh(resolution)
     M = m.num
     ptr, idx = m.disk1_csr()
@@ -210,12 +267,23 @@ def build_latent_graph(resolution: int = 2):
     return (torch.from_numpy(np.stack([src, dst]).astype(np.int64)), torch.from_numpy(attr), plan_from_coo(src, dst, M, M, attr))
 
 
-def build_observation_graph(lat_lon_heights, resolution: int = 2):
+def build_observation_graph(lat_lon_heights, resolution: int = 2, provider=None):
     """Bipartite observation -> mesh graph of the assimilation encoder (assimilator_encoder.py:166-219): observation i is
     connected to the cell that contains it, at row ``N + (M - 1 - rank(cell))`` of the [observations ; mesh] table;
     edge attributes [sin d, cos d, height].  Returns (edge_index [2, N] int64 in reference order, edge_attr [N, 3],
     dst-sorted plan over (observation rows, mesh rows))."""
     llh = np.asarray(lat_lon_heights, dtype=np.float64).reshape(-1, 3)
+    provider = provider if provider is not None else _mesh.get_provider()
+    if not isinstance(provider, _mesh.H3Like):  # pragma: no cover - literal loops of assimilator_encoder.py:166-219 over real h3
+        base, rank = _h3_base(provider, resolution)
+        N, M = llh.shape[0], len(base)
+        cells = [provider.latlng_to_cell(float(a), float(b), resolution) for a, b, _ in llh]
+        d = np.array([provider.great_circle_distance((float(llh[i, 0]), float(llh[i, 1])), provider.cell_to_latlng(c), unit="rads")
+                      for i, c in enumerate(cells)])
+        attr = np.stack([np.sin(d), np.cos(d), llh[:, 2]], axis=1).astype(np.float32)
+        src = np.arange(N, dtype=np.int64)
+        dst_row = np.array([M - 1 - rank[c] for c in cells], dtype=np.int64)
+        return (torch.from_numpy(np.stack([src, dst_row + N])), torch.from_numpy(attr), plan_from_coo(src, dst_row, N, M, attr))
     m = _mesh.get_mesh(resolution)
     N, M = llh.shape[0], m.num
     cell = m.locate(llh[:, 0], llh[:, 1])

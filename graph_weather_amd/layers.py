@@ -29,13 +29,23 @@ from .ops import Operand, PackedMLP
 _NORMS = ["LayerNorm", "GraphNorm", "InstanceNorm", "BatchNorm", "MessageNorm"]
 
 
+def _ver(t: torch.Tensor) -> int:
+    """Version counter of a tensor for cache keys.  Tensors created under ``torch.inference_mode()`` carry no counter
+    (reading ``_version`` raises): they get -1, i.e. the cache then trusts the tensor's identity (the caches hold the tensor
+    object itself, so its address cannot be recycled) - an in-place change of an inference tensor between two calls is not
+    detectable by anybody, autograd included."""
+    return -1 if t.is_inference() else t._version
+
+
 def _version_key(params) -> tuple:
-    return tuple((p.data_ptr(), p._version, p.device) for p in params)
+    return tuple((p.data_ptr(), _ver(p), p.device) for p in params)
 
 
-def _autograd_on(module: nn.Module) -> bool:
-    """True when the call must be differentiable: grad mode on and the module has trainable parameters."""
-    on = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+def _autograd_on(module: nn.Module, *inputs: Optional[torch.Tensor]) -> bool:
+    """True when the call must be differentiable: grad mode on and either the module has trainable parameters or one of the
+    given input tensors requires grad (a frozen block downstream of a trainable one must still pass gradients through)."""
+    on = torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters())
+                                      or any(t is not None and t.requires_grad for t in inputs))
     if on:
         for m in module.modules():
             if isinstance(m, MLP) and m.compute_dtype != torch.float32:
@@ -94,7 +104,9 @@ class MLP(nn.Module):
     def __init__(self, in_dim: int, out_dim: int = 128, hidden_dim: int = 128, hidden_layers: int = 2,
                  norm_type: Optional[str] = "LayerNorm", use_checkpointing: bool = False):
         super().__init__()
-        self.use_checkpointing = use_checkpointing  # forward-only kernels save nothing: flag kept for API parity
+        # graph_net_block.py:73-74: under autograd, keep no activations of this MLP and recompute them in the backward
+        # (autograd.recompute); inference keeps nothing anyway
+        self.use_checkpointing = use_checkpointing
         layers: List[nn.Module] = [nn.Linear(in_dim, hidden_dim), nn.ReLU()]
         for _ in range(hidden_layers - 1):
             layers += [nn.Linear(hidden_dim, hidden_dim), nn.ReLU()]
@@ -215,7 +227,13 @@ class MLP(nn.Module):
             x2 = torch.nn.functional.pad(x2, (0, k - x2.shape[1]))  # inputs of 113..255 features: zero columns
         if residual is not None and self.native_out() != self.out_dim:
             raise NotImplementedError("graph_weather_amd: a fused residual needs an output head of at most 80 features")
-        if _autograd_on(self) or (torch.is_grad_enabled() and x2.requires_grad):
+        if _autograd_on(self, x2, None if residual is None else residual.tensor):
+            if self.use_checkpointing:  # graph_net_block.py:73-74: keep nothing, recompute this MLP in the backward
+                if residual is None:
+                    return ag.recompute(lambda x_: (ag.mlp_rows(self, x_, n_rows, rows_per_batch),), (x2,), self)[0]
+                return ag.recompute(lambda x_, r_: (ag.mlp_rows(self, x_, n_rows, rows_per_batch,
+                                                               residual_op=Operand(r_, residual.rows_per_batch, residual.k)),),
+                                    (x2, residual.tensor), self)[0]
             return ag.mlp_rows(self, x2, n_rows, rows_per_batch, residual_op=residual)
         return ops.mlp_forward(self.packed(), Operand(x2, rows_per_batch, k), n_rows, rows_per_batch, residual=residual)
 
@@ -269,7 +287,7 @@ class GraphNetBlock(nn.Module):
         Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``).
         ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch)."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
-        if _autograd_on(self):
+        if _autograd_on(self, x_src.tensor, x_dst.tensor, e_in.tensor, e_res, x_node.tensor, x_res):
             agg, e_out = ag.edge_update(self.edge_model.edge_mlp, plan, batch, (x_src.spec(), x_dst.spec(), e_in.spec()),
                                         want_edges, x_src.tensor, x_dst.tensor, e_in.tensor, e_res, e_res_rows_pb)
             x_new = ag.node_update(self.node_model.node_mlp, batch * n_dst, n_dst, x_node.spec(), x_node.tensor, x_res,
@@ -322,6 +340,7 @@ class GraphProcessor(nn.Module):
         for _ in range(mp_iterations):
             self.blocks.append(build_graph_processor_block(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge,
                                                            hidden_layers_node, hidden_layers_edge, norm_type))
+        self.checkpoint_segments = 0  # processor.py:70-81, set through Processor.set_checkpoint_segments
         self._plan_cache = None
         self._e0_cache = None
 
@@ -330,19 +349,55 @@ class GraphProcessor(nn.Module):
                  want_edges: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """Layer 1 of every edge MLP is split (cat[x_s, x_d, e].W1^T = x_s.Ws^T + x_d.Wd^T + e.We^T): the node
         products are computed once per node (shared by its ~7 incident edges) and gathered per edge; when the
-        incoming edge features are batch independent (first block after the encoder) their product is cached."""
+        incoming edge features are batch independent (first block after the encoder) their product is cached.
+
+        Under autograd, ``use_checkpointing`` (graph_net_block.py:294-297: one checkpoint per block) and
+        ``checkpoint_segments`` (processor.py:70-81: -1 = the whole stack, N > 0 = every N blocks) select recomputation:
+        the segment's forward runs the inference kernels and keeps only its inputs; its backward re-runs it with the
+        activation saves (autograd.recompute)."""
         _check_native_dims(*self._dims)
+        nb = len(self.blocks)
+        seg = 0
+        if _autograd_on(self, x, e):
+            if self.checkpoint_segments == -1:
+                seg = nb
+            elif self.checkpoint_segments > 0:
+                seg = int(self.checkpoint_segments)
+            elif self.use_checkpointing:
+                seg = 1
+        if seg <= 0 or nb == 0:
+            x, e_cur, _ = self._run_blocks(0, nb, x, e, e_shared, plan, batch, want_edges)
+            return x, (e_cur if want_edges else None)
+        e_cur, shared = e, e_shared
+        for lo in range(0, nb, seg):
+            hi = min(nb, lo + seg)
+            need_e = want_edges or hi < nb
+
+            def fn(x_, e_, lo=lo, hi=hi, shared=shared, need_e=need_e):
+                xo, eo, _ = self._run_blocks(lo, hi, x_, e_, shared, plan, batch, need_e)
+                return (xo, eo) if need_e else (xo,)
+
+            outs = ag.recompute(fn, (x, e_cur), nn.ModuleList(list(self.blocks)[lo:hi]))
+            x = outs[0]
+            if need_e:
+                e_cur, shared = outs[1], False
+        return x, (e_cur if want_edges else None)
+
+    def _run_blocks(self, lo: int, hi: int, x: torch.Tensor, e: torch.Tensor, e_shared: bool, plan: GraphPlan, batch: int,
+                    want_edges: bool):
+        """Blocks [lo, hi) of the stack; returns (x, e, e_shared) after them (e of the last block only if ``want_edges``)."""
         n, n_edges = plan.n_dst, plan.num_edges
         e_cur, shared = e, e_shared
-        train = _autograd_on(self)
-        for i, blk in enumerate(self.blocks):
-            last = i == len(self.blocks) - 1
+        train = _autograd_on(self, x, e)
+        for i in range(lo, hi):
+            blk = self.blocks[i]
+            last = i == hi - 1
             mlp_e = blk.edge_model.edge_mlp
+            agg_buf = None
             if train:
                 ps, pd = ag.project(mlp_e, (0, 1), x, batch * n, n)
             else:
                 pm_e = mlp_e.packed()
-                agg_buf = None
                 if mlp_e.compute_dtype == torch.float32:  # the projection launch also zero-fills this block's aggregate
                     agg_buf = torch.empty((batch * n, 256), dtype=torch.float32, device=x.device)
                 ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n, zero_rows=agg_buf)
@@ -350,8 +405,8 @@ class GraphProcessor(nn.Module):
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
                 else:
-                    key = (e_cur.data_ptr(), e_cur._version, blk.params_key())
-                    if self._e0_cache is None or self._e0_cache[0] != key:
+                    key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key())
+                    if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
                         pe = ops.project_forward([mlp_e.packed().w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
                         self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
                     pe = self._e0_cache[1]
@@ -360,14 +415,14 @@ class GraphProcessor(nn.Module):
                 e_in = Feed(e_cur, n_edges, "raw")
             x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_cur, 0 if shared else n_edges,
                                Feed(x, n, "raw"), x, n, want_edges or not last, x.device, tag="processor_edge",
-                               agg_zeroed=None if train else agg_buf)
+                               agg_zeroed=agg_buf)
             if e_new is not None:
                 e_cur, shared = e_new, False
-        return x, (e_cur if want_edges else None)
+        return x, e_cur, shared
 
     def _plan_for(self, edge_index: torch.Tensor, num_nodes: int) -> GraphPlan:
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, num_nodes)
-        if self._plan_cache is not None and self._plan_cache[0] == key:
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), _ver(edge_index), num_nodes)
+        if self._plan_cache is not None and self._plan_cache[0] == key and self._plan_cache[2] is edge_index:
             return self._plan_cache[1]
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise RuntimeError("edge_index must be [2, E] in COO format")
@@ -527,8 +582,11 @@ class Processor(nn.Module):
                                               hidden_layers_processor_edge, mlp_norm_type, use_checkpointing)
 
     def set_checkpoint_segments(self, checkpoint_segments: int):
-        """processor.py:70-81 (forward-only kernels keep no activations; value is recorded for API parity)."""
+        """processor.py:70-81: 0 = per-block checkpointing as configured by ``use_checkpointing``; -1 = the whole processor
+        is one recomputed segment; N > 0 = one segment per N blocks (the reference documents N > 0 as not yet
+        implemented - here it is).  Takes effect under autograd (``GraphProcessor.run_plan``)."""
         self.checkpoint_segments = checkpoint_segments
+        self.graph_processor.checkpoint_segments = checkpoint_segments
 
     def forward(self, x: torch.Tensor, edge_index, edge_attr, t: int = 0, batch_size: int = None,
                 efficient_batching: bool = False) -> torch.Tensor:
@@ -605,7 +663,7 @@ class AssimilatorDecoder(nn.Module):
         # lat/lon rows are zeros (assimilator_decoder.py:84,190-192): x_dst = 0, node input [0 | agg], residual 0.
         # Layer 1 of the edge MLP is then relu(Ws.x[src] + (We.e + b)): a gather-add of a per-mesh-node product and a
         # cached batch-independent per-edge product - no matrix work per edge in layer 1.
-        train = _autograd_on(self)
+        train = _autograd_on(self, processor_features)
         mlp_e = blk.edge_model.edge_mlp
         n_e = plan.num_edges
         if train:
@@ -623,6 +681,9 @@ class AssimilatorDecoder(nn.Module):
                         tag="decoder_edge")
         res = None
         if residual is not None:
+            if residual.dim() != 2 or residual.shape[0] != B * G or residual.shape[1] < self.output_dim:
+                raise RuntimeError("graph_weather_amd: the residual (start features) must have batch*num_latlons rows of at least "
+                                   "output_dim = %d features, got %s" % (self.output_dim, tuple(residual.shape)))
             res = Operand(residual, G, self.output_dim)
         y = self.node_decoder.run(xg, B * G, G, residual=res)
         if y.shape[1] != self.output_dim:

@@ -43,6 +43,26 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device_of(t: torch.Tensor):
+    """Context that makes ``t``'s GPU the current HIP device for the C-ABI call inside it: kernels are launched on the
+    stream of ``t.device`` and a launch on a stream of a non-current device fails.  Free when it already is current."""
+    idx = t.device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
+
+
 def _require(t: torch.Tensor, name: str, dtype=torch.float32):
     if not t.is_cuda:
         raise RuntimeError(f"graph_weather_amd: {name} must live on a HIP device (no CPU path exists)")
@@ -114,6 +134,8 @@ class PackedMLP:
             if tuple(w.shape) != (self.hidden, self.hidden):
                 raise RuntimeError("graph_weather_amd: hidden layers must be square")
         st = torch.cuda.current_stream(dev).cuda_stream
+        guard = on_device_of(weights[0])
+        guard.__enter__()  # every packing launch below runs with the weights' GPU current (released at the end of __init__)
 
         def pack(w, k_lo, k_hi):
             w = w.detach().contiguous().float()
@@ -156,6 +178,7 @@ class PackedMLP:
 
         self.gamma = pad(pad_head(ln[0])) if ln is not None else None
         self.beta = pad(pad_head(ln[1])) if ln is not None else None
+        guard.__exit__(None, None, None)
 
     def c(self, active: Sequence[bool] = (True, True, True)) -> GwMlpWeights:
         w = GwMlpWeights()
@@ -186,8 +209,9 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
     rc = residual.c() if residual is not None else None
     if rc is not None:
         rc.k = pm.n_out
-    _lib.check(_lib.lib().gw_mlp_forward(n_rows, max(1, rows_per_batch), xc, wc, rc, out.data_ptr(), int(out.stride(0)),
-                                         None if save is None else save.c(), _stream(out)), "gw_mlp_forward")
+    with on_device_of(out):
+        _lib.check(_lib.lib().gw_mlp_forward(n_rows, max(1, rows_per_batch), xc, wc, rc, out.data_ptr(), int(out.stride(0)),
+                                             None if save is None else save.c(), _stream(out)), "gw_mlp_forward")
     return out
 
 
@@ -205,10 +229,11 @@ def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, r
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     if weight_dtype is None:
         weight_dtype = _lib.DTYPE_BF16 if w_slices[0].dtype == torch.bfloat16 else _lib.DTYPE_F32
-    _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, weight_dtype,
-                                             None if relu_mask is None else relu_mask.data_ptr(),
-                                             None if zero_rows is None else zero_rows.data_ptr(), _stream(outs[0])),
-               "gw_project_forward")
+    with on_device_of(outs[0]):
+        _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, weight_dtype,
+                                                 None if relu_mask is None else relu_mask.data_ptr(),
+                                                 None if zero_rows is None else zero_rows.data_ptr(), _stream(outs[0])),
+                   "gw_project_forward")
     return outs
 
 
@@ -230,11 +255,12 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
         if ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=agg.device)
     ev = TIMER.start(tag) if TIMER is not None else None
-    _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), xs, xd, ei,
-                                                 e_res.c(), wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(),
-                                                 n_dst, None if save is None else save.c(), None if ws is None else ws.data_ptr(),
-                                                 ws_bytes, _stream(agg)),
-               "gw_edge_update_forward")
+    with on_device_of(agg):
+        _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), xs, xd, ei,
+                                                     e_res.c(), wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(),
+                                                     n_dst, None if save is None else save.c(),
+                                                     None if ws is None else ws.data_ptr(), ws_bytes, _stream(agg)),
+                   "gw_edge_update_forward")
     if ev is not None:
         TIMER.stop(tag, ev)
 
@@ -247,9 +273,10 @@ def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Oper
         out = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=dev)
     _require(out, "out")
     wc = pm.c((x.k > 0 and not x.projected, True, False))
-    _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), x_res.c(), agg.c(), wc, out.data_ptr(),
-                                                 int(out.stride(0)), None if save is None else save.c(), _stream(out)),
-               "gw_node_update_forward")
+    with on_device_of(out):
+        _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), x_res.c(), agg.c(), wc, out.data_ptr(),
+                                                     int(out.stride(0)), None if save is None else save.c(), _stream(out)),
+                   "gw_node_update_forward")
     return out
 
 
@@ -272,8 +299,9 @@ def normalized_mse_forward(pred: torch.Tensor, target: torch.Tensor, lat_weights
         elif inv_var.numel() != c:
             raise RuntimeError("graph_weather_amd: 1 / feature_variance must be per channel [C] or shaped like pred")
     loss = torch.zeros((), dtype=torch.float32, device=pred.device)
-    _lib.check(_lib.lib().gw_normalized_mse_forward(pred.data_ptr(), target.data_ptr(),
-                                                    None if inv_var is None else inv_var.data_ptr(), full, lat_weights.data_ptr(),
-                                                    int(lat_weights.numel()), b, nodes, c, loss.data_ptr(), _stream(pred)),
-               "gw_normalized_mse_forward")
+    with on_device_of(pred):
+        _lib.check(_lib.lib().gw_normalized_mse_forward(pred.data_ptr(), target.data_ptr(),
+                                                        None if inv_var is None else inv_var.data_ptr(), full, lat_weights.data_ptr(),
+                                                        int(lat_weights.numel()), b, nodes, c, loss.data_ptr(), _stream(pred)),
+                   "gw_normalized_mse_forward")
     return loss

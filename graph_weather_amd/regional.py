@@ -346,7 +346,10 @@ class RegionalForecaster(nn.Module):
         enc_plan, lat_plan, dec_plan, rows = self.graph_builder.native_plans(lat_lons, dev)
         token = (self.graph_builder.generation, str(dev))
         C = enc_plan.n_dst
-        train = _autograd_on(self)
+        train = _autograd_on(self, features)
+        if F < self.output_dim:
+            raise RuntimeError("graph_weather_amd: features need at least output_dim = %d channels for the residual "
+                               "(regional_forecast.py:283-284)" % self.output_dim)
         _check_native_dims(*self.encoder_gnn._dims)
         _check_native_dims(*self.decoder_gnn._dims)
         feats = features.reshape(B * N, F)

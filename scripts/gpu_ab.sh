@@ -3,6 +3,8 @@
 TAG=${1:-ab}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+export GW_TUNING=1  # the env knobs exist only in tuning builds (-DGW_TUNING)
+python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1 || echo BUILD FAILED
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -n 15 $OUT/pytest_gpu.log
 for impl in 1 0; do
   GW_EDGE_IMPL=$impl timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_impl$impl.log 2>&1

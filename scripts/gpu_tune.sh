@@ -4,6 +4,7 @@
 TAG=$1; VAR=$2; shift 2
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+export GW_TUNING=1  # the env knobs exist only in tuning builds (-DGW_TUNING)
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1 || echo BUILD FAILED
 for v in "$@"; do
   env $VAR=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_${VAR}_$v.log 2>&1
