@@ -255,6 +255,8 @@ def get_provider():
     try:  # pragma: no cover - h3 is absent in this image
         import h3  # type: ignore
 
+        if getattr(h3, "__version__", None) is None:  # a stand-in module (oracle/refload.py registers one), not h3-py
+            return H3Like()
         return h3
     except Exception:
         return H3Like()
