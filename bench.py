@@ -4,14 +4,22 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one forward pass of the hot path over one batch of synthetic input that is already resident in HBM.
-Workload at every N = BASELINE.json configs[1] per GPU: 1 degree grid (64 800 nodes), 102 -> 78 features,
-batch 2, fp32 arithmetic (fp32-in / fp32-accumulate MFMA), random-init weights.  Batch elements are independent,
-so N GPUs run N independent shards with no data-path collective (weak scaling); value = all forecasts / max time.
+Default workload at every N = BASELINE.json configs[1] per GPU ("c2"): 1 degree grid (64 800 nodes), 102 -> 78 features,
+batch 2, fp32 arithmetic (fp32-in / fp32-accumulate MFMA), random-init weights.  Batch elements are independent, so N GPUs
+run N independent shards with no data-path collective (weak scaling); value = all forecasts / max-over-ranks time.
+
+Other configurations of BASELINE.json (--config): c3 = same grid, bf16 matrix products, batch 16; c4 = global batch 64 sharded
+over the ranks (8 per GPU at N = 8; strong scaling); c5 = 0.25 degree grid, mesh resolution 3, batch 1.
 
 Prints ONE JSON line with the driver contract fields plus
-  "roofline":     dominant kernel (decoder edge update) - algorithmic FLOPs per launch / HIP-event duration vs the
-                  fp32 matrix peak of gfx950 (157.3 TFLOP/s), and
-  "cpu_baseline": the CPU oracle (port of the reference forward, replicated-graph semantics) on this host.
+  "roofline":     the dominant kernel (decoder edge update): EXECUTED matrix FLOPs per launch / HIP-event duration against the
+                  MFMA peak of the arithmetic dtype (frac <= 1); the figure on the reference's algorithmic FLOPs (which the
+                  layer-1 split legally does not execute) is kept under algorithmic_*; step_frac = the whole forward;
+  "cold_ms_per_step": a forward right after the weights changed (every per-weight-version cache misses: edge / mesh embeddings
+                  and their layer-1 products recomputed, weights re-packed) - what the reference pays on every forward;
+  "extra":        c3 and c5 measured in the same run (N = 1 only), each with value, ms_per_step and its dominant kernel;
+  "cpu_baseline": the CPU oracle (port of the reference forward) on this host: batch 2, 1 warm-up + 3 timed forwards, mean
+                  and min, replicated-graph semantics (what the reference executes) with the shared-graph variant beside it.
 """
 from __future__ import annotations
 
@@ -29,51 +37,87 @@ import torch  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 acc
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
+PEAK_HBM_TBS = 8.0
+D = 256
 EDGE_MLP_FLOPS = 2 * (768 * 256 + 256 * 256 + 256 * 256)  # per edge, SURVEY.md 8(d): mlp(768,256,256) - algorithmic
-# What the decoder edge kernel executes on the matrix cores after the layer-1 split: x_dst == 0 and the x_src / e
-# products are gathered (per-node product, cached per-edge product) -> only the two 256x256 layers remain per edge.
-DEC_EDGE_EXECUTED_FLOPS = 2 * (256 * 256 + 256 * 256)
+LAYER = 2 * D * D  # one 256 x 256 layer on one column
+
+CONFIGS = {
+    "c2": dict(grid=1.0, resolution=2, batch=2, precision="fp32"),
+    "c3": dict(grid=1.0, resolution=2, batch=16, precision="bf16"),
+    "c4": dict(grid=1.0, resolution=2, batch=64, precision="fp32"),  # global batch, sharded over the ranks
+    "c5": dict(grid=0.25, resolution=3, batch=1, precision="fp32"),
+}
 
 
-def cpu_baseline(lat_lons, state, graphs, budget_s=30.0):
-    """Oracle forward (what the reference executes: replicated graph, fp32, eval) on the host cores.
-    Bounded sample: one forecast (batch 1) of the same 1 degree workload, timed at a few thread counts (torch's
-    default = every core is rarely the fastest for these scatter/GEMM sizes); the best one is reported."""
+def executed_flops_per_forecast(graphs) -> dict:
+    """Matrix FLOPs the kernels execute per forecast (default dims) after the layer-1 split, by stage.  Per column: one
+    256x256 layer = 131 072 FLOP.  Batch-independent products (edge / mesh embeddings and their layer-1 products) are cached
+    per weight version in eval and are not in this count (they are what cold_ms_per_step adds)."""
+    G, M = graphs.num_grid, graphs.num_mesh
+    e_enc, e_lat, e_dec = graphs.enc_plan.num_edges, graphs.lat_plan.num_edges, graphs.dec_plan.num_edges
+    enc = G * 2 * (112 * D + D * D + D * D) + e_enc * 3 * LAYER + M * 3 * LAYER  # node encoder (K padded to 112), edge (raw x_src), node (raw agg)
+    proc = 0
+    for b in range(9):
+        proc += M * 2 * LAYER  # P_s, P_d
+        proc += e_lat * (2 if b == 0 else 3) * LAYER  # block 0: e is batch shared (product cached)
+        proc += M * 4 * LAYER  # node update: x raw + agg raw + 2 layers
+    dec = M * LAYER + e_dec * 2 * LAYER + G * 3 * LAYER + G * 2 * (D * 128 + 128 * 128 + 128 * 80)
+    return {"encoder": enc, "processor": proc, "decoder": dec, "total": enc + proc + dec}
+
+
+def algorithmic_flops_per_forecast(graphs) -> float:
+    """model-definition math on live rows."""
+    G, M = graphs.num_grid, graphs.num_mesh
+    e_enc, e_lat, e_dec = graphs.enc_plan.num_edges, graphs.lat_plan.num_edges, graphs.dec_plan.num_edges
+
+    def mlp(i, h, o, rows):
+        return 2 * rows * (i * h + h * h + h * o)
+
+    enc = mlp(102, D, D, G) + mlp(768, D, D, e_enc) + mlp(512, D, D, M)
+    proc = 9 * (mlp(768, D, D, e_lat) + mlp(512, D, D, M))
+    dec = mlp(768, D, D, e_dec) + mlp(512, D, D, G) + 2 * G * (D * 128 + 128 * 128 + 128 * 78)
+    return enc + proc + dec
+
+
+def cpu_baseline(lat_lons, state, graphs):
+    """SURVEY.md 8(d) protocol: the oracle forward (port of the reference; fp32, eval, no_grad) on this host's cores, batch 2,
+    1 warm-up + 3 timed forwards, mean and min; replicated-graph semantics (what the reference executes by default) and the
+    shared-graph variant (encoder.py:168-196 ...) beside it, to separate the reference's replicated-graph waste from the
+    hardware ratio.  Threads: 32 (measured round 1: faster than all 256 logical CPUs for these scatter / GEMM sizes)."""
     from graph_weather_amd.utils import seeded_features
     from oracle import reference_math as om
 
-    feats = seeded_features(1, len(lat_lons), 102, seed=42)
+    feats = seeded_features(2, len(lat_lons), 102, seed=42)
     g = graphs.as_oracle_dict()
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    cands = []
-    for t in (default_threads, max(1, ncpu // 4), 32, 16):  # all physical cores, one socket, 32, 16
-        if 1 <= t <= ncpu and t not in cands:
-            cands.append(t)
-    results = []
-    t_start = time.perf_counter()
-    for i, t in enumerate(cands):
-        torch.set_num_threads(t)
-        with torch.no_grad():
-            if i == 0:
-                om.forecaster_forward(state, g, feats)  # warm-up (allocator, MKL init)
-            t0 = time.perf_counter()
-            om.forecaster_forward(state, g, feats)
-            results.append((time.perf_counter() - t0, t))
-        if time.perf_counter() - t_start > budget_s:
-            break
+    threads = max(1, min(32, ncpu))
+    torch.set_num_threads(threads)
+    res = {}
+    with torch.no_grad():
+        for name, shared in (("replicated", False), ("shared", True)):
+            om.forecaster_forward(state, g, feats, shared=shared)  # warm-up
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                om.forecaster_forward(state, g, feats, shared=shared)
+                ts.append(time.perf_counter() - t0)
+            res[name] = ts
     torch.set_num_threads(default_threads)
-    best, threads = min(results)
-    return {"value": 1.0 / best, "unit": "forecasts/s", "cores": threads, "kind": "port",
-            "sample": "one 1 degree forecast (batch 1, fp32, torch CPU oracle = port of the reference forward), 1 warm-up, "
-                      "timed once per thread count " + ", ".join(f"{t}t: {s:.2f}s" for s, t in results)
-                      + f"; host has {ncpu} logical CPUs"}
+    rep, sh = res["replicated"], res["shared"]
+    mean = sum(rep) / len(rep)
+    return {"value": 2.0 / mean, "unit": "forecasts/s", "cores": threads, "kind": "port",
+            "value_best": 2.0 / min(rep), "shared_graph_value": 2.0 / (sum(sh) / len(sh)), "shared_graph_value_best": 2.0 / min(sh),
+            "sample": "1 degree, batch 2, fp32 torch CPU oracle (port of the reference forward): 1 warm-up + 3 timed forwards per "
+                      "variant; replicated graph (reference default) " + ", ".join(f"{t:.2f}s" for t in rep)
+                      + "; shared graph " + ", ".join(f"{t:.2f}s" for t in sh) + f"; {threads} threads of {ncpu} logical CPUs"}
 
 
-def pmc_traffic():
+def pmc_traffic(name="pmc_decoder_edge.json"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE applied by scripts/gpu_pmc.sh).  None if not collected."""
-    p = os.path.join(ROOT, "profiles", "pmc_decoder_edge.json")
+    p = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(p))
         if d.get("hbm_read_bytes") is None or d.get("hbm_write_bytes") is None:
@@ -83,25 +127,140 @@ def pmc_traffic():
         return None, None
 
 
-def train_bench(args, model, feats, lat_lons, dev, world, rank):
+def build_model(cfg, dev):
+    import graph_weather_amd as gw
+    from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons
+
+    lat_lons = regular_lat_lons(cfg["grid"])
+    model = gw.GraphWeatherForecaster(lat_lons, resolution=cfg["resolution"])
+    deterministic_fill_(model, seed=0)
+    return model, lat_lons
+
+
+def time_forward(model, feats, steps, warmup, barrier, kernel_timer=True):
+    """W untimed steps, then exactly K steps between barrier + synchronise; HIP events around the tagged edge launches."""
+    from graph_weather_amd import ops
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            y = model(feats)
+        ops.TIMER = ops.KernelTimer(["decoder_edge", "processor_edge", "encoder_edge"]) if kernel_timer else None
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = model(feats)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    assert torch.isfinite(y).all()
+    return elapsed, timer
+
+
+def cold_step_ms(model, feats, n=3):
+    """Forward right after every parameter's version changed: all per-weight-version caches miss (layers.py: packed weights,
+    edge / mesh embeddings, their layer-1 products)."""
+    from graph_weather_amd.optim import _bump_versions
+
+    ts = []
+    with torch.no_grad():
+        for _ in range(n):
+            _bump_versions(model.parameters())  # what an optimizer step does to Tensor._version (no kernel launched)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model(feats)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+    return 1e3 * sum(ts) / len(ts)
+
+
+def kernel_report(graphs, batch, precision, timer, ms_per_step):
+    """roofline object: dominant kernel = decoder edge update (one C-ABI call; in bf16 mode it is two launches: gather +
+    persistent matrix kernel, timed together)."""
+    peak = PEAK_F32_MATRIX_TFLOPS if precision == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+    e_dec, e_lat = graphs.dec_plan.num_edges, graphs.lat_plan.num_edges
+    dec_ms = timer.mean_ms("decoder_edge")
+    proc_ms = timer.mean_ms("processor_edge")
+    executed = 2 * LAYER * e_dec * batch  # the two 256x256 layers; layer 1 is a gather-add of cached / per-node products
+    algorithmic = EDGE_MLP_FLOPS * e_dec * batch
+    ex = executed_flops_per_forecast(graphs)
+    # algorithmic HBM bytes of one decoder edge launch: per (sample, edge) the cached product row and the residual edge-feature
+    # row (2 x 1 KiB), per destination row one 1 KiB sum written; indices 8 B per edge
+    alg_bytes = batch * e_dec * (2 * 1024 + 8) + batch * graphs.num_grid * 1024
+    # gather / scatter stage of one processor block (SURVEY.md 8d): 2 E D 4 + 2 M D 4 bytes per sample (fp32 storage)
+    gs_bytes = batch * (2 * e_lat * D * 4 + 2 * graphs.num_mesh * D * 4)
+    ach = executed / (dec_ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "kernel": "decoder edge update (gw_edge_update_forward on the mesh->grid graph)",
+        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "basis": "EXECUTED matrix FLOPs per launch (2 x 256x256 layers per edge and sample) / HIP-event duration",
+        "launch_ms": dec_ms, "executed_flops_per_launch": executed,
+        "algorithmic_flops_per_launch": algorithmic, "algorithmic_tflops": algorithmic / (dec_ms * 1e-3) / 1e12,
+        "algorithmic_frac": algorithmic / (dec_ms * 1e-3) / 1e12 / peak,
+        "algorithmic_note": "reference edge MLP 768->256->256->256 per edge (SURVEY.md 8d); 60 % of it (layer 1) is removed by the "
+                            "layer-1 split (x_dst == 0, per-node and cached per-edge products), so this ratio may exceed 1",
+        "algorithmic_bytes_per_launch": alg_bytes, "hbm_tbs": alg_bytes / (dec_ms * 1e-3) / 1e12,
+        "step_frac": ex["total"] * batch / (ms_per_step * 1e-3) / 1e12 / peak,
+        "step_executed_gflop": ex["total"] * batch / 1e9,
+        "other_kernels_ms": {"processor_edge": proc_ms, "encoder_edge": timer.mean_ms("encoder_edge")},
+        "gather_scatter": {"kernel": "processor edge update (one block)", "algorithmic_bytes": gs_bytes, "launch_ms": proc_ms,
+                           "achieved_tbs": gs_bytes / (proc_ms * 1e-3) / 1e12, "peak_tbs": PEAK_HBM_TBS,
+                           "frac": gs_bytes / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                           "executed_tflops": 3 * LAYER * e_lat * batch / (proc_ms * 1e-3) / 1e12},
+    }
+
+
+def run_extra(name, dev, steps, warmup):
+    """One of the other BASELINE configurations on this GPU (N = 1): value, ms_per_step, dominant kernel."""
+    import gc
+
+    from graph_weather_amd.utils import seeded_features
+
+    cfg = CONFIGS[name]
+    t0 = time.perf_counter()
+    model, lat_lons = build_model(cfg, dev)
+    graphs = model.encoder.graphs
+    build_s = time.perf_counter() - t0
+    model = model.to(dev).eval()
+    if cfg["precision"] == "bf16":
+        model.set_compute_dtype(torch.bfloat16)
+    feats = seeded_features(cfg["batch"], len(lat_lons), 102, seed=42).to(dev)
+    gc.collect()
+    elapsed, timer = time_forward(model, feats, steps, warmup, torch.cuda.synchronize)
+    ms = 1e3 * elapsed / steps
+    r = kernel_report(graphs, cfg["batch"], cfg["precision"], timer, ms)
+    out = {"workload": f"{cfg['grid']:g}deg grid ({len(lat_lons)} nodes), mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), "
+                       f"batch {cfg['batch']}, {cfg['precision']}",
+           "value": cfg["batch"] * steps / elapsed, "unit": "forecasts/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+           "graph_build_s": build_s, "dominant_kernel": r["kernel"], "launch_ms": r["launch_ms"], "frac": r["frac"], "peak": r["peak"],
+           "step_frac": r["step_frac"], "other_kernels_ms": r["other_kernels_ms"], "gather_scatter_frac": r["gather_scatter"]["frac"],
+           "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
+           "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}
+    del model, feats
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_bench(args, cfg, batch, model, feats, lat_lons, dev, world, rank):
     """Training step of the same workload (not the BASELINE metric; reported with its own metric name): forward under
-    autograd, NormalizedMSELoss, backward, gradient all-reduce across ranks (one flat RCCL collective), HIP AdamW."""
+    autograd, NormalizedMSELoss, backward into a flat gradient buffer, bucketed gradient all-reduce across ranks (RCCL), one
+    multi-tensor AdamW launch."""
     import graph_weather_amd as gw
     from graph_weather_amd import sharding as sh
 
     ctx = sh.ShardContext(rank, int(os.environ.get("LOCAL_RANK", "0")), world, "nccl" if world > 1 else None)
     model.train()
     crit = gw.NormalizedMSELoss([1.0] * 78, lat_lons, normalize=False)
-    opt = gw.AdamW(model.parameters(), lr=1e-4)
-    target = torch.randn(args.batch, len(lat_lons), 78, device=dev)
-    params = list(model.parameters())
+    flat = sh.FlatGradients(model.parameters())
+    opt = gw.AdamW(model.parameters(), lr=1e-4, flat=flat)
+    target = torch.randn(batch, len(lat_lons), 78, device=dev)
 
     def step():
+        flat.zero_()
         loss = crit(model(feats), target)
         loss.backward()
-        sh.allreduce_gradients(ctx, params)
+        flat.allreduce(ctx)
         opt.step()
-        opt.zero_grad(set_to_none=True)
         return loss
 
     for _ in range(args.warmup):
@@ -113,69 +272,89 @@ def train_bench(args, model, feats, lat_lons, dev, world, rank):
     sh.barrier(ctx, dev)
     elapsed = sh.max_over_ranks(ctx, time.perf_counter() - t0, dev)
     assert torch.isfinite(loss)
+    total = sh.sum_over_ranks(ctx, batch, dev)
     if rank == 0:
         print(json.dumps({
             "metric": "training samples/sec (1° grid, 102→78 feat): forward + loss + backward + grad all-reduce + AdamW",
-            "value": world * args.batch * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": total * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if args.config == "c4" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"GraphWeatherForecaster {args.grid:g}deg training step, batch={args.batch} per GPU, fp32",
-                       "global_batch": world * args.batch, "parallelism": f"data parallel x{world}, one flat gradient all-reduce (RCCL)"},
+            "config": {"workload": f"GraphWeatherForecaster {cfg['grid']:g}deg training step ({args.config}), batch={batch} on rank 0, fp32",
+                       "global_batch": int(total), "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (RCCL) on a flat buffer"},
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    sh.shutdown(ctx)
 
 
-def main():
+def main(argv=None, backend="nccl", device=None, model_factory=None):
+    """``backend`` / ``device`` / ``model_factory`` exist for the world-2 gloo test (tests/test_sharding.py), which drives this
+    very function on CPU with a stand-in model: rank / launch / barrier / max-over-ranks / JSON path are then what is tested."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", type=float, default=1.0, help="grid spacing in degrees (1.0 = BASELINE configs[1])")
-    ap.add_argument("--batch", type=int, default=2, help="batch per GPU")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
-                    help="matrix-product dtype: fp32 = BASELINE configs[1] (default), bf16 = configs[2] (use --batch 16)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configuration: c2 (default, the metric's config: 1deg fp32 batch 2 per GPU), c3 (bf16, batch 16 "
+                         "per GPU), c4 (global batch 64 sharded over the ranks), c5 (0.25deg, mesh res 3, batch 1 per GPU)")
+    ap.add_argument("--grid", type=float, default=None, help="override the grid spacing in degrees")
+    ap.add_argument("--batch", type=int, default=None, help="override the batch per GPU")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None, help="override the matrix-product dtype")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE metric (default); train = forward + loss + backward + gradient all-reduce + AdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c5 measurements and the cold-cache step")
+    args = ap.parse_args(argv)
+
+    from graph_weather_amd import sharding as sh
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = device is None
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device(device)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
-    import graph_weather_amd as gw
-    from graph_weather_amd import ops
-    from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features
+    from graph_weather_amd.utils import seeded_features
 
-    lat_lons = regular_lat_lons(args.grid)
-    model = gw.GraphWeatherForecaster(lat_lons)
-    deterministic_fill_(model, seed=0)
+    cfg = dict(CONFIGS[args.config])
+    if args.grid is not None:
+        cfg["grid"] = args.grid
+    if args.precision is not None:
+        cfg["precision"] = args.precision
+    if args.config == "c4":  # global batch sharded over the ranks (8 per GPU at N = 8): strong scaling
+        lo, hi = sh.shard_range(cfg["batch"] if args.batch is None else args.batch, world, rank)
+        batch = hi - lo
+    else:
+        batch = cfg["batch"] if args.batch is None else args.batch
+    model, lat_lons = (model_factory or build_model)(cfg, dev)
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     graphs = model.encoder.graphs
     model = model.to(dev).eval()
-    if args.precision == "bf16":
+    if cfg["precision"] == "bf16":
         model.set_compute_dtype(torch.bfloat16)
-    feats = seeded_features(args.batch, len(lat_lons), 102, seed=42 + rank).to(dev)  # resident in HBM before timing
+    feats = seeded_features(batch, len(lat_lons), 102, seed=42 + rank).to(dev)  # resident in HBM before timing
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     if args.mode == "train":
-        return train_bench(args, model, feats, lat_lons, dev, world, rank)
+        return train_bench(args, cfg, batch, model, feats, lat_lons, dev, world, rank)
     # A full Python garbage collection walks the model's large host-side containers (64 800 lat/lon tuples, grid
     # mappings) and takes ~130 ms - longer than 15 steps; freeze the existing heap so that no cyclic-GC pass over it
     # lands inside the timed region (standard practice for latency benchmarks; the steps themselves create no cycles).
@@ -183,55 +362,47 @@ def main():
 
     gc.collect()
     gc.freeze()
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            y = model(feats)
-        ops.TIMER = ops.KernelTimer(["decoder_edge", "processor_edge", "encoder_edge"])
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = model(feats)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    timer, ops.TIMER = ops.TIMER, None
-    assert torch.isfinite(y).all()
+    elapsed, timer = time_forward(model, feats, args.steps, args.warmup, barrier, kernel_timer=on_gpu)
+    total_batch = batch
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, float(batch)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        elapsed, total_batch = float(t[0].item()), int(round(t[1].item()))
 
     if rank == 0:
-        e_dec = graphs.dec_plan.num_edges
-        dec_ms = timer.mean_ms("decoder_edge")
-        flops = EDGE_MLP_FLOPS * e_dec * args.batch
-        achieved = flops / (dec_ms * 1e-3) / 1e12
-        executed = DEC_EDGE_EXECUTED_FLOPS * e_dec * args.batch / (dec_ms * 1e-3) / 1e12
-        traffic, pmc = pmc_traffic() if (args.grid == 1.0 and args.batch == 2 and args.precision == "fp32") else (None, None)
-        peak = PEAK_F32_MATRIX_TFLOPS if args.precision == "fp32" else PEAK_BF16_MATRIX_TFLOPS
-        # algorithmic HBM bytes of one decoder edge launch: per (sample, edge) the cached product row and the residual
-        # edge-feature row (2 x 1 KiB), per destination row one 1 KiB sum written; indices 8 B per edge
-        alg_bytes = args.batch * e_dec * (2 * 1024 + 8) + args.batch * len(lat_lons) * 1024
+        ms = 1e3 * elapsed / args.steps
+        prec = cfg["precision"]
+        roof = None
+        if timer is not None:
+            roof = kernel_report(graphs, batch, prec, timer, ms)
+            is_c2 = (cfg["grid"] == 1.0 and batch == 2 and prec == "fp32")
+            traffic, pmc = pmc_traffic() if is_c2 else (None, None)
+            roof["traffic"] = traffic
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/pmc_decoder_edge.json)"
+            roof["mfma_busy_frac_pmc"] = None if pmc is None else pmc.get("mfma_busy_frac")
         out = {
-            "metric": "forward forecasts/sec (1° grid, 102→78 feat)", "value": world * args.batch * args.steps / elapsed,
+            "metric": "forward forecasts/sec (1° grid, 102→78 feat)", "value": total_batch * args.steps / elapsed,
             "unit": "forecasts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA operands; fp32 accumulate, fp32 storage / LayerNorm / sums)",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None,
+            "dtype": "f32" if prec == "fp32" else "bf16 (MFMA operands; fp32 accumulate, LayerNorm, residuals, sums)",
             "data": "synthetic",
-            "config": {"workload": f"GraphWeatherForecaster {args.grid:g}deg grid ({len(lat_lons)} nodes), 102->78 feat, "
-                                   f"batch={args.batch} per GPU, {args.precision}, mesh res 2 (5882 nodes), random-init weights",
-                       "global_batch": world * args.batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
-            "roofline": {"bound": "mfma", "kernel": "edge_kernel (decoder edge update)", "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/pmc_decoder_edge.json)",
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "mfma_busy_frac_pmc": None if pmc is None else pmc.get("mfma_busy_frac"), "launch_ms": dec_ms, "algorithmic_flops_per_launch": flops,
-                         "executed_tflops": executed, "executed_frac": executed / peak,
-                         "note": "achieved/frac use the ALGORITHMIC flops of the reference edge MLP (768->256->256->256 per "
-                                 "edge); the kernel legally executes fewer (layer-1 split), executed_* is the MFMA work it runs",
-                         "other_kernels_ms": {"processor_edge": timer.mean_ms("processor_edge"),
-                                              "encoder_edge": timer.mean_ms("encoder_edge")}},
+            "config": {"workload": f"{args.config}: GraphWeatherForecaster {cfg['grid']:g}deg grid ({len(lat_lons)} nodes), 102->78 feat, "
+                                   f"batch={batch} on rank 0, {prec}, mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), random-init weights",
+                       "global_batch": total_batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
+            "roofline": roof,
+            "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_extra and on_gpu:
+            out["cold_ms_per_step"] = cold_step_ms(model, feats)
+            out["cold_note"] = ("forward right after every parameter changed: packed weights, edge / mesh embeddings and their layer-1 "
+                                "products are rebuilt (the reference recomputes the embeddings on every forward)")
+        if world == 1 and not args.no_extra and args.config == "c2" and on_gpu:
+            del model, feats
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["extra"] = {"c3": run_extra("c3", dev, steps=10, warmup=3), "c5": run_extra("c5", dev, steps=5, warmup=2)}
+        if world == 1 and not args.no_cpu_baseline and cfg["grid"] == 1.0:
             out["cpu_baseline"] = cpu_baseline(lat_lons, cpu_state, graphs)
         else:
             out["cpu_baseline"] = None

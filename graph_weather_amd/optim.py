@@ -7,16 +7,48 @@ import torch
 from . import _lib
 
 
+def _bump_versions(params) -> None:
+    """The kernel updates parameters through raw pointers; the packed-weight / embedding caches of the modules key on
+    ``Tensor._version``, so it is advanced here - without launching anything."""
+    ps = tuple(params)
+    torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
+
+
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """``flat``: a ``sharding.FlatGradients`` that owns the parameters and gradients as views of two flat buffers - the whole
+    model is then updated by ONE kernel launch per step (one per parameter tensor otherwise: 215 for the forecaster)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat = flat
+        if flat is not None:
+            if flat.param is None:
+                raise ValueError("graph_weather_amd.AdamW: flat must own the parameters (FlatGradients(flatten_params=True))")
+            mine = {id(p) for g in self.param_groups for p in g["params"] if p.requires_grad}
+            if len(self.param_groups) != 1 or mine != {id(p) for p in flat.params}:
+                raise ValueError("graph_weather_amd.AdamW: flat must cover exactly the parameters of the single parameter group")
+            self._flat_state = {"step": 0, "exp_avg": torch.zeros_like(flat.param), "exp_avg_sq": torch.zeros_like(flat.param)}
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         L = _lib.lib()
+        if self.flat is not None:
+            f, st, group = self.flat, self._flat_state, self.param_groups[0]
+            if not f.views_intact():
+                raise RuntimeError("graph_weather_amd.AdamW: a parameter or gradient is no longer a view of the flat buffers "
+                                   "(use flat.zero_() instead of zero_grad(set_to_none=True); build FlatGradients after model.to())")
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            with torch.cuda.device(f.param.device):
+                _lib.check(L.gw_adamw_step(f.numel, f.param.data_ptr(), f.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                           st["exp_avg_sq"].data_ptr(), group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                           st["step"], torch.cuda.current_stream(f.param.device).cuda_stream), "gw_adamw_step")
+            _bump_versions(f.params)
+            return loss
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            done = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -29,9 +61,10 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 g = p.grad.contiguous()
-                _lib.check(L.gw_adamw_step(p.numel(), p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                           group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
-                                           torch.cuda.current_stream(p.device).cuda_stream), "gw_adamw_step")
-                p._version  # noqa: B018  (in-place update through the raw pointer: bump the version below)
-                p.add_(0)   # version bump so that packed-weight caches notice the new values
+                with torch.cuda.device(p.device):
+                    _lib.check(L.gw_adamw_step(p.numel(), p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                               group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
+                                               torch.cuda.current_stream(p.device).cuda_stream), "gw_adamw_step")
+                done.append(p)
+            _bump_versions(done)
         return loss

@@ -114,10 +114,114 @@ def whole_job_rate(ctx: ShardContext, units_this_rank: float, elapsed_max: float
     return sum_over_ranks(ctx, units_this_rank, device) / elapsed_max
 
 
+class FlatGradients:
+    """Parameters and gradients of a model as views into two persistent flat fp32 buffers (data-parallel training step,
+    SURVEY.md 8e / train/run.py:509-521).
+
+    * every ``p.grad`` is a view of ``self.grad`` and stays one: autograd accumulates into it in place, ``zero_()`` is a
+      single fill, nothing is concatenated or copied back around the collective;
+    * every ``p.data`` is (by default) a view of ``self.param``, so the optimizer updates the whole model with ONE kernel
+      launch over the flat buffers (``graph_weather_amd.AdamW(..., flat=...)``) instead of one per tensor;
+    * gradients are all-reduced in buckets laid out in REVERSE parameter order - the order the backward produces them -
+      and each bucket's collective is launched (asynchronously: RCCL over xGMI on GPUs, gloo in the CPU tests) from a
+      post-accumulate hook as soon as its last gradient has been written, i.e. while the backward of the earlier layers is
+      still running; ``allreduce()`` after ``backward()`` only waits and averages.
+    xGMI rings are per-link bound, so the buckets are few and large (default 8 MiB: 4 collectives for the 30.9 MB model)."""
+
+    def __init__(self, params, bucket_bytes: int = 8 << 20, flatten_params: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradients: no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("FlatGradients: parameters must share one device and dtype")
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4  # 16-byte aligned slices
+        self.numel = off
+        self.grad = torch.zeros(off, dtype=dt, device=dev)
+        self.param = None
+        with torch.no_grad():
+            if flatten_params:
+                self.param = torch.zeros(off, dtype=dt, device=dev)
+                for p, o in zip(self.params, self.offsets):
+                    view = self.param[o:o + p.numel()].view_as(p)
+                    view.copy_(p)
+                    p.data = view
+            for p, o in zip(self.params, self.offsets):
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+        # buckets over the flat buffer, from its tail (last parameters = first gradients of the backward) to its head
+        self.buckets = []  # (lo, hi, n_params)
+        hi, n, self._bucket_of = off, 0, [0] * len(self.params)
+        for i in range(len(self.params) - 1, -1, -1):
+            self._bucket_of[i] = len(self.buckets)
+            n += 1
+            if (hi - self.offsets[i]) * self.grad.element_size() >= bucket_bytes or i == 0:
+                self.buckets.append((self.offsets[i], hi, n))
+                hi, n = self.offsets[i], 0
+        self._pending = [b[2] for b in self.buckets]
+        self._handles = [None] * len(self.buckets)
+        self._ctx: Optional[ShardContext] = None
+        self.collectives = 0
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i: int):
+        def hook(param):
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and self._ctx is not None and self._ctx.world > 1:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int) -> None:
+        import torch.distributed as dist
+
+        lo, hi, _ = self.buckets[b]
+        self._handles[b] = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        self.collectives += 1
+
+    def attach(self, ctx: ShardContext) -> "FlatGradients":
+        """Arm the overlap: from now on a bucket's all-reduce starts inside ``backward()`` when its last gradient lands."""
+        self._ctx = ctx
+        return self
+
+    def views_intact(self) -> bool:
+        """False when something replaced a ``p.grad`` / ``p.data`` view (``zero_grad(set_to_none=True)``, ``model.to(...)``)."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
+                return False
+            if self.param is not None and p.data_ptr() != self.param.data_ptr() + o * self.param.element_size():
+                return False
+        return True
+
+    def zero_(self) -> None:
+        """One fill for every gradient; re-arms the bucket counters for the next backward."""
+        self.grad.zero_()
+        self._pending = [b[2] for b in self.buckets]
+        self._handles = [None] * len(self.buckets)
+
+    def allreduce(self, ctx: ShardContext) -> int:
+        """Average the gradients over the ranks: launch the buckets the backward has not already launched, wait for all of
+        them, scale by 1 / world (one kernel over the flat buffer).  Returns the number of collectives of this step."""
+        if ctx.world == 1:
+            return 0
+        self._ctx = ctx
+        n = 0
+        for b in range(len(self.buckets)):
+            if self._handles[b] is None:
+                self._launch(b)
+            n += 1
+        for h in self._handles:
+            h.wait()
+        self.grad.div_(ctx.world)
+        return n
+
+
 def allreduce_gradients(ctx: ShardContext, params, bucket_bytes: int = 64 << 20) -> int:
-    """Data-parallel gradient step: average the gradients of ``params`` over the ranks with one all-reduce
-    per flat bucket (RCCL over xGMI on GPUs, gloo in the CPU tests).  The whole model is 7.7 M fp32 gradients = 30.9 MB,
-    i.e. a single bucket: xGMI rings are per-link bound, so fewer, larger collectives are the right shape.
+    """Gradient averaging for parameters that are NOT views of a ``FlatGradients`` buffer (generic fallback; the training
+    bench uses ``FlatGradients``): one all-reduce per flat bucket, gradients copied in and out.
     Returns the number of collectives issued (0 for world == 1)."""
     if ctx.world == 1:
         return 0

@@ -63,3 +63,52 @@ def test_edge16_matches_bf16_emulation(case):
         err_e = (e_out.cpu().double().reshape(B, E, 256) - y).abs().max().item()
         # a bf16 rounding of one activation can fall the other way (fp32 sums here, float64 in the emulation): ~1e-3
         assert err_e < 1.5e-3 * y.abs().max().item(), f"{case}: e' max err {err_e:.3e}"
+
+
+@pytest.mark.parametrize("use_dst", [False, True])
+def test_edge16_against_the_oracle(use_dst):
+    """The same launches against the ORACLE (oracle/reference_math.py: EdgeProcessor.forward + scatter_sum in full precision
+    from the raw node / edge rows), not against a model of the kernel: the layer-1 products the kernel gathers are made from
+    the raw rows here, so split, gather, both resident layers, LayerNorm, residual and segment sums are all inside the
+    comparison.  Error budget of bf16 operands: 2e-2 of the output scale."""
+    from graph_weather_amd.utils import deterministic_fill_
+    from oracle import reference_math as om
+    import graph_weather_amd as gw
+
+    rs = np.random.RandomState(11 + int(use_dst))
+    B, n_src, n_dst, E = 3, 60, 45, 700
+    ep = gw.EdgeProcessor(256, 256, 256, 2, "LayerNorm")
+    deterministic_fill_(ep, seed=17)
+    p = {"blk.edge_model." + k: v.clone() for k, v in ep.state_dict().items()}
+    x_src = torch.from_numpy(rs.standard_normal((B, n_src, 256)).astype(np.float32))
+    x_dst = torch.from_numpy(rs.standard_normal((n_dst, 256)).astype(np.float32)) if use_dst else torch.zeros(n_dst, 256)
+    e = torch.from_numpy(rs.standard_normal((E, 256)).astype(np.float32))  # batch-shared edge features (encoder / decoder case)
+    dst = np.sort(np.where(rs.rand(E) < 0.35, n_dst // 3, rs.randint(0, n_dst, size=E)))
+    src = rs.randint(0, n_src, size=E)
+    st, dt = torch.from_numpy(src), torch.from_numpy(dst)
+    # oracle, per sample
+    e_ref, agg_ref = [], []
+    for b in range(B):
+        en = om.edge_processor(p, "blk.edge_model", x_src[b][st], x_dst[dt], e)
+        e_ref.append(en)
+        agg_ref.append(om.scatter_sum(en, dt, n_dst))
+    e_ref, agg_ref = torch.stack(e_ref), torch.stack(agg_ref)
+    # kernel: layer-1 products from the raw rows (fp64 product, fp32 table - what gw_project_forward hands over in fp32 mode)
+    W0 = ep.edge_mlp.model[0].weight.detach().double()
+    ps = (x_src.double().reshape(B * n_src, 256) @ W0[:, :256].t()).float()
+    pd = (x_dst.double() @ W0[:, 256:512].t()).float()
+    pe = (e.double() @ W0[:, 512:].t()).float()
+    lin = [m for m in ep.edge_mlp.model if isinstance(m, torch.nn.Linear)]
+    norm = ep.edge_mlp.model[-1]
+    pm = PackedMLP([l.weight.detach().to(DEV) for l in lin], [l.bias.detach().to(DEV) for l in lin],
+                   (norm.weight.detach().to(DEV), norm.bias.detach().to(DEV)), ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+    agg = torch.zeros((B * n_dst, 256), device=DEV)
+    e_out = torch.empty((B * E, 256), device=DEV)
+    ops.edge_update_forward(pm, B, st.int().to(DEV), dt.int().to(DEV), Operand(ps.to(DEV), n_src, 256, projected=True),
+                            Operand(pd.to(DEV), 0, 256, projected=True) if use_dst else ops.ZERO,
+                            Operand(pe.to(DEV), 0, 256, projected=True), Operand(e.to(DEV), 0, 256), n_dst, agg, e_out)
+    torch.cuda.synchronize()
+    err_e = (e_out.cpu().reshape(B, E, 256) - e_ref).abs().max().item() / e_ref.abs().max().item()
+    err_a = (agg.cpu().reshape(B, n_dst, 256) - agg_ref).abs().max().item() / agg_ref.abs().max().item()
+    print(f"[edge16 vs oracle] use_dst={use_dst}: e' max-rel {err_e:.2e}, aggregate max-rel {err_a:.2e}")
+    assert 1e-5 < err_e <= 2e-2 and err_a <= 2e-2

@@ -212,3 +212,24 @@ def test_regional_forecaster_matches_reference_golden(golden_dir):
     yn = om.regional_forward(p, g, feats, 78, global_context=ctx, lat_lons=lat_lons)
     assert (yn - torch.from_numpy(gold["y_nudged"])).abs().max().item() < 2e-5
     assert (yn - y).abs().mean().item() > 0.1  # the nudging layer does something
+
+
+def test_chunked_oracle_equals_whole_tensor_oracle():
+    """oracle/chunked.py (slab-wise, decoder on a row sample) is the same arithmetic as the whole-tensor oracle: all rows at
+    10 degree with slabs far smaller than the graphs, and a row sample."""
+    from oracle import chunked as oc
+
+    lat_lons = regular_lat_lons(10.0)
+    graphs = build_forecast_graphs(lat_lons, 2)
+    p = make_params(forecaster_param_shapes(graphs.num_mesh), seed=3)
+    feats = seeded_features(2, len(lat_lons), seed=4)
+    g = graphs.as_oracle_dict()
+    with torch.no_grad():
+        y = om.forecaster_forward(p, g, feats)
+    rows_all = torch.arange(len(lat_lons))
+    y_all = oc.forecaster_rows(p, g, feats, rows_all, slab=1000)
+    scale = (y - feats[..., :78]).abs().max().item()
+    assert (y_all - y).abs().max().item() <= 2e-6 * scale
+    rows = torch.from_numpy(np.random.RandomState(0).choice(len(lat_lons), size=50, replace=False)).long()
+    y_s = oc.forecaster_rows(p, g, feats[1:], rows, slab=4096)
+    assert (y_s[0] - y[1][rows]).abs().max().item() <= 2e-6 * scale

@@ -88,3 +88,126 @@ def test_world_size_two_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+# ---- bench.py's own main() under a world-2 gloo group, with a stand-in model ------------------------------------------------------
+class _StubEncoder(torch.nn.Module):
+    def __init__(self, graphs):
+        super().__init__()
+        self.graphs = graphs
+
+
+class _StubForecaster(torch.nn.Module):
+    """Stands for GraphWeatherForecaster in the launch-path test: same call signature and attributes bench.py reads
+    (``encoder.graphs``), a per-sample function on the CPU (the HIP kernels cannot run here)."""
+
+    def __init__(self, lat_lons):
+        super().__init__()
+        from graph_weather_amd.graphs import build_forecast_graphs
+
+        self.encoder = _StubEncoder(build_forecast_graphs(lat_lons, 2))
+        self.w = torch.nn.Parameter(torch.full((78,), 0.5))
+
+    def forward(self, features):
+        import time
+
+        time.sleep(0.005 * (1 + int(os.environ.get("RANK", "0"))))  # rank 1 is slower: the reported time must be its time
+        return features[..., :78] * self.w
+
+
+def _stub_factory(cfg, dev):
+    from graph_weather_amd.utils import regular_lat_lons
+
+    lat_lons = regular_lat_lons(30.0)
+    return _StubForecaster(lat_lons), lat_lons
+
+
+def _bench_worker(rank: int, world: int, port: int, out_dir: str, config: str):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import contextlib
+    import io
+
+    import bench
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "2", "--config", config, "--no-cpu-baseline"],
+                   backend="gloo", device="cpu", model_factory=_stub_factory)
+    with open(os.path.join(out_dir, f"out{rank}.txt"), "w") as fh:
+        fh.write(buf.getvalue())
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("config,per_rank,scaling", [("c2", [2, 2], "weak"), ("c4", [32, 32], "strong")])
+def test_bench_main_world_two_gloo(tmp_path, config, per_rank, scaling):
+    """The rank / launch / barrier / max-over-ranks / one-JSON-line path of bench.py itself: rank 0 alone prints, value is
+    all ranks' forecasts over the slowest rank's time, c4 shards the global batch of 64 over the ranks."""
+    import json
+
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), config), nprocs=world, join=True)
+    out0 = (tmp_path / "out0.txt").read_text().strip().splitlines()
+    out1 = (tmp_path / "out1.txt").read_text().strip()
+    assert out1 == "" and len(out0) == 1
+    d = json.loads(out0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == scaling
+    assert d["config"]["global_batch"] == sum(per_rank)
+    assert d["unit"] == "forecasts/s" and d["cpu_baseline"] is None and d["roofline"] is None
+    # slowest rank sleeps 10 ms per step: 4 steps >= 40 ms, so value <= global batch * 4 / 0.04
+    assert d["ms_per_step"] >= 10.0 * 0.9
+    assert abs(d["value"] - sum(per_rank) * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+
+
+def _flat_worker(rank: int, world: int, port: int, out_dir: str):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from graph_weather_amd import sharding as sh
+
+    ctx = sh.init_from_env(backend="gloo")
+    torch.manual_seed(0)  # same weights on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 3))
+    ref = [p.detach().clone() for p in model.parameters()]
+    flat = sh.FlatGradients(model.parameters(), bucket_bytes=256).attach(ctx)  # several buckets
+    assert len(flat.buckets) >= 3 and flat.views_intact(), flat.buckets
+    for p, r in zip(model.parameters(), ref):
+        assert torch.equal(p, r)  # flattening keeps the values
+    torch.manual_seed(100 + rank)  # different data per rank
+    x, y = torch.randn(16, 6), torch.randn(16, 3)
+    for it in range(2):
+        flat.zero_()
+        loss = (model(x) - y).square().mean()
+        loss.backward()
+        launched_in_backward = flat.collectives
+        n = flat.allreduce(ctx)
+        assert n == len(flat.buckets) and flat.views_intact()
+        assert launched_in_backward >= (it + 1) * len(flat.buckets)  # every bucket's collective started from its hook
+    # the averaged gradient equals the mean of the per-rank gradients computed the plain way
+    import torch.distributed as dist
+
+    model2 = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 3))
+    with torch.no_grad():
+        for p2, r in zip(model2.parameters(), ref):
+            p2.copy_(r)
+    (model2(x) - y).square().mean().backward()
+    for p, p2 in zip(model.parameters(), model2.parameters()):
+        g = p2.grad.clone()
+        dist.all_reduce(g)
+        assert torch.allclose(p.grad, g / world, atol=1e-6)
+    sh.shutdown(ctx)
+    with open(os.path.join(out_dir, f"flat{rank}"), "w") as fh:
+        fh.write("ok")
+
+
+@pytest.mark.timeout(180)
+def test_flat_gradient_buckets_overlap_world_two_gloo(tmp_path):
+    """FlatGradients: parameters / gradients as views of flat buffers, bucketed all-reduce launched from the backward."""
+    world = 2
+    mp.spawn(_flat_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"flat{r}").exists() for r in range(world))
