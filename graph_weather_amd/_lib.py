@@ -15,13 +15,15 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 DTYPE_F32, DTYPE_BF16 = 0, 1
+LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16 = 0, 1
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
     "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector",
-    "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_node_update_forward",
+    "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
+    "gw_edge_rows_to_tiles", "gw_node_update_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
     "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step", "gw_nudging_forward", "gw_nudging_backward",
 ]
@@ -31,7 +33,7 @@ GEMM_NN, GEMM_TN = 0, 1
 
 class GwOperand(Structure):
     _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("rows_per_batch", c_int32), ("ld", c_int32), ("k", c_int32),
-                ("projected", c_int32)]
+                ("projected", c_int32), ("layout", c_int32)]
 
 
 class GwMlpWeights(Structure):
@@ -105,8 +107,12 @@ def lib():
                                  c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]
     L.gw_edge_update_forward.restype = c_int
     L.gw_edge_update_forward.argtypes = [c_int32, c_int32, c_void_p, c_void_p, POINTER(GwOperand), POINTER(GwOperand),
-                                         POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_void_p,
+                                         POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_int32, c_void_p,
                                          c_int32, POINTER(GwActivationSave), c_void_p, c_size_t, c_void_p]
+    L.gw_edge_tiles_bytes.restype = c_size_t
+    L.gw_edge_tiles_bytes.argtypes = [c_int32, c_int32]
+    L.gw_edge_rows_to_tiles.restype = c_int
+    L.gw_edge_rows_to_tiles.argtypes = [c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]
     L.gw_edge_update_workspace_bytes.restype = c_size_t
     L.gw_edge_update_workspace_bytes.argtypes = [c_int32, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
                                                  POINTER(GwMlpWeights)]

@@ -1,31 +1,38 @@
-// gw_edge16.hip - bf16-MFMA edge update with the weights held in registers (BASELINE.json configs[2]).
+// gw_edge16.hip - bf16-MFMA edge update with the weights held on chip (BASELINE.json configs[2]).
 //
-//   e'[c] = LayerNorm(W_out . relu(W_mid . relu(z1[c]) + b_mid) + b_out) + e_res[c],   agg[dst(c)] += e'[c]
-//   z1[c] = b1 + sum_p P_p[row_p(c)]  (+ W_raw . x_raw[c])        (layer 1 split: projected operands are gathered)
+//   e'[c] = LayerNorm(W_out . relu(W_mid . relu(z1[c]) + b_mid) + b_out) + e[c],   agg[dst(c)] += e'[c]
+//   z1[c] = b1 + sum_p P_p[row_p(c)]  (+ W_e . e[c])           (layer 1 split: projected operands are gathered)
 //
 // The first bf16 version (gw_bf16.hip) streams the packed weights through LDS for every 128-column tile like the fp32
 // kernels do.  At bf16 MFMA rates (16x fp32) that stream - 128 KiB per layer and tile - and its barriers cost ten times
-// the matrix time (measured: 10 % MFMA utilisation).  Here the weights never move: a workgroup is persistent (one per
-// CU), wave w keeps rows 64w .. 64w+63 of every layer's matrix in registers as MFMA A fragments (4 row tiles x 8 K-steps
-// x 4 VGPRs = 128 VGPRs per layer), and the ACTIVATIONS travel instead - 16-column groups, 8 KiB per layer as bf16,
-// exchanged between the four waves through LDS in the B-operand layout
-//       Hbuf[group][K-step s][lane][8 x bf16],   k(s, q, i) = 32 s + 16 (i >> 2) + 4 q + (i & 3)
-// (the K order of gw_pack_linear_bf16, so wave w / row tile t of the producing layer writes the 8-byte half
-//  s = 2w + (t >> 1), half = t & 1 of its own lane: no shuffles).
+// the matrix time (measured: 10 % MFMA utilisation).  Here the weights never move: workgroups are persistent (one per
+// CU) and the ACTIVATIONS travel, 16-column groups of bf16 in the MFMA B-operand layout
+//       H[group][K-step s][lane][8 x bf16],   k(s, q, i) = 32 s + 16 (i >> 2) + 4 q + (i & 3)
+// (the K order of gw_pack_linear_bf16: a wave that owns output row tile T of the producing layer writes the 8-byte half
+//  s = T >> 1, half = T & 1 of its own lane - no shuffles).
 //
-// A tile is 64 consecutive destination-sorted edges of ONE batch element.  Tiles are walked batch-innermost and XCD-aware:
-// the 32 workgroups of an XCD work on the same two edge blocks of all batch elements at a time, so rows of batch-shared
-// tables (the cached per-edge products and edge embeddings of the encoder / decoder) are fetched from HBM once and hit in
-// that XCD's L2 for the other batch elements.
+// A tile is 64 consecutive destination-sorted edges of ONE batch element = 4 groups = 32 KiB in that layout.  The same layout
+// is the HBM format of the per-sample edge features between processor blocks ("edge tiles", GW_LAYOUT_EDGE_TILES_BF16):
+// block n writes e' as tiles, block n+1 reads them as the B operand of its W_e pass and as its residual - half the bytes
+// of fp32 rows, every access a fully coalesced 1 KiB per wave instruction, no conversion anywhere.
 //
-// Two launches per edge update:
-//  1. edge16_gather_kernel - the layer-1 gather-add (b1 + sum of projected rows), relu, bf16, written to a workspace in the
-//     B-operand layout, 32 KiB per tile.  Pure data movement with thousands of waves in flight: the dependent
-//     index -> row -> 16-byte-piece loads that a one-workgroup-per-CU kernel cannot hide are hidden by occupancy here.
-//  2. edge16_kernel (persistent, weights in registers) - per tile: the 32 KiB of layer-1 activations arrive by LDS-DMA,
-//     prefetched one tile ahead | barrier | middle layer (32 MFMAs per group and wave) -> Hbuf2 | barrier | output layer,
-//     LayerNorm partial sums through LDS | barrier | LayerNorm, residual, [e' store], staging | barrier | per-feature
-//     segment sums (plain stores for segments inside the tile, atomics for the two that may continue in a neighbour).
+// Launches of one edge update:
+//  1. layer 1 -> workspace tiles of relu(z1) in bf16:
+//     edge16_gather_kernel  (every operand projected: encoder, decoder, first processor block) - pure gather-add, or
+//     edge16_l1_kernel      (processor blocks 1..: the per-sample edge features are a raw operand) - W_e lives in LDS
+//                           (128 KiB, loaded once per persistent workgroup), every wave works on its own 16-column groups
+//                           with no inter-wave synchronisation: b1 + P_s[src] + P_d[dst] gathered into the accumulators,
+//                           128 MFMAs against the edge tile, relu, bf16, one 16-byte store per K-step.
+//  2. edge16_kernel<NW> (persistent, W_mid and W_out in registers: wave w keeps rows 256/NW * w .. of both matrices as MFMA
+//     A fragments in AGPRs for the whole kernel) - per tile: the 32 KiB of layer-1 activations arrive by LDS-DMA, prefetched
+//     one tile ahead | barrier | middle layer -> Hbuf2 | barrier | output layer, LayerNorm partial sums through LDS |
+//     barrier | LayerNorm, residual, [e' tile store], staging | barrier | per-feature segment sums (plain stores for segments
+//     inside the tile, atomics for the two that may continue in a neighbour) [| e' rows from the staged tile].
+//     NW = 8 (512 threads, two waves per SIMD, 128 weight registers each) is the default: the phases outside the matrix
+//     products are instruction-issue bound with one wave per SIMD (measured round 1: ~3100 instructions per tile and wave
+//     at ~7 cycles each), a partner wave on the same SIMD fills those stalls.  NW = 4 is kept for A/B runs (tuning builds).
+// Tiles are walked batch-innermost and XCD-aware: the workgroups of an XCD work on the same edge blocks of all batch
+// elements at a time, so rows of batch-shared tables are fetched from HBM once and hit in that XCD's L2 afterwards.
 // Everything outside the matrix products is fp32, as in gw_bf16.hip.
 
 #include <hip/hip_runtime.h>
@@ -44,14 +51,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTileCols = 64;                       // columns (edges) per tile: 4 groups of 16
 constexpr int kGroups = 4;
-constexpr int kHBytes = kGroups * 8 * 1024;         // one activation exchange buffer: 4 groups x 8 K-steps x 1 KiB
+constexpr int kHBytes = kGroups * 8 * 1024;         // one tile in the B-operand layout: 4 groups x 8 K-steps x 1 KiB
 constexpr int kStageLd = 260;                       // staging row stride in floats (256 + 4: conflict-free column walks)
 constexpr int kOffH1 = 0;                           // two layer-1 buffers (DMA prefetch of the next tile)
 constexpr int kOffH2 = 2 * kHBytes;                 // layer-2 activations; the staging area reuses it (dead by then)
 constexpr int kOffStage = kOffH2;
 constexpr int kOffGd = kOffStage + kTileCols * kStageLd * 4;
 constexpr int kOffLn = kOffGd + kTileCols * 4;
-constexpr int kOffPar = kOffLn + 4 * kTileCols * 8;    // after [wave][column] (sum, sum of squares): b_mid, b_out, gamma, beta
+constexpr int kOffPar = kOffLn + 8 * kTileCols * 8;    // after [wave <= 8][column] (sum, sum of squares): b_mid, b_out, gamma, beta
 constexpr int kLdsTotal = kOffPar + 4 * 256 * 4;
 static_assert(kTileCols * kStageLd * 4 >= kHBytes, "staging area covers Hbuf2");
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
@@ -67,19 +74,24 @@ struct Edge16Args {
   int p_ld[3];
   int p_kind[3];  // 0: row = src[k], 1: dst[k], 2: k
   const float* b1;
+  const char* w_raw;  // packed W_e (layer-1 slice of the raw edge operand), edge16_l1_kernel only
   const char* w_mid;
   const float* b_mid;
   const char* w_out;
   const float* b_out;
   const float* gamma;
   const float* beta;
+  // residual e: fp32 rows (res_ptr) or bf16 edge tiles (res_tiles); exactly one is set
   const float* res_ptr;
   int res_rows_pb;
   int res_ld;
-  float* e_out;
+  const char* res_tiles;
+  const char* e_tiles;  // raw edge operand of edge16_l1_kernel (== res_tiles in the forecaster)
+  float* e_out;         // fp32 rows [batch * n_edges, 256] or null
+  char* e_out_tiles;    // bf16 edge tiles or null
   float* agg;
   char* h1g;  // workspace: layer-1 activations, [batch * neb tiles][4 groups][8 K-steps][64 lanes][8 bf16]
-  int skip;                 // tuning aid (GW_EDGE16_SKIP): 1 = no aggregate writes (results are then wrong)
+  int skip;                 // tuning builds only (GW_EDGE16_SKIP): 1 = no aggregate writes
   unsigned long long* dbg;  // gw_debug_timestamps(kind 3): phase clocks of each workgroup's third tile
   int dbg_cap;
 };
@@ -91,18 +103,27 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
   r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
   return r;
 }
+__device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+  r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+  return r;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 
 // B fragments of one 16-column group: 8 K-steps x 16 bytes per lane, all reads issued back to back
 __device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* __restrict__ hbuf_g, int lane) {
 #pragma unroll
   for (int s = 0; s < 8; ++s) bf[s] = *(const bf16x8*)(hbuf_g + s * 1024 + lane * 16);
 }
-// One resident layer on one 16-column group: acc[t] (4 row tiles of this wave) += W[tile t][K-step s] . B[s].
-// The MFMAs are written as asm with the weight fragment constrained to an accumulation register ("a"): the 256 weight
+// One resident layer on one 16-column group: acc[t] (RT row tiles of this wave) += W[tile t][K-step s] . B[s].
+// The MFMAs are written as asm with the weight fragment constrained to an accumulation register ("a"): the weight
 // registers then live in the AGPR half of the file for the whole kernel and feed the matrix cores from there.  Left to
 // itself the allocator treats AGPRs as spill space and copies every fragment back to a VGPR before use (~700 copies per
 // tile, measured).  Inline asm is opaque to the hazard recogniser, so the wait states it would insert are explicit:
 // before the first MFMA (accumulator written by a VALU move) and after the last one (accumulator read by VALU code).
+// An accumulator is touched by every 4th MFMA at most (RT = 2: even and odd K-steps accumulate separately and are added
+// at the end), as in the round-1 kernel.
 __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
 }
@@ -113,6 +134,49 @@ __device__ __forceinline__ void layer_group(f32x4 (&acc)[4], const bf16x8 (&w)[4
 #pragma unroll
     for (int t = 0; t < 4; ++t) mfma_a(acc[t], w[t][s], bf[s]);
   asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+__device__ __forceinline__ void layer_group(f32x4 (&acc)[2], const bf16x8 (&w)[2][8], const bf16x8 (&bf)[8]) {
+  f32x4 odd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]));
+#pragma unroll
+  for (int s = 0; s < 8; s += 2) {
+    mfma_a(acc[0], w[0][s], bf[s]);
+    mfma_a(acc[1], w[1][s], bf[s]);
+    mfma_a(odd[0], w[0][s + 1], bf[s + 1]);
+    mfma_a(odd[1], w[1][s + 1], bf[s + 1]);
+  }
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]));
+  acc[0] += odd[0];
+  acc[1] += odd[1];
+}
+// The same layer with the B fragments read from LDS in two halves of 4 K-steps (16 fragment registers instead of 32: the
+// 8-wave kernel has 128 VGPRs beside its 128 weight registers); the partner wave on the SIMD covers the second LDS latency.
+__device__ __forceinline__ void layer_group_lds(f32x4 (&acc)[2], const bf16x8 (&w)[2][8], const char* __restrict__ hbuf_g, int lane) {
+  f32x4 odd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 bf[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bf[s] = *(const bf16x8*)(hbuf_g + (4 * h + s) * 1024 + lane * 16);
+    asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+#pragma unroll
+    for (int s = 0; s < 4; s += 2) {
+      mfma_a(acc[0], w[0][4 * h + s], bf[s]);
+      mfma_a(acc[1], w[1][4 * h + s], bf[s]);
+      mfma_a(odd[0], w[0][4 * h + s + 1], bf[s + 1]);
+      mfma_a(odd[1], w[1][4 * h + s + 1], bf[s + 1]);
+    }
+    // the fragment registers are rewritten by the next half's LDS reads: keep those behind the MFMAs that read them
+    asm volatile("s_nop 7" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+  }
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]));
+  acc[0] += odd[0];
+  acc[1] += odd[1];
+}
+__device__ __forceinline__ void layer_group_lds(f32x4 (&acc)[4], const bf16x8 (&w)[4][8], const char* __restrict__ hbuf_g, int lane) {
+  bf16x8 bf[8];
+  load_frags(bf, hbuf_g, lane);
+  layer_group(acc, w, bf);
 }
 
 // unit u of XCD x -> (edge block, batch element); workgroups / loop iterations with u >= n_units have nothing to do
@@ -127,7 +191,7 @@ __device__ __forceinline__ TileWalk tile_walk(int xcd, int neb, int batch) {
   return w;
 }
 
-// Launch 1: one workgroup per tile (wave = 16-column group).  Eight lanes read one 128-byte line of a row (features
+// Launch 1a: one workgroup per tile (wave = 16-column group).  Eight lanes read one 128-byte line of a row (features
 // 32 s .. 32 s + 31), so an instruction touches 8 full cache lines; lane piece p = lane & 7 holds features 32 s + 4 p .. + 3,
 // which is half (p >> 2) of the B fragment of lane (j, q = p & 3): written there directly as 8 bytes of bf16.
 __global__ __launch_bounds__(256) void edge16_gather_kernel(const Edge16Args a) {
@@ -178,27 +242,125 @@ __global__ __launch_bounds__(256) void edge16_gather_kernel(const Edge16Args a) 
   }
 }
 
-__global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
+// Launch 1b: layer 1 with a raw edge operand.  Persistent workgroups of 8 waves; W_e (packed bf16 stream, 128 KiB:
+// [K-step s][row tile t][lane][8]) is copied into LDS once, then every wave takes 16-column groups on its own:
+//   acc[t] = b1 + P_s[src] + P_d[dst]   (accumulator layout: lane (j, q) holds features 16 t + 4 q .. + 3 of column j)
+//   acc[t] += W_e[tile t][s] . E[s]      (E = the group's 8 KiB of the edge tile, one coalesced 16-byte load per K-step)
+//   H1[s] = bf16(relu(acc[2 s]), relu(acc[2 s + 1]))   (one coalesced 16-byte store per K-step)
+// No inter-wave synchronisation after the weight copy: the gathers of one wave overlap the MFMAs of its neighbours.
+constexpr int kL1Waves = 8;
+__global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
   const int q = lane >> 4;
-  const int f0 = 64 * wave + 4 * q;  // this lane's features: f0 + 16 t + r
-
-  // ---- resident weights: rows 64 wave .. +63 of both matrices, all 8 K-steps (packed stream: [s][16 tiles][lane][8]) ----
-  bf16x8 wm[4][8], wo[4][8];
+  {
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    for (int p = wave; p < 128; p += kL1Waves)
+      glds16_asm_s((const float*)(a.w_raw + (size_t)p * 1024), (unsigned)lane * 16u,
+                   __builtin_amdgcn_readfirstlane(lds0 + (unsigned)p * 1024u));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int n_groups = a.batch * a.neb * kGroups;
+  const int stride = gridDim.x * kL1Waves;
+#pragma unroll 1
+  for (int u = blockIdx.x * kL1Waves + wave; u < n_groups; u += stride) {
+    const int tile = u >> 2, g = u & 3;
+    const int b = tile / a.neb;
+    const int eb = tile - b * a.neb;
+    const int kr = eb * kTileCols + 16 * g + j;
+    const bool valid = kr < a.n_edges;
+    const int k = valid ? kr : a.n_edges - 1;
+    const size_t goff = ((size_t)tile * kGroups + g) * 8192 + (size_t)lane * 16;
+    bf16x8 bf[8];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int s = 0; s < 8; ++s) bf[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + goff + s * 1024);
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = ldg4(a.b1 + 16 * t + 4 * q);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      if (p < a.n_proj) {
+        const int r = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
+        const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          acc[t] += ldg4(row + 16 * t);
+          if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // at most 8 row pieces in flight: registers
+        }
+      }
+    const char* wl = lds + lane * 16;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const size_t off = ((size_t)(s * 16 + 4 * wave + t) * 64 + lane) * 16;
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {  // A fragments four at a time (16 registers), read one quartet ahead by the scheduler
+        bf16x8 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(wl + (s * 16 + 4 * t4 + t) * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[4 * t4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf[s], acc[4 * t4 + t], 0, 0, 0);
+        if (t4 & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    char* out = a.h1g + goff;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      bf16x8 v = to_bf16x8(relu4(acc[2 * s]), relu4(acc[2 * s + 1]));
+      if (!valid) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      *(GW_AS1 bf16x8*)(out + s * 1024) = v;
+    }
+  }
+}
+
+// fp32 edge rows -> bf16 edge tiles (entry of the tile format: per-sample edge features handed over as rows by a caller)
+__global__ __launch_bounds__(256) void rows_to_tiles_kernel(int batch, int n_edges, int neb, const float* __restrict__ rows,
+                                                            int rows_pb, int ld, char* __restrict__ tiles) {
+  const int lane = threadIdx.x & 63;
+  const int g = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int b = tile / neb, eb = tile - b * neb;
+  const int kr = eb * kTileCols + 16 * g + j;
+  const bool valid = kr < n_edges;
+  const float* row = rows + ((size_t)b * (size_t)rows_pb + (size_t)(valid ? kr : 0)) * (size_t)ld + 4 * q;
+  char* out = tiles + ((size_t)tile * kGroups + g) * 8192 + (size_t)lane * 16;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) v = to_bf16x8(ldg4(row + 32 * s), ldg4(row + 32 * s + 16));
+    *(GW_AS1 bf16x8*)(out + s * 1024) = v;
+  }
+}
+
+// RES_TILES: the residual e comes from bf16 edge tiles (a.res_tiles) instead of fp32 rows (a.res_ptr) - a template parameter
+// so that only one set of prefetch registers exists.
+template <int NW, bool RES_TILES>
+__global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Args a) {
+  constexpr int RT = 16 / NW;         // output row tiles (16 features) per wave
+  constexpr int PPW = 32 / NW;        // LDS-DMA pieces (1 KiB) of a 32 KiB tile per wave
+  constexpr int KS = RT / 2;          // K-steps of the next layer this wave's outputs fill (2 for RT 4, 1 for RT 2)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const int f0 = 16 * RT * wave + 4 * q;  // this lane's features: f0 + 16 t + r
+  const int s0 = (RT * wave) >> 1;        // first K-step of the B layout this wave's outputs belong to (RT even)
+
+  // ---- resident weights: rows 16 RT wave .. of both matrices, all 8 K-steps (packed stream: [s][16 tiles][lane][8]) ----
+  bf16x8 wm[RT][8], wo[RT][8];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const size_t off = ((size_t)(s * 16 + RT * wave + t) * 64 + lane) * 16;
       wm[t][s] = *(const bf16x8*)(a.w_mid + off);
       wo[t][s] = *(const bf16x8*)(a.w_out + off);
     }
-  // biases / LayerNorm parameters live in LDS (4 KiB) and are re-read where each phase needs them: with 256 registers of
-  // weights, 64 more resident ones would push the fragment and residual prefetches into scratch
-  {
+  // biases / LayerNorm parameters live in LDS (4 KiB) and are re-read where each phase needs them
+  if (threadIdx.x < 256) {
     float* par_w = (float*)(lds + kOffPar);
     const int i = threadIdx.x;
     par_w[i] = a.b_mid[i];
@@ -218,25 +380,24 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
   const int slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
   const TileWalk tw = tile_walk(blockIdx.x & 7, a.neb, a.batch);
 
-  // 32 KiB of layer-1 activations of unit u -> Hbuf1[par]: 32 LDS-DMA pieces of 1 KiB, 8 per wave (asynchronous).  The DMA
+  // 32 KiB of layer-1 activations of unit u -> Hbuf1[par]: 32 LDS-DMA pieces of 1 KiB, PPW per wave (asynchronous).  The DMA
   // queue of a wave is shallow - eight back-to-back issues stall it for ~5 k cycles (measured) - so in steady state the
-  // pieces are issued two per 16-column group of the output layer, ~1 k cycles apart, when no other load is outstanding.
-  auto tile_src = [&](int u) -> const char* {
+  // pieces are issued a few per 16-column group of the output layer, when no other load is outstanding.
+  auto tile_index = [&](int u) -> size_t {
     const int eb = tw.eb_start + u / a.batch;
     const int b = u - (u / a.batch) * a.batch;
-    return a.h1g + (size_t)(b * a.neb + eb) * kHBytes;
+    return (size_t)(b * a.neb + eb);
   };
   auto prefetch_piece = [&](const char* src, int par, int i) {
-    const int piece = 8 * wave + i;
+    const int piece = PPW * wave + i;
     glds16_asm_s((const float*)(src + piece * 1024), (unsigned)lane * 16u,
                  __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kOffH1 + par * kHBytes + piece * 1024)));
   };
-  auto prefetch = [&](int u, int par) {
-    const char* src = tile_src(u);
+  if (slot < tw.n_units) {
+    const char* src = a.h1g + tile_index(slot) * kHBytes;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) prefetch_piece(src, par, i);
-  };
-  if (slot < tw.n_units) prefetch(slot, 0);
+    for (int i = 0; i < PPW; ++i) prefetch_piece(src, 0, i);
+  }
 
   int par = 0;
 #pragma unroll 1
@@ -244,6 +405,7 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
     const int eb = tw.eb_start + u / a.batch;
     const int b = u - (u / a.batch) * a.batch;
     const int k0 = eb * kTileCols;
+    const size_t tile = (size_t)(b * a.neb + eb);
     const char* h1 = lds + kOffH1 + par * kHBytes;
 
     unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -251,15 +413,15 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
     if (stamp) ts[0] = gw_clock();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its stores of the previous tile) are done
     if (stamp) ts[1] = gw_clock();
-    wg_barrier();  // (1) Hbuf1[par] complete; every wave has left the previous tile's segment sums
+    wg_barrier();  // (1) Hbuf1[par] complete; every wave has left the previous tile's last phase
     if (stamp) ts[2] = gw_clock();
-    // next tile -> Hbuf1[par ^ 1] (last read before barrier (2) of the previous tile), one piece per group step below
+    // next tile -> Hbuf1[par ^ 1] (last read before barrier (2) of the previous tile), a few pieces per group step below
     const bool more = u + nslot < tw.n_units;
-    const char* nsrc = more ? tile_src(u + nslot) : nullptr;
+    const char* nsrc = more ? a.h1g + tile_index(u + nslot) * kHBytes : nullptr;
 
-    f32x4 bmv[4];  // (after barrier (1): on the first tile it also publishes the parameter block)
+    f32x4 bmv[RT];  // (after barrier (1): on the first tile it also publishes the parameter block)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bmv[t] = *(const f32x4*)(par_l + 16 * t);
+    for (int t = 0; t < RT; ++t) bmv[t] = *(const f32x4*)(par_l + 16 * t);
     int kk[kGroups];
     bool valid[kGroups];
 #pragma unroll
@@ -274,56 +436,61 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
       gd_mine = kr < a.n_edges ? b * a.n_dst + ldgi(a.dst + kr) : -1;
     }
 
-    // ---- residual rows: requested here, used after barrier (3) - their latency passes under the middle layer, and they
-    // are back before the DMA pieces of the next tile are issued (the wave's memory queue is shallow) ----
-    f32x4 resv[kGroups][4];
+    // ---- residual: requested here, used after barrier (3) - its latency passes under the middle layer, and it is back
+    // before the DMA pieces of the next tile are issued (the wave's memory queue is shallow).  fp32 rows: 16-byte pieces of
+    // this lane's features; bf16 edge tiles: the lane's own 16-byte slots of K-steps s0 .. (its features are exactly those).
+    f32x4 resv[RES_TILES ? 1 : kGroups][RES_TILES ? 1 : RT];
+    bf16x8 rest[RES_TILES ? kGroups : 1][RES_TILES ? KS : 1];
+    if constexpr (RES_TILES) {
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-      const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)kk[g]) * (size_t)a.res_ld + f0;
+      for (int g = 0; g < kGroups; ++g)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) resv[g][t] = ldg4(rrow + 16 * t);
+        for (int ks = 0; ks < KS; ++ks)
+          rest[g][ks] = *(const GW_AS1 bf16x8*)(a.res_tiles + (tile * kGroups + g) * 8192 + (size_t)(s0 + ks) * 1024 + (size_t)lane * 16);
+    } else {
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)kk[g]) * (size_t)a.res_ld + f0;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) resv[g][t] = ldg4(rrow + 16 * t);
+      }
     }
     if (stamp) ts[3] = gw_clock();
-    // ---- middle layer -> Hbuf2 (the next group's B fragments are read from LDS while this group's MFMAs run) ----
-    bf16x8 bfr[2][8];
-    load_frags(bfr[0], h1, lane);
+    // ---- middle layer -> Hbuf2 ----
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
-      if (g + 1 < kGroups) load_frags(bfr[(g + 1) & 1], h1 + (g + 1) * 8 * 1024, lane);
-      f32x4 acc[4];
+      f32x4 acc[RT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = bmv[t];
-      layer_group(acc, wm, bfr[g & 1]);
+      for (int t = 0; t < RT; ++t) acc[t] = bmv[t];
+      layer_group_lds(acc, wm, h1 + g * 8 * 1024, lane);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 h = f32x4{fmaxf(acc[t].x, 0.f), fmaxf(acc[t].y, 0.f), fmaxf(acc[t].z, 0.f), fmaxf(acc[t].w, 0.f)};
-        *(bf16x4*)(h2 + ((g * 8 + 2 * wave + (t >> 1)) * 64 + lane) * 16 + (t & 1) * 8) = to_bf16x4(h);
+      for (int t = 0; t < RT; ++t) {
+        const int T = RT * wave + t;  // output row tile -> K-step T >> 1, half T & 1 of this lane's slot
+        *(bf16x4*)(h2 + ((g * 8 + (T >> 1)) * 64 + lane) * 16 + (T & 1) * 8) = to_bf16x4(relu4(acc[t]));
       }
-      if (stamp) ts[4 + g] = gw_clock();
+      if (stamp && g < 4) ts[4 + g] = gw_clock();
     }
     wg_barrier();  // (2) Hbuf2 complete, Hbuf1 free
     if (stamp) ts[8] = gw_clock();
 
-    f32x4 bov[4];
+    f32x4 bov[RT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bov[t] = *(const f32x4*)(par_l + 256 + 16 * t);
+    for (int t = 0; t < RT; ++t) bov[t] = *(const f32x4*)(par_l + 256 + 16 * t);
 
     // ---- output layer + LayerNorm partial sums ----
-    f32x4 o[kGroups][4];
-    load_frags(bfr[0], h2, lane);
+    f32x4 o[kGroups][RT];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
-      if (g + 1 < kGroups) load_frags(bfr[(g + 1) & 1], h2 + (g + 1) * 8 * 1024, lane);
       if (more) {
-        prefetch_piece(nsrc, par ^ 1, 2 * g);
-        prefetch_piece(nsrc, par ^ 1, 2 * g + 1);
+#pragma unroll
+        for (int i = 0; i < PPW / kGroups; ++i) prefetch_piece(nsrc, par ^ 1, (PPW / kGroups) * g + i);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) o[g][t] = bov[t];
-      layer_group(o[g], wo, bfr[g & 1]);
+      for (int t = 0; t < RT; ++t) o[g][t] = bov[t];
+      layer_group_lds(o[g], wo, h2 + g * 8 * 1024, lane);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           s1 += o[g][t][r];
@@ -338,23 +505,23 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
         lnp[(wave * kTileCols + 16 * g + j) * 2 + 1] = s2;
       }
     }
-    f32x4 gmv[4], btv[4];
+    if (stamp) ts[9] = gw_clock();
+    wg_barrier();  // (3) partial sums of all feature slices visible
+    if (stamp) ts[10] = gw_clock();
+    f32x4 gmv[RT], btv[RT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RT; ++t) {
       gmv[t] = *(const f32x4*)(par_l + 512 + 16 * t);
       btv[t] = *(const f32x4*)(par_l + 768 + 16 * t);
     }
-    if (stamp) ts[9] = gw_clock();
-    wg_barrier();  // (3) partial sums of all four feature quarters visible
-    if (stamp) ts[10] = gw_clock();
 
-    // ---- LayerNorm (eps 1e-5, biased variance), residual, staging ----
+    // ---- LayerNorm (eps 1e-5, biased variance), residual, staging, e' tile ----
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
       const int col = 16 * g + j;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) {
+      for (int w4 = 0; w4 < NW; ++w4) {
         s1 += lnp[(w4 * kTileCols + col) * 2];
         s2 += lnp[(w4 * kTileCols + col) * 2 + 1];
       }
@@ -362,14 +529,29 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
       const float var = fmaxf(s2 * (1.0f / 256.0f) - mean * mean, 0.f);
       const float rstd = 1.0f / sqrtf(var + 1e-5f);
       float* srow = stage + col * kStageLd + f0;
+      f32x4 v[RT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f32x4 rv = resv[g][t];
-        f32x4 v;
+      for (int t = 0; t < RT; ++t) {
+        f32x4 rv;
+        if constexpr (RES_TILES) {
+          const bf16x8 rr = rest[g][t >> 1];
+          rv = (t & 1) ? f32x4{(float)rr[4], (float)rr[5], (float)rr[6], (float)rr[7]}
+                       : f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+        } else {
+          rv = resv[g][t];
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (o[g][t][r] - mean) * rstd * gmv[t][r] + btv[t][r] + rv[r];
-        *(f32x4*)(srow + 16 * t) = v;
-        if (a.e_out != nullptr && valid[g]) stg4(a.e_out + ((size_t)b * a.n_edges + kk[g]) * 256 + f0 + 16 * t, v);
+        for (int r = 0; r < 4; ++r) v[t][r] = (o[g][t][r] - mean) * rstd * gmv[t][r] + btv[t][r] + rv[r];
+        *(f32x4*)(srow + 16 * t) = v[t];
+        if (NW == 4 && a.e_out != nullptr && valid[g]) stg4(a.e_out + ((size_t)b * a.n_edges + kk[g]) * 256 + f0 + 16 * t, v[t]);
+      }
+      if (a.e_out_tiles != nullptr) {  // e' as bf16 edge tiles: this lane's own 16-byte slots, 1 KiB per wave instruction
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 pk = to_bf16x8(v[2 * ks], v[2 * ks + 1]);
+          if (!valid[g]) pk = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          *(GW_AS1 bf16x8*)(a.e_out_tiles + (tile * kGroups + g) * 8192 + (size_t)(s0 + ks) * 1024 + (size_t)lane * 16) = pk;
+        }
       }
     }
     if (wave == 0) gdl[lane] = gd_mine;
@@ -377,11 +559,11 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
     wg_barrier();  // (4) staged tile + destination ids visible
     if (stamp) ts[12] = gw_clock();
 
-    // ---- per-feature segment sums over the 64 destination-sorted columns ----
-    // all 64 LDS reads first (independent), then a straight-line walk over registers.  Segment ends are the same for every
-    // thread: lane i compares column i's destination with column i + 1's, the ballot is a 64-bit scalar mask, and the walk
-    // tests one bit per column (a scalar branch that is rarely taken).
-    {
+    if (threadIdx.x < 256) {
+      // ---- per-feature segment sums over the 64 destination-sorted columns (waves 0 .. 3) ----
+      // all 64 LDS reads first (independent), then a straight-line walk over registers.  Segment ends are the same for every
+      // thread: lane i compares column i's destination with column i + 1's, the ballot is a 64-bit scalar mask, and the walk
+      // tests one bit per column (a scalar branch that is rarely taken).
       const int f = threadIdx.x;
       float vv[kTileCols];
 #pragma unroll
@@ -407,6 +589,16 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
           run = 0.f;
         }
       }
+    } else if (NW == 8 && a.e_out != nullptr) {
+      // ---- e' as fp32 rows from the staged tile (waves 4 .. 7, beside the segment sums): one coalesced 1 KiB store per row ----
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int col = 16 * (wave - 4) + i;
+        if (k0 + col < a.n_edges) {
+          const f32x4 v = *(const f32x4*)(stage + col * kStageLd + 4 * lane);
+          stg4(a.e_out + ((size_t)b * a.n_edges + k0 + col) * 256 + 4 * lane, v);
+        }
+      }
     }
     // the next tile's barrier (1) separates these reads from the next Hbuf2 / staging writes
     if (stamp) {
@@ -418,6 +610,14 @@ __global__ __launch_bounds__(256, 1) void edge16_kernel(const Edge16Args a) {
   }
 }
 
+template <typename K>
+int launch_resident(K kernel, int threads, int n_wg, const Edge16Args& a, void* stream) {
+  static DeviceOnce once;  // per template instantiation and device
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)n_wg), dim3((unsigned)threads), kLdsTotal, (hipStream_t)stream, a);
+  return check_launch("edge16_kernel launch");
+}
+
 inline bool is_proj16(const gw_operand* o) { return o->k > 0 && o->projected != 0; }
 inline bool is_raw16(const gw_operand* o) { return o->k > 0 && o->projected == 0; }
 
@@ -425,19 +625,18 @@ inline bool is_raw16(const gw_operand* o) { return o->k > 0 && o->projected == 0
 
 namespace gw {
 
-// Eligible: bf16 weights, one middle layer, every non-zero operand pre-projected (encoder / decoder / first processor block).
+// Eligible: bf16 weights, one middle layer, and layer 1 = projected operands (+ at most the edge operand raw, as bf16 tiles).
 bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w) {
   if (w->weight_dtype != GW_DTYPE_BF16 || w->n_mid != 1) return false;
   if (w->ln_width > 0 && w->ln_width != 256) return false;
-  const gw_operand* ops[3] = {x_src, x_dst, e_in};
-  int n_proj = 0;
-  for (int i = 0; i < 3; ++i) {
-    if (is_raw16(ops[i])) return false;
-    n_proj += is_proj16(ops[i]) ? 1 : 0;
-  }
-  if (n_proj < 1) return false;
-  static int impl = -1;  // GW_EDGE16_IMPL=0 forces the streaming kernel of gw_bf16.hip (A/B measurements, tests of both paths)
-  if (impl < 0) impl = GW_TUNE("GW_EDGE16_IMPL", 1);
+  if (is_raw16(x_src) || is_raw16(x_dst)) return false;
+  if (x_src->layout != GW_LAYOUT_ROWS_F32 || x_dst->layout != GW_LAYOUT_ROWS_F32) return false;
+  const bool raw_e = is_raw16(e_in);
+  if (raw_e && (e_in->layout != GW_LAYOUT_EDGE_TILES_BF16 || !w->w1[2])) return false;
+  if (!raw_e && e_in->k > 0 && e_in->layout != GW_LAYOUT_ROWS_F32) return false;
+  const int n_proj = (is_proj16(x_src) ? 1 : 0) + (is_proj16(x_dst) ? 1 : 0) + (is_proj16(e_in) ? 1 : 0);
+  if (n_proj < 1 && !raw_e) return false;
+  static const int impl = GW_TUNE("GW_EDGE16_IMPL", 1);  // tuning builds: 0 forces the streaming kernel of gw_bf16.hip
   return impl != 0;
 }
 
@@ -445,9 +644,17 @@ size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges) {
   return (size_t)batch * (size_t)((n_edges + kTileCols - 1) / kTileCols) * (size_t)kHBytes;
 }
 
+int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
+                         void* stream) {
+  const int neb = (n_edges + kTileCols - 1) / kTileCols;
+  hipLaunchKernelGGL(rows_to_tiles_kernel, dim3((unsigned)(batch * neb)), dim3(256), 0, (hipStream_t)stream, batch, n_edges, neb, rows,
+                     rows_per_batch, ld, (char*)tiles);
+  return check_launch("rows_to_tiles_kernel launch");
+}
+
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                  float* e_out, float* agg, int32_t n_dst, void* workspace, void* stream) {
+                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, void* stream) {
   Edge16Args a;
   memset(&a, 0, sizeof(a));
   a.batch = batch;
@@ -465,38 +672,55 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
       a.p_kind[a.n_proj] = i;
       ++a.n_proj;
     }
+  const bool raw_e = is_raw16(e_in);
   a.b1 = w->b1;
+  a.w_raw = raw_e ? (const char*)w->w1[2] : nullptr;
+  a.e_tiles = raw_e ? (const char*)e_in->ptr : nullptr;
   a.w_mid = (const char*)w->w_mid;
   a.b_mid = w->b_mid;
   a.w_out = (const char*)w->w_out;
   a.b_out = w->b_out;
   a.gamma = w->ln_gamma;
   a.beta = w->ln_beta;
-  a.res_ptr = e_res->ptr;
-  a.res_rows_pb = e_res->rows_per_batch;
-  a.res_ld = e_res->ld;
+  if (e_res->layout == GW_LAYOUT_EDGE_TILES_BF16) {
+    a.res_tiles = (const char*)e_res->ptr;
+  } else {
+    a.res_ptr = e_res->ptr;
+    a.res_rows_pb = e_res->rows_per_batch;
+    a.res_ld = e_res->ld;
+  }
   a.e_out = e_out;
+  a.e_out_tiles = (char*)e_out_tiles;
   a.agg = agg;
   a.h1g = (char*)workspace;
+#ifdef GW_TUNING
   {
-    static int skip = -1;
-    if (skip < 0) skip = GW_TUNE("GW_EDGE16_SKIP", 0);
+    static const int skip = GW_TUNE("GW_EDGE16_SKIP", 0);
     a.skip = skip;
   }
+#endif
   if (g_dbg != nullptr && g_dbg_kind == 3) {
     a.dbg = g_dbg;
     a.dbg_cap = g_dbg_cap;
   }
-  static DeviceOnce once;
-  if (once.first()) (void)hipFuncSetAttribute((const void*)edge16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
-  // launch 1: one workgroup per tile, numbered like the persistent kernel walks them (XCD = workgroup & 7)
-  const int units_max = (a.neb / 8 + (a.neb % 8 ? 1 : 0)) * batch;
-  hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)(8 * units_max)), dim3(256), 0, (hipStream_t)stream, a);
-  if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
-  static int n_wg = -1;  // persistent workgroups: one per CU, a multiple of 8 (XCD round-robin)
-  if (n_wg < 0) n_wg = (GW_TUNE("GW_EDGE16_WGS", 256) + 7) / 8 * 8;
-  hipLaunchKernelGGL(edge16_kernel, dim3((unsigned)n_wg), dim3(256), kLdsTotal, (hipStream_t)stream, a);
-  return check_launch("edge16_kernel launch");
+  static const int n_wg = (GW_TUNE("GW_EDGE16_WGS", 256) + 7) / 8 * 8;  // persistent workgroups: one per CU, a multiple of 8 (XCD round-robin)
+  // launch 1: layer 1 -> workspace tiles
+  if (raw_e) {
+    static DeviceOnce once_l1;
+    if (once_l1.first()) (void)hipFuncSetAttribute((const void*)edge16_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipLaunchKernelGGL(edge16_l1_kernel, dim3((unsigned)n_wg), dim3(64 * kL1Waves), 128 * 1024, (hipStream_t)stream, a);
+    if (int rc = check_launch("edge16_l1_kernel launch")) return rc;
+  } else {
+    // one workgroup per tile, numbered like the persistent kernel walks them (XCD = workgroup & 7)
+    const int units_max = (a.neb / 8 + (a.neb % 8 ? 1 : 0)) * batch;
+    hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)(8 * units_max)), dim3(256), 0, (hipStream_t)stream, a);
+    if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
+  }
+  // launch 2: the resident layers
+  static const int nw = GW_TUNE("GW_EDGE16_NW", 8);
+  const bool rt = a.res_tiles != nullptr;
+  if (nw == 4) return rt ? launch_resident(edge16_kernel<4, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false>, 256, n_wg, a, stream);
+  return rt ? launch_resident(edge16_kernel<8, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false>, 512, n_wg, a, stream);
 }
 
 }  // namespace gw

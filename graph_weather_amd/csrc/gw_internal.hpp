@@ -110,7 +110,9 @@ bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_
 size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges);
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                  float* e_out, float* agg, int32_t n_dst, void* workspace, void* stream);
+                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, void* stream);
+int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
+                         void* stream);
 
 }  // namespace gw
 

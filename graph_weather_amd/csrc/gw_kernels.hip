@@ -767,10 +767,22 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
   return gw::edge16_eligible(x_src, x_dst, e_in, w) ? gw::edge16_workspace_bytes(batch, n_edges) : 0;
 }
 
+size_t gw_edge_tiles_bytes(int32_t batch, int32_t n_edges) {
+  if (batch <= 0 || n_edges <= 0) return 0;
+  return gw::edge16_workspace_bytes(batch, n_edges);  // a tile buffer and the layer-1 workspace have the same shape
+}
+
+int gw_edge_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
+                          void* stream) {
+  if (batch <= 0 || n_edges <= 0 || !rows || !tiles || ld < 256 || ld % 4 != 0 || rows_per_batch < 0)
+    return fail(GW_E_BADARG, "gw_edge_rows_to_tiles: bad arguments");
+  return gw::edge16_rows_to_tiles(batch, n_edges, rows, rows_per_batch, ld, tiles, stream);
+}
+
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
-                           const gw_operand* e_res, const gw_mlp_weights* w, float* e_out, float* agg, int32_t n_dst,
-                           const gw_activation_save* save, void* workspace, size_t workspace_bytes, void* stream) {
+                           const gw_operand* e_res, const gw_mlp_weights* w, void* e_out_any, int32_t e_out_layout, float* agg,
+                           int32_t n_dst, const gw_activation_save* save, void* workspace, size_t workspace_bytes, void* stream) {
   if (batch <= 0 || n_edges < 0 || n_dst <= 0) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if (n_edges == 0) return GW_OK;  // nothing to add: agg stays as the caller zeroed it
   if (!src || !dst || !x_src || !x_dst || !e_in || !e_res || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
@@ -786,6 +798,21 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
   if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
+  // edge tiles (bf16) are a format of the bf16 path with resident weights only
+  const bool tiles_in = (e_in->k > 0 && e_in->layout == GW_LAYOUT_EDGE_TILES_BF16) || e_res->layout == GW_LAYOUT_EDGE_TILES_BF16;
+  const bool tiles_out = e_out_any != nullptr && e_out_layout == GW_LAYOUT_EDGE_TILES_BF16;
+  if (e_out_any != nullptr && e_out_layout != GW_LAYOUT_ROWS_F32 && e_out_layout != GW_LAYOUT_EDGE_TILES_BF16)
+    return fail(GW_E_BADARG, "gw_edge_update_forward: bad e_out_layout");
+  if (x_src->layout != GW_LAYOUT_ROWS_F32 || x_dst->layout != GW_LAYOUT_ROWS_F32)
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: node operands must be fp32 rows");
+  float* e_out = tiles_out ? nullptr : (float*)e_out_any;
+  if (tiles_in || tiles_out) {
+    if (save || !workspace || !gw::edge16_eligible(x_src, x_dst, e_in, w) || workspace_bytes < gw::edge16_workspace_bytes(batch, n_edges))
+      return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
+                                    "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, tiles_out ? e_out_any : nullptr, agg,
+                             n_dst, workspace, stream);
+  }
   if (w->weight_dtype == GW_DTYPE_F32 && (!save || w->n_mid == 1) && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) {
     if (save && (!save->hidden || !save->pre_norm || save->hidden_ld < 256 || save->hidden_ld % 4 != 0))
       return fail(GW_E_BADARG, "gw_edge_update_forward: bad gw_activation_save");
@@ -793,7 +820,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   }
   if (!save && workspace && gw::edge16_eligible(x_src, x_dst, e_in, w) &&
       workspace_bytes >= gw::edge16_workspace_bytes(batch, n_edges))
-    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, workspace, stream);
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace, stream);
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;

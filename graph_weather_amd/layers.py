@@ -65,6 +65,8 @@ class Feed:
     def operand(self) -> Operand:
         if self.mode == "zero":
             return ops.ZERO
+        if self.mode == "tiles":  # per-sample edge features as bf16 edge tiles (bf16 mode between processor blocks)
+            return Operand(self.tensor, 0, 256, tiles=True)
         return Operand(self.tensor, self.rows_pb, 256, projected=(self.mode == "proj"))
 
     def spec(self) -> OperandSpec:
@@ -294,9 +296,13 @@ class GraphNetBlock(nn.Module):
                                    x_res_rows_pb, agg)
             return x_new, e_out
         agg = agg_zeroed if agg_zeroed is not None else torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
-        e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
+        if want_edges == "tiles":  # e' stays in the kernels' own bf16 tile format for the next block
+            e_out = torch.empty(ops.edge_tiles_bytes(batch, n_edges), dtype=torch.uint8, device=device)
+        else:
+            e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
+        res_op = Operand(e_res, 0, 256, tiles=True) if e_res.dtype == torch.uint8 else Operand(e_res, e_res_rows_pb, 256)
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
-                                e_in.operand(), Operand(e_res, e_res_rows_pb, 256), n_dst, agg, e_out, tag=tag)
+                                e_in.operand(), res_op, n_dst, agg, e_out, tag=tag)
         x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(),
                                         ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256),
                                         Operand(agg, n_dst, 256))
@@ -394,6 +400,7 @@ class GraphProcessor(nn.Module):
             last = i == hi - 1
             mlp_e = blk.edge_model.edge_mlp
             agg_buf = None
+            pm_e = None
             if train:
                 ps, pd = ag.project(mlp_e, (0, 1), x, batch * n, n)
             else:
@@ -401,6 +408,10 @@ class GraphProcessor(nn.Module):
                 if mlp_e.compute_dtype == torch.float32:  # the projection launch also zero-fills this block's aggregate
                     agg_buf = torch.empty((batch * n, 256), dtype=torch.float32, device=x.device)
                 ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n, zero_rows=agg_buf)
+            # bf16 mode (inference): between blocks the per-sample edge features live as bf16 "edge tiles" - the MFMA B-operand
+            # order the next block's layer-1 product consumes directly (csrc/gw_edge16.hip); only what crosses the API is rows
+            tiled = ((not train) and mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0
+                     and n_edges > 0)
             if shared:
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
@@ -411,11 +422,16 @@ class GraphProcessor(nn.Module):
                         self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
                     pe = self._e0_cache[1]
                 e_in = Feed(pe, 0, "proj")
+            elif tiled:
+                if e_cur.dtype != torch.uint8:  # per-sample rows handed over by a caller: into the tile format once
+                    e_cur = ops.edge_rows_to_tiles(e_cur.contiguous(), batch, n_edges, n_edges)
+                e_in = Feed(e_cur, 0, "tiles")
             else:
                 e_in = Feed(e_cur, n_edges, "raw")
+            need_e = want_edges or not last
+            out_kind = "tiles" if (tiled and need_e and not (last and want_edges)) else need_e
             x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_cur, 0 if shared else n_edges,
-                               Feed(x, n, "raw"), x, n, want_edges or not last, x.device, tag="processor_edge",
-                               agg_zeroed=agg_buf)
+                               Feed(x, n, "raw"), x, n, out_kind, x.device, tag="processor_edge", agg_zeroed=agg_buf)
             if e_new is not None:
                 e_cur, shared = e_new, False
         return x, e_cur, shared

@@ -82,15 +82,19 @@ class Operand:
     k: int
     index: Optional[torch.Tensor] = None
     projected: bool = False  # rows are X . W1_slice^T (see project_forward): gather-added, no MFMA pass
+    tiles: bool = False  # ``tensor`` is a byte buffer of bf16 edge tiles (include/gw_amd.h: GW_LAYOUT_EDGE_TILES_BF16)
 
     def c(self) -> GwOperand:
         if self.k == 0 or self.tensor is None:
-            return GwOperand(None, None, 0, 0, 0, 0)
+            return GwOperand(None, None, 0, 0, 0, 0, 0)
+        if self.tiles:
+            _require(self.tensor, "edge tiles", torch.uint8)
+            return GwOperand(self.tensor.data_ptr(), None, 0, 256, 256, 0, _lib.LAYOUT_EDGE_TILES_BF16)
         _require(self.tensor, "operand")
         if self.index is not None:
             _require(self.index, "operand index", torch.int32)
         return GwOperand(self.tensor.data_ptr(), None if self.index is None else self.index.data_ptr(),
-                         int(self.rows_per_batch), int(self.tensor.stride(0)), int(self.k), 1 if self.projected else 0)
+                         int(self.rows_per_batch), int(self.tensor.stride(0)), int(self.k), 1 if self.projected else 0, 0)
 
 
 ZERO = Operand(None, 0, 0)
@@ -237,15 +241,35 @@ def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, r
     return outs
 
 
+def edge_tiles_bytes(batch: int, n_edges: int) -> int:
+    return int(_lib.lib().gw_edge_tiles_bytes(batch, n_edges))
+
+
+def edge_rows_to_tiles(rows: torch.Tensor, batch: int, n_edges: int, rows_per_batch: int) -> torch.Tensor:
+    """fp32 edge rows [batch * n_edges (or n_edges when shared), >= 256] -> bf16 edge tiles (byte buffer)."""
+    _require(rows, "edge rows")
+    tiles = torch.empty(edge_tiles_bytes(batch, n_edges), dtype=torch.uint8, device=rows.device)
+    with on_device_of(rows):
+        _lib.check(_lib.lib().gw_edge_rows_to_tiles(batch, n_edges, rows.data_ptr(), rows_per_batch, int(rows.stride(0)),
+                                                    tiles.data_ptr(), _stream(rows)), "gw_edge_rows_to_tiles")
+    return tiles
+
+
 def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
                         e_in: Operand, e_res: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
                         tag: Optional[str] = None, save: Optional[SavedActivations] = None) -> None:
-    """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed."""
+    """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed.
+    ``e_out``: None, fp32 rows [batch * n_edges, 256], or a uint8 buffer of ``edge_tiles_bytes`` (bf16 edge tiles)."""
     _require(src, "src", torch.int32)
     _require(dst, "dst", torch.int32)
     _require(agg, "agg")
+    e_out_layout = _lib.LAYOUT_ROWS_F32
     if e_out is not None:
-        _require(e_out, "e_out")
+        if e_out.dtype == torch.uint8:
+            _require(e_out, "e_out tiles", torch.uint8)
+            e_out_layout = _lib.LAYOUT_EDGE_TILES_BF16
+        else:
+            _require(e_out, "e_out")
     n_edges = int(src.shape[0])
     wc = pm.c((x_src.k > 0 and not x_src.projected, x_dst.k > 0 and not x_dst.projected, e_in.k > 0 and not e_in.projected))
     xs, xd, ei = x_src.c(), x_dst.c(), e_in.c()
@@ -257,8 +281,8 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
     ev = TIMER.start(tag) if TIMER is not None else None
     with on_device_of(agg):
         _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), xs, xd, ei,
-                                                     e_res.c(), wc, None if e_out is None else e_out.data_ptr(), agg.data_ptr(),
-                                                     n_dst, None if save is None else save.c(),
+                                                     e_res.c(), wc, None if e_out is None else e_out.data_ptr(), e_out_layout,
+                                                     agg.data_ptr(), n_dst, None if save is None else save.c(),
                                                      None if ws is None else ws.data_ptr(), ws_bytes, _stream(agg)),
                    "gw_edge_update_forward")
     if ev is not None:

@@ -31,13 +31,26 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 9
+#define GW_ABI_VERSION 10
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
  * in registers - BASELINE.json configs[2]. */
 #define GW_DTYPE_F32 0
 #define GW_DTYPE_BF16 1
+
+/* Memory layout of a per-edge table handed to / produced by gw_edge_update_forward.
+ * GW_LAYOUT_ROWS_F32: row-major fp32 rows (the reference's layout, graph_net_block.py:279-301 carries [E, D] tensors).
+ * GW_LAYOUT_EDGE_TILES_BF16: the per-sample edge features of a processor stack between two blocks (bf16 mode,
+ * BASELINE.json configs[2]; SURVEY.md 8(d): "halve for bf16 storage"): tiles of 64 consecutive destination-sorted edges of
+ * one batch element, each tile 4 groups x 8 K-steps x 64 lanes x 8 bf16 = 32 KiB in the MFMA B-operand order
+ *     byte offset ((b * ceil(E/64) + k/64) * 4 + (k%64)/16) * 8192 + s * 1024 + (16 q + k%16) * 16 + 2 i
+ *     holds feature 32 s + 16 (i >> 2) + 4 q + (i & 3) of edge k of batch element b    (s < 8, q < 4, i < 8).
+ * Block n writes e' in this form, block n+1 consumes it as the B operand of its layer-1 product and as its residual: half the
+ * bytes of fp32 rows and every access a coalesced 1 KiB per wave instruction.  gw_edge_tiles_bytes() sizes such a buffer,
+ * gw_edge_rows_to_tiles() converts rows a caller hands over. */
+#define GW_LAYOUT_ROWS_F32 0
+#define GW_LAYOUT_EDGE_TILES_BF16 1
 
 /* Library / ABI version and last error text (thread local). */
 int gw_version(void);
@@ -70,6 +83,9 @@ typedef struct gw_operand {
                         /* its weight slice is skipped, exact since 0*W == 0)                    */
   int32_t projected;    /* 1 = rows already hold X . W1_slice^T (from gw_project_forward): they */
                         /* are gather-added into the layer-1 accumulator, no MFMA pass           */
+  int32_t layout;       /* GW_LAYOUT_*: ROWS_F32 everywhere except the e_in / e_res operands of  */
+                        /* gw_edge_update_forward, which may be EDGE_TILES_BF16 (ptr = tile      */
+                        /* buffer, rows_per_batch / ld / index unused, k = 256)                  */
 } gw_operand;
 
 /* A 3+ layer MLP in packed form: Linear(k_in,h) ReLU [Linear(h,h) ReLU]*n_mid Linear(h,n_out) [LayerNorm]. */
@@ -125,9 +141,16 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w,
-                           float* e_out /* [batch*n_edges,256] or NULL */, float* agg /* [batch*n_dst,256] */,
+                           void* e_out /* NULL, or fp32 rows [batch*n_edges,256], or bf16 edge tiles (e_out_layout) */,
+                           int32_t e_out_layout /* GW_LAYOUT_* of e_out */, float* agg /* [batch*n_dst,256] */,
                            int32_t n_dst, const struct gw_activation_save* save /* may be NULL */,
                            void* workspace /* may be NULL */, size_t workspace_bytes, void* stream);
+/* Edge tiles (GW_LAYOUT_EDGE_TILES_BF16) are consumed and produced by the bf16 path with register-resident weights only:
+ * bf16 weights, one middle layer, x_src / x_dst pre-projected or zero, and the workspace of gw_edge_update_workspace_bytes. */
+size_t gw_edge_tiles_bytes(int32_t batch, int32_t n_edges);
+/* rows [batch (rows_per_batch > 0) or shared (0)][n_edges, ld] fp32 -> tiles (bf16, round to nearest even; padding edges 0). */
+int gw_edge_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
+                          void* stream);
 /* Scratch device memory (16-byte aligned, contents irrelevant) that lets gw_edge_update_forward pick its fastest kernel
  * for these operands - today the bf16 path with register-resident weights, which stages the layer-1 activations of all
  * tiles (32 KiB per 64 edges and batch element).  0 = none needed; the library never allocates (the caller's allocator

@@ -108,3 +108,36 @@ def pack_linear_bf16_ref(w: np.ndarray, k_lo: int, k_hi: int) -> np.ndarray:
                     if f < n_out:
                         out[s, tile, lane, i] = w[f, k_lo + kk]
     return out
+
+
+def edge_tile_feature_index() -> np.ndarray:
+    """[8 (K-step s), 4 (q), 8 (i)] -> feature 32 s + 16 (i >> 2) + 4 q + (i & 3): the bf16 MFMA B-operand order of an edge tile
+    (include/gw_amd.h: GW_LAYOUT_EDGE_TILES_BF16)."""
+    s, q, i = np.meshgrid(np.arange(8), np.arange(4), np.arange(8), indexing="ij")
+    return 32 * s + 16 * (i >> 2) + 4 * q + (i & 3)
+
+
+def edge_tiles_from_rows(rows: torch.Tensor) -> torch.Tensor:
+    """numpy/torch statement of gw_edge_rows_to_tiles: rows [B, E, 256] fp32 -> bf16 tensor [B, ceil(E/64), 4, 8, 64, 8]
+    (tile, group, K-step, lane = 16 q + column, element i); padding edges are zero."""
+    B, E, _ = rows.shape
+    neb = (E + 63) // 64
+    padded = torch.zeros((B, neb * 64, 256), dtype=torch.float32)
+    padded[:, :E] = rows
+    f = torch.from_numpy(edge_tile_feature_index())  # [8, 4, 8]
+    x = padded.reshape(B, neb, 4, 16, 256)  # [B, tile, group, column j, feature]
+    # out[b, tile, g, s, q, j, i] = x[b, tile, g, j, f[s, q, i]]
+    out = x[:, :, :, :, f]  # [B, neb, 4, 16(j), 8(s), 4(q), 8(i)]
+    out = out.permute(0, 1, 2, 4, 5, 3, 6).contiguous()  # [B, neb, 4, s, q, j, i]
+    return out.reshape(B, neb, 4, 8, 64, 8).to(torch.bfloat16)
+
+
+def edge_rows_from_tiles(tiles: torch.Tensor, E: int) -> torch.Tensor:
+    """Inverse of edge_tiles_from_rows (values as float32): [B, neb, 4, 8, 64, 8] -> [B, E, 256]."""
+    B, neb = tiles.shape[0], tiles.shape[1]
+    t = tiles.float().reshape(B, neb, 4, 8, 4, 16, 8)  # [B, neb, g, s, q, j, i]
+    f = torch.from_numpy(edge_tile_feature_index()).reshape(-1)  # order (s, q, i)
+    t = t.permute(0, 1, 2, 5, 3, 4, 6).reshape(B, neb, 4, 16, 256)  # [.., j, (s, q, i)]
+    rows = torch.empty_like(t)
+    rows[..., f] = t
+    return rows.reshape(B, neb * 64, 256)[:, :E]

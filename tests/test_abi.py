@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(cdll, name), name
     L = _lib.lib()
-    assert L.gw_version() == 9
+    assert L.gw_version() == 10
     assert L.gw_packed_floats(256, 0, 256) == 256 * 256
     assert L.gw_packed_floats(78, 0, 128) == 32 * 2 * 256
     assert L.gw_packed_floats(256, 0, 102) == 28 * 4 * 256
@@ -37,7 +37,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.gw_pack_linear(None, 256, 256, 0, 256, None, None) == -1
     assert b"bad arguments" in L.gw_last_error()
-    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, None, 1, None, None, 0, None) == -1
+    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, 0, None, 1, None, None, 0, None) == -1
     assert L.gw_edge_update_workspace_bytes(2, 100, None, None, None, None) == 0
     assert L.gw_project_forward(10, 10, None, 1, None, None, 256, 0, None, None, None) == -1
     assert L.gw_pack_linear_bf16(None, 256, 256, 0, 256, None, None) == -1
@@ -71,14 +71,21 @@ def test_edge_update_workspace_query_is_host_logic():
     from graph_weather_amd._lib import DTYPE_BF16, DTYPE_F32, GwMlpWeights, GwOperand
 
     L = _lib.lib()
-    proj = GwOperand(1, None, 10, 256, 256, 1)   # ptr only has to be non-null for the query
-    raw = GwOperand(1, None, 10, 256, 256, 0)
-    zero = GwOperand(None, None, 0, 0, 0, 0)
+    from graph_weather_amd._lib import LAYOUT_EDGE_TILES_BF16
+
+    proj = GwOperand(1, None, 10, 256, 256, 1, 0)   # ptr only has to be non-null for the query
+    raw = GwOperand(1, None, 10, 256, 256, 0, 0)
+    tiles = GwOperand(1, None, 0, 256, 256, 0, LAYOUT_EDGE_TILES_BF16)
+    zero = GwOperand(None, None, 0, 0, 0, 0, 0)
     w = GwMlpWeights()
     w.hidden, w.n_mid, w.n_out, w.weight_dtype, w.ln_width = 256, 1, 256, DTYPE_BF16, 0
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 3 * 3 * 32768  # ceil(130 / 64) = 3 tiles
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w) == 3 * 3 * 32768
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w) == 0   # a raw operand needs a third resident matrix
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w) == 0   # raw fp32 rows: the streaming kernel
+    w.w1[2] = 1
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, tiles, w) == 3 * 3 * 32768  # raw edge operand as bf16 tiles: layer-1 kernel
+    assert L.gw_edge_update_workspace_bytes(3, 130, tiles, proj, proj, w) == 0  # node operands are never tiles
+    assert L.gw_edge_tiles_bytes(3, 130) == 3 * 3 * 32768
     w.weight_dtype = DTYPE_F32
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0   # fp32: the streaming kernels, no scratch
     w.weight_dtype, w.n_mid = DTYPE_BF16, 2

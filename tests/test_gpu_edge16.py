@@ -112,3 +112,88 @@ def test_edge16_against_the_oracle(use_dst):
     err_a = (agg.cpu().reshape(B, n_dst, 256) - agg_ref).abs().max().item() / agg_ref.abs().max().item()
     print(f"[edge16 vs oracle] use_dst={use_dst}: e' max-rel {err_e:.2e}, aggregate max-rel {err_a:.2e}")
     assert 1e-5 < err_e <= 2e-2 and err_a <= 2e-2
+
+
+def test_edge_rows_to_tiles_matches_the_layout_statement():
+    """gw_edge_rows_to_tiles against the numpy statement of GW_LAYOUT_EDGE_TILES_BF16 (tests/helpers.py), ragged last tile."""
+    from .helpers import edge_tiles_from_rows
+
+    rs = np.random.RandomState(4)
+    for B, E, shared in ((3, 130, False), (1, 64, False), (2, 5, True)):
+        rows = torch.from_numpy(rs.standard_normal((1 if shared else B, E, 256)).astype(np.float32))
+        tiles = ops.edge_rows_to_tiles(rows.reshape(-1, 256).to(DEV), B, E, 0 if shared else E)
+        ref = edge_tiles_from_rows(rows.expand(B, E, 256) if shared else rows)
+        got = tiles.cpu().view(torch.bfloat16).reshape(ref.shape)
+        assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("E,out_kind", [(333, "tiles"), (64, "rows"), (700, None), (5, "tiles")])
+def test_edge16_tile_path_matches_bf16_emulation_and_oracle(E, out_kind):
+    """Processor-block form of the bf16 edge update: the per-sample edge features arrive as bf16 edge tiles (raw layer-1
+    operand on edge16_l1_kernel with W_e in LDS, and residual), node operands pre-projected, e' leaves as tiles / rows / not at
+    all.  Against (a) a float64 emulation of exactly this arithmetic (bf16-rounded operands, exact products) and (b) the oracle
+    on the raw rows (bf16 budget 2e-2)."""
+    from graph_weather_amd.utils import deterministic_fill_
+    from oracle import reference_math as om
+    import graph_weather_amd as gw
+
+    from .helpers import edge_rows_from_tiles, edge_tiles_from_rows
+
+    rs = np.random.RandomState(E)
+    B, n = 3, 50
+    ep = gw.EdgeProcessor(256, 256, 256, 2, "LayerNorm")
+    deterministic_fill_(ep, seed=23)
+    p = {"blk.edge_model." + k: v.clone() for k, v in ep.state_dict().items()}
+    x = torch.from_numpy(rs.standard_normal((B, n, 256)).astype(np.float32))
+    e = torch.from_numpy(rs.standard_normal((B, E, 256)).astype(np.float32))
+    dst = np.sort(np.where(rs.rand(E) < 0.3, n // 2, rs.randint(0, n, size=E)))
+    src = rs.randint(0, n, size=E)
+    st, dt = torch.from_numpy(src), torch.from_numpy(dst)
+    lin = [m for m in ep.edge_mlp.model if isinstance(m, torch.nn.Linear)]
+    norm = ep.edge_mlp.model[-1]
+    W0 = lin[0].weight.detach().double()
+    ps = (x.double().reshape(B * n, 256) @ W0[:, :256].t()).float()
+    pd = (x.double().reshape(B * n, 256) @ W0[:, 256:512].t()).float()
+    # (a) emulation
+    e16 = _bf(e)
+    z1 = lin[0].bias.detach().double() + ps.double().reshape(B, n, 256)[:, st] + pd.double().reshape(B, n, 256)[:, dt] + e16 @ _bf(W0[:, 512:].float()).t()
+    h1 = _bf(torch.relu(z1).float())
+    h2 = _bf(torch.relu(h1 @ _bf(lin[1].weight.detach()).t() + lin[1].bias.detach().double()).float())
+    o = h2 @ _bf(lin[2].weight.detach()).t() + lin[2].bias.detach().double()
+    y = torch.nn.functional.layer_norm(o, (256,), norm.weight.detach().double(), norm.bias.detach().double(), 1e-5) + e16
+    agg_emu = torch.zeros(B, n, 256, dtype=torch.float64)
+    agg_emu.index_add_(1, dt, y)
+    # (b) oracle
+    e_ref = torch.stack([om.edge_processor(p, "blk.edge_model", x[b][st], x[b][dt], e[b]) for b in range(B)])
+    agg_ref = torch.stack([om.scatter_sum(e_ref[b], dt, n) for b in range(B)])
+    # kernel
+    pm = PackedMLP([l.weight.detach().to(DEV) for l in lin], [l.bias.detach().to(DEV) for l in lin],
+                   (norm.weight.detach().to(DEV), norm.bias.detach().to(DEV)), ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+    tiles = ops.edge_rows_to_tiles(e.reshape(B * E, 256).to(DEV), B, E, E)
+    assert torch.equal(tiles.cpu().view(torch.bfloat16).reshape(-1), edge_tiles_from_rows(e).reshape(-1))
+    agg = torch.zeros((B * n, 256), device=DEV)
+    e_out = None
+    if out_kind == "tiles":
+        e_out = torch.full((ops.edge_tiles_bytes(B, E),), 255, dtype=torch.uint8, device=DEV)
+    elif out_kind == "rows":
+        e_out = torch.empty((B * E, 256), device=DEV)
+    ops.edge_update_forward(pm, B, st.int().to(DEV), dt.int().to(DEV), Operand(ps.to(DEV), n, 256, projected=True),
+                            Operand(pd.to(DEV), n, 256, projected=True), Operand(tiles, 0, 256, tiles=True),
+                            Operand(tiles, 0, 256, tiles=True), n, agg, e_out)
+    torch.cuda.synchronize()
+    a = agg.cpu().double().reshape(B, n, 256)
+    err_emu = (a - agg_emu).abs().max().item() / agg_emu.abs().max().item()
+    err_orc = (a - agg_ref.double()).abs().max().item() / agg_ref.abs().max().item()
+    print(f"[edge16 tiles] E={E} out={out_kind}: aggregate vs emulation {err_emu:.2e}, vs oracle {err_orc:.2e}")
+    assert err_emu < 3e-4 and err_orc <= 2e-2
+    if out_kind == "rows":
+        err_e = (e_out.cpu().double().reshape(B, E, 256) - y).abs().max().item() / y.abs().max().item()
+        assert err_e < 1.5e-3, err_e
+    if out_kind == "tiles":
+        neb = (E + 63) // 64
+        got = e_out.cpu().view(torch.bfloat16).reshape(B, neb, 4, 8, 64, 8)
+        rows = edge_rows_from_tiles(got, E).double()
+        # bf16 of y: one unit in the last place of bf16 (2^-8 relative) where fp32 and float64 sums round differently
+        assert ((rows - y).abs() <= 2.0 ** -7 * y.abs() + 1e-3 * y.abs().max()).all()
+        pad = edge_rows_from_tiles(got, neb * 64)[:, E:]
+        assert (pad == 0).all(), "padding edges of the last tile must be written as zeros"

@@ -40,11 +40,13 @@ def test_edge_kernel_isa_has_no_scratch_and_no_hidden_load_hazards(tmp_path):
 
 
 @pytest.mark.timeout(600)
-def test_edge16_kernel_keeps_its_weights_in_accumulation_registers(tmp_path):
-    """csrc/gw_edge16.hip: the persistent bf16 kernel is only fast while all 256 weight registers stay in the AGPR half and
-    feed the MFMAs from there.  Checked on the generated ISA: no scratch, every MFMA takes its A
-    operand from an AGPR, no AGPR <-> VGPR copies anywhere in the tile loop, 2 layers x 4 groups x 32 MFMAs per tile, and
-    the explicit wait states around each asm MFMA batch are present (inline asm is invisible to the hazard recogniser)."""
+def test_edge16_kernels_keep_their_weights_in_accumulation_registers(tmp_path):
+    """csrc/gw_edge16.hip: the persistent bf16 kernels are only fast while all weight registers stay in the AGPR half and feed
+    the MFMAs from there.  Checked on the generated ISA of every instantiation (4 or 8 waves x
+    residual from fp32 rows or bf16 tiles): no scratch, the register budget of its occupancy (512 for one wave per SIMD, 256
+    for two), every MFMA takes its A operand from an AGPR, no AGPR <-> VGPR copies anywhere in the tile loop, 2 layers x
+    4 groups x (64 / waves-per-matrix-quarter) MFMAs per tile, and an explicit wait state before and after each asm MFMA batch
+    (inline asm is invisible to the hazard recogniser).  The layer-1 kernel (W_e in LDS) must fit two waves per SIMD unspilled."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
@@ -52,27 +54,45 @@ def test_edge16_kernel_keeps_its_weights_in_accumulation_registers(tmp_path):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "e.o", "-save-temps"]
     subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
     text = (tmp_path / "gw_edge16-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
-    name = re.search(r"^(_Z\w*edge16_kernel\w*):", text, re.M).group(1)
-    meta = text[text.index(".amdhsa_kernel " + name):]
-    meta = meta[:meta.index(".end_amdhsa_kernel")]
-    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0
-    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 512
-    body = text[text.index(name + ":"):]
+
+    def meta_of(name):
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        return (int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)),
+                int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)))
+
+    names = re.findall(r"^(_Z\w*edge16_kernelILi\d+ELb[01]E\w*):", text, re.M)
+    assert len(names) == 4, names
+    for name in names:
+        nw = int(re.search(r"edge16_kernelILi(\d+)E", name).group(1))
+        scratch, vgpr = meta_of(name)
+        assert scratch == 0, (name, scratch)
+        assert vgpr <= (512 if nw == 4 else 256), (name, vgpr)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        mfma = [ln for ln in lines if ln.startswith("v_mfma_f32_16x16x32_bf16")]
+        per_group = 32 if nw == 4 else 16
+        assert len(mfma) == 8 * per_group, (name, len(mfma))
+        for ln in mfma:
+            ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
+            assert ops[1].startswith("a["), f"weight operand not in an AGPR: {ln}"
+        first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
+        loop = lines[first_barrier:]
+        assert not any(ln.startswith(("v_accvgpr_read", "v_accvgpr_write")) for ln in loop), f"{name}: AGPR <-> VGPR copies in the tile loop"
+        # wait states: an s_nop directly before the first and after the last MFMA of every batch (8 MFMAs between LDS reads for
+        # the 8-wave form, whose fragments arrive in two halves; 32 for the 4-wave form)
+        idx = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma")]
+        step = 32 if nw == 4 else 8
+        for k in range(0, len(idx), step):
+            b = idx[k:k + step]
+            before = lines[max(0, b[0] - 3):b[0]]
+            after = lines[b[-1] + 1:b[-1] + 4]
+            assert any(ln.startswith("s_nop") for ln in before), f"{name}: no wait state before the MFMA batch at {b[0]}"
+            assert any(ln.startswith("s_nop") for ln in after), f"{name}: no wait state after the MFMA batch at {b[-1]}"
+    l1 = re.search(r"^(_Z\w*edge16_l1_kernel\w*):", text, re.M).group(1)
+    scratch, vgpr = meta_of(l1)
+    assert scratch == 0 and vgpr <= 256, (l1, scratch, vgpr)
+    body = text[text.index(l1 + ":"):]
     body = body[:body.index(".end_amdhsa_kernel")]
-    lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
-    mfma = [ln for ln in lines if ln.startswith("v_mfma_f32_16x16x32_bf16")]
-    assert len(mfma) == 256, len(mfma)
-    for ln in mfma:
-        ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
-        assert ops[1].startswith("a["), f"weight operand not in an AGPR: {ln}"
-    first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
-    loop = lines[first_barrier:]
-    assert not any(ln.startswith(("v_accvgpr_read", "v_accvgpr_write")) for ln in loop), "AGPR <-> VGPR copies in the tile loop"
-    # wait states: an s_nop directly before the first and after the last MFMA of every 32-MFMA batch
-    idx = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma")]
-    batches = [idx[i:i + 32] for i in range(0, 256, 32)]
-    for b in batches:
-        before = lines[max(0, b[0] - 3):b[0]]
-        after = lines[b[-1] + 1:b[-1] + 4]
-        assert any(ln.startswith("s_nop") for ln in before), f"no wait state before the MFMA batch at {b[0]}"
-        assert any(ln.startswith("s_nop") for ln in after), f"no wait state after the MFMA batch at {b[-1]}"
+    assert len(re.findall(r"^\s*v_mfma_f32_16x16x32_bf16", body, re.M)) == 128
