@@ -111,6 +111,19 @@ __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 
+// x + (x of lane ^ 16) + (x of lane ^ 32) + (x of lane ^ 48): the sum over the four 16-lane rows, i.e. over the q index of
+// the accumulator layout, on the gfx950 lane-swap instructions (v_permlane16_swap swaps the odd rows of its first operand
+// with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second): two
+// VALU operations per step instead of a ds_bpermute round trip through the LDS pipeline.
+__device__ __forceinline__ float sum_rows(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned v = __float_as_uint(t);
+  const auto r2 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
 // B fragments of one 16-column group: 8 K-steps x 16 bytes per lane, all reads issued back to back
 __device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* __restrict__ hbuf_g, int lane) {
 #pragma unroll
@@ -191,53 +204,65 @@ __device__ __forceinline__ TileWalk tile_walk(int xcd, int neb, int batch) {
   return w;
 }
 
-// Launch 1a: one workgroup per tile (wave = 16-column group).  Eight lanes read one 128-byte line of a row (features
-// 32 s .. 32 s + 31), so an instruction touches 8 full cache lines; lane piece p = lane & 7 holds features 32 s + 4 p .. + 3,
-// which is half (p >> 2) of the B fragment of lane (j, q = p & 3): written there directly as 8 bytes of bf16.
+// Launch 1a: one workgroup per EDGE BLOCK (wave = 16-column group), all batch elements in turn.  Eight lanes read one
+// 128-byte line of a row (features 32 s .. 32 s + 31), so an instruction touches 8 full cache lines; lane piece p = lane & 7
+// holds features 32 s + 4 p .. + 3, which is half (p >> 2) of the B fragment of lane (j, q = p & 3): written there directly as
+// 8 bytes of bf16.  Indices, the bias and the rows of batch-shared tables (the cached per-edge products of the encoder /
+// decoder / first processor block) are fetched once per edge block and reused for every batch element.
 __global__ __launch_bounds__(256) void edge16_gather_kernel(const Edge16Args a) {
   const int lane = threadIdx.x & 63;
   const int g = threadIdx.x >> 6;
   const int piece = lane & 7;
-  const TileWalk tw = tile_walk(blockIdx.x & 7, a.neb, a.batch);
-  const int u = blockIdx.x >> 3;
-  if (u >= tw.n_units) return;
-  const int eb = tw.eb_start + u / a.batch;
-  const int b = u - (u / a.batch) * a.batch;
-  char* out_g = a.h1g + ((size_t)(b * a.neb + eb) * kGroups + g) * 8192;
-#pragma unroll
+  const int eb = blockIdx.x;
+  const int q = piece & 3, half = piece >> 2;
+#pragma unroll 1
   for (int h = 0; h < 2; ++h) {  // columns j = 8 h + (lane >> 3)
     const int j = 8 * h + (lane >> 3);
     const int kr = eb * kTileCols + 16 * g + j;
     const bool valid = kr < a.n_edges;
     const int k = valid ? kr : a.n_edges - 1;
-    const float* rows[3] = {nullptr, nullptr, nullptr};
+    int ridx[3] = {0, 0, 0};
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      if (p < a.n_proj) {
-        const int r = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
-        rows[p] = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * piece;
-      }
-    // all row pieces are requested before the first one is used: one round trip per wave, not one per K-step
-    f32x4 z[8];
+      if (p < a.n_proj) ridx[p] = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
+    // batch-independent part: bias + rows of the tables shared by the batch
+    f32x4 zs[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) z[s] = ldg4(a.b1 + 32 * s + 4 * piece);
+    for (int s = 0; s < 8; ++s) zs[s] = ldg4(a.b1 + 32 * s + 4 * piece);
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      if (p < a.n_proj) {
+      if (p < a.n_proj && a.p_rows_pb[p] == 0) {
+        const float* row = a.p_ptr[p] + (size_t)ridx[p] * (size_t)a.p_ld[p] + 4 * piece;
         f32x4 v[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = ldg4(rows[p] + 32 * s);
+        for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) z[s] += v[s];
+        for (int s = 0; s < 8; ++s) zs[s] += v[s];
       }
-    const int q = piece & 3, half = piece >> 2;
-    char* out = out_g + (16 * q + j) * 16 + half * 8;
+#pragma unroll 1
+    for (int b = 0; b < a.batch; ++b) {
+      f32x4 z[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      bf16x4 v;
+      for (int s = 0; s < 8; ++s) z[s] = zs[s];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (__bf16)(valid ? fmaxf(z[s][r], 0.f) : 0.f);
-      *(bf16x4*)(out + s * 1024) = v;
+      for (int p = 0; p < 3; ++p)
+        if (p < a.n_proj && a.p_rows_pb[p] != 0) {
+          // all row pieces are requested before the first one is used: one round trip per wave, not one per K-step
+          const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)ridx[p]) * (size_t)a.p_ld[p] + 4 * piece;
+          f32x4 v[8];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) z[s] += v[s];
+        }
+      char* out = a.h1g + ((size_t)(b * a.neb + eb) * kGroups + g) * 8192 + (16 * q + j) * 16 + half * 8;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(valid ? fmaxf(z[s][r], 0.f) : 0.f);
+        *(bf16x4*)(out + s * 1024) = v;
+      }
     }
   }
 }
@@ -447,22 +472,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
           rest[g][ks] = *(const GW_AS1 bf16x8*)(a.res_tiles + (tile * kGroups + g) * 8192 + (size_t)(s0 + ks) * 1024 + (size_t)lane * 16);
-    } else {
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
-        const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)kk[g]) * (size_t)a.res_ld + f0;
-#pragma unroll
-        for (int t = 0; t < RT; ++t) resv[g][t] = ldg4(rrow + 16 * t);
-      }
     }
     if (stamp) ts[3] = gw_clock();
-    // ---- middle layer -> Hbuf2 ----
+    // ---- middle layer -> Hbuf2 (the residual rows of the fp32-row form are requested one group per step: a burst of 8+
+    // loads stalls the wave's memory queue) ----
+    bf16x8 bfr[8];
+    load_frags(bfr, h1, lane);
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
       f32x4 acc[RT];
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[t] = bmv[t];
-      layer_group_lds(acc, wm, h1 + g * 8 * 1024, lane);
+      layer_group(acc, wm, bfr);
+      // the MFMAs have read their operands: the same registers take the next group's fragments, whose LDS latency passes
+      // under this group's epilogue
+      if (g + 1 < kGroups) load_frags(bfr, h1 + (g + 1) * 8 * 1024, lane);
+      if constexpr (!RES_TILES) {
+        const float* rrow = a.res_ptr + ((size_t)b * (size_t)a.res_rows_pb + (size_t)kk[g]) * (size_t)a.res_ld + f0;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) resv[g][t] = ldg4(rrow + 16 * t);
+      }
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
         const int T = RT * wave + t;  // output row tile -> K-step T >> 1, half T & 1 of this lane's slot
@@ -496,14 +525,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
           s1 += o[g][t][r];
           s2 = fmaf(o[g][t][r], o[g][t][r], s2);
         }
-      s1 += __shfl_xor(s1, 16);
-      s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (q == 0) {
-        lnp[(wave * kTileCols + 16 * g + j) * 2] = s1;
-        lnp[(wave * kTileCols + 16 * g + j) * 2 + 1] = s2;
-      }
+      s1 = sum_rows(s1);
+      s2 = sum_rows(s2);
+      if (q == 0) *(float2*)(lnp + (wave * kTileCols + 16 * g + j) * 2) = float2{s1, s2};
     }
     if (stamp) ts[9] = gw_clock();
     wg_barrier();  // (3) partial sums of all feature slices visible
@@ -522,8 +546,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w4 = 0; w4 < NW; ++w4) {
-        s1 += lnp[(w4 * kTileCols + col) * 2];
-        s2 += lnp[(w4 * kTileCols + col) * 2 + 1];
+        const float2 pr = *(const float2*)(lnp + (w4 * kTileCols + col) * 2);
+        s1 += pr.x;
+        s2 += pr.y;
       }
       const float mean = s1 * (1.0f / 256.0f);
       const float var = fmaxf(s2 * (1.0f / 256.0f) - mean * mean, 0.f);
@@ -559,44 +584,57 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     wg_barrier();  // (4) staged tile + destination ids visible
     if (stamp) ts[12] = gw_clock();
 
-    if (threadIdx.x < 256) {
-      // ---- per-feature segment sums over the 64 destination-sorted columns (waves 0 .. 3) ----
-      // all 64 LDS reads first (independent), then a straight-line walk over registers.  Segment ends are the same for every
-      // thread: lane i compares column i's destination with column i + 1's, the ballot is a 64-bit scalar mask, and the walk
-      // tests one bit per column (a scalar branch that is rarely taken).
-      const int f = threadIdx.x;
-      float vv[kTileCols];
+    {
+      // ---- per-feature segment sums over the 64 destination-sorted columns ----
+      // Thread (f, h) owns feature f = thread & 255 for the columns 32 h .. 32 h + 31 (NW = 8: h = 0, 1; NW = 4: one thread walks
+      // both halves).  All LDS reads first (independent), then a straight-line walk over registers.  Segment ends are the same
+      // for every thread: lane i compares column i's destination with column i + 1's, the ballot is a 64-bit scalar mask, and
+      // the walk tests one bit per column (a scalar branch that is rarely taken).  A segment that is wholly inside the
+      // thread's columns is complete: plain store.  The first and the last one may continue elsewhere - in the neighbouring
+      // tiles, or across the middle of the tile when column 31 does not end a segment - and are added with atomics.
+      constexpr int HALVES = NW / 4, COLS = kTileCols / HALVES;
+      int f = threadIdx.x & 255;
+      asm volatile("" : "+v"(f));  // keeps agg + f out of the kernel-lifetime registers (it was hoisted out of the tile loop and spilled)
+      const int hh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+      const int c0 = hh * COLS;
+      float vv[COLS];
 #pragma unroll
-      for (int i = 0; i < kTileCols; ++i) vv[i] = stage[i * kStageLd + f];
+      for (int i = 0; i < COLS; ++i) vv[i] = stage[(c0 + i) * kStageLd + f];
       const int gdv = gdl[lane];
       const int gdn = gdl[lane < kTileCols - 1 ? lane + 1 : lane];
       const unsigned long long ends = __ballot(lane == kTileCols - 1 || gdn != gdv);  // bit i: a segment ends with column i
+      const bool mid_open = HALVES == 2 && ((ends >> (COLS - 1)) & 1ull) == 0;        // a segment straddles columns 31 | 32
+      const unsigned long long mine = (ends >> c0) | (1ull << (COLS - 1));              // ... the thread's walk ends there anyway
       if (stamp) ts[13] = gw_clock();
       float run = 0.f;
       bool first = true;
 #pragma unroll
-      for (int i = 0; i < kTileCols; ++i) {
+      for (int i = 0; i < COLS; ++i) {
         run += vv[i];
-        if (__builtin_expect((ends >> i) & 1ull, 0)) {
-          const int cur = __builtin_amdgcn_readlane(gdv, i);
+        if (__builtin_expect((mine >> i) & 1ull, 0)) {
+          const int cur = __builtin_amdgcn_readlane(gdv, c0 + i);
           if (cur >= 0 && GW_SKIP(a) != 1) {
             float* dstp = a.agg + (size_t)cur * 256 + f;
-            // the first and the last segment of a tile may continue in the neighbouring tiles: atomics; the others are complete
-            if (first || i == kTileCols - 1) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool open_lo = first && (hh == 0 || mid_open);                  // may continue before this thread's columns
+            const bool open_hi = i == COLS - 1 && (hh == HALVES - 1 || mid_open);  // ... or after them
+            if (open_lo || open_hi) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else stg1(dstp, run);
           }
           first = false;
           run = 0.f;
         }
       }
-    } else if (NW == 8 && a.e_out != nullptr) {
-      // ---- e' as fp32 rows from the staged tile (waves 4 .. 7, beside the segment sums): one coalesced 1 KiB store per row ----
+    }
+    if (NW == 8 && a.e_out != nullptr) {
+      // ---- e' as fp32 rows from the staged tile: one coalesced 1 KiB store per row, 8 rows per wave ----
+      int l4 = 4 * lane;
+      asm volatile("" : "+v"(l4));  // (keeps e_out + 4 lane out of the kernel-lifetime registers)
 #pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
-        const int col = 16 * (wave - 4) + i;
+      for (int i = 0; i < 8; ++i) {
+        const int col = 8 * wave + i;
         if (k0 + col < a.n_edges) {
-          const f32x4 v = *(const f32x4*)(stage + col * kStageLd + 4 * lane);
-          stg4(a.e_out + ((size_t)b * a.n_edges + k0 + col) * 256 + 4 * lane, v);
+          const f32x4 v = *(const f32x4*)(stage + col * kStageLd + l4);
+          stg4(a.e_out + ((size_t)b * a.n_edges + k0 + col) * 256 + l4, v);
         }
       }
     }
@@ -711,9 +749,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     hipLaunchKernelGGL(edge16_l1_kernel, dim3((unsigned)n_wg), dim3(64 * kL1Waves), 128 * 1024, (hipStream_t)stream, a);
     if (int rc = check_launch("edge16_l1_kernel launch")) return rc;
   } else {
-    // one workgroup per tile, numbered like the persistent kernel walks them (XCD = workgroup & 7)
-    const int units_max = (a.neb / 8 + (a.neb % 8 ? 1 : 0)) * batch;
-    hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)(8 * units_max)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)a.neb), dim3(256), 0, (hipStream_t)stream, a);  // one workgroup per edge block
     if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
   }
   // launch 2: the resident layers

@@ -8,6 +8,7 @@ from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seede
 
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+WHICH = sys.argv[2] if len(sys.argv) > 2 else "decoder"  # "decoder" or "processor" (last launch of the stack wins)
 ll = regular_lat_lons(1.0)
 m = gw.GraphWeatherForecaster(ll); deterministic_fill_(m, 0); m = m.to(dev).eval(); m.set_compute_dtype(torch.bfloat16)
 x = seeded_features(B, len(ll)).to(dev)
@@ -19,17 +20,23 @@ with torch.no_grad():
     xe = m.encoder.encode(x)
     _, lp = m.encoder._plans(x.device)
     el = m.encoder.latent_edge_embedding(lp)
+    if WHICH == "processor":
+        torch.cuda.synchronize()
+        L.gw_debug_timestamps(buf.data_ptr(), cap, 3)
     xp, _ = m.processor.graph_processor.run_plan(xe, lp, el, True, B, False)
     torch.cuda.synchronize()
-    L.gw_debug_timestamps(buf.data_ptr(), cap, 3)
-    yd = m.decoder.decode(xp, B, residual=x.reshape(B * len(ll), 102))
-    torch.cuda.synchronize()
-    L.gw_debug_timestamps(None, 0, -1)
+    if WHICH == "processor":
+        L.gw_debug_timestamps(None, 0, -1)
+    else:
+        L.gw_debug_timestamps(buf.data_ptr(), cap, 3)
+        yd = m.decoder.decode(xp, B, residual=x.reshape(B * len(ll), 102))
+        torch.cuda.synchronize()
+        L.gw_debug_timestamps(None, 0, -1)
 rec = buf.cpu().numpy().reshape(cap, 16)
 rec = rec[rec[:, 0] != 0][:, :15]
 d = np.diff(rec, axis=1)
 names = ["wait vmcnt", "barrier1", "prefetch issue + setup", "mid group 0", "mid group 1", "mid group 2", "mid group 3", "barrier2", "res loads + out layer + LN partial", "barrier3", "LN+residual+stage", "barrier4", "seg: LDS reads", "seg: walk + stores"]
-print("workgroups", rec.shape[0], "clock ticks (s_memtime, 100 MHz => x24 for shader cycles at 2.4 GHz)")
+print(WHICH, "workgroups", rec.shape[0], "clock ticks (s_memtime, 100 MHz => x24 for shader cycles at 2.4 GHz)")
 for i, n in enumerate(names):
     print(f"{n:36s} median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
 print("tile total median", np.median(rec[:, 14] - rec[:, 0]))

@@ -80,14 +80,21 @@ def test_edge16_kernels_keep_their_weights_in_accumulation_registers(tmp_path):
         first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
         loop = lines[first_barrier:]
         assert not any(ln.startswith(("v_accvgpr_read", "v_accvgpr_write")) for ln in loop), f"{name}: AGPR <-> VGPR copies in the tile loop"
-        # wait states: an s_nop directly before the first and after the last MFMA of every batch (8 MFMAs between LDS reads for
-        # the 8-wave form, whose fragments arrive in two halves; 32 for the 4-wave form)
+        # wait states: an s_nop directly before the first and after the last MFMA of every batch (a batch = MFMAs with fewer
+        # than 8 other instructions between neighbours - the scheduler drops waits and LDS reads between them)
         idx = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma")]
-        step = 32 if nw == 4 else 8
-        for k in range(0, len(idx), step):
-            b = idx[k:k + step]
-            before = lines[max(0, b[0] - 3):b[0]]
-            after = lines[b[-1] + 1:b[-1] + 4]
+        batches, cur = [], [idx[0]]
+        for a_, b_ in zip(idx, idx[1:]):
+            if b_ - a_ <= 8:
+                cur.append(b_)
+            else:
+                batches.append(cur)
+                cur = [b_]
+        batches.append(cur)
+        assert all(len(b) % 8 == 0 for b in batches), (name, [len(b) for b in batches])
+        for b in batches:
+            before = lines[max(0, b[0] - 6):b[0]]  # (instructions between the s_nop and the MFMA are wait states too)
+            after = lines[b[-1] + 1:b[-1] + 12]
             assert any(ln.startswith("s_nop") for ln in before), f"{name}: no wait state before the MFMA batch at {b[0]}"
             assert any(ln.startswith("s_nop") for ln in after), f"{name}: no wait state after the MFMA batch at {b[-1]}"
     l1 = re.search(r"^(_Z\w*edge16_l1_kernel\w*):", text, re.M).group(1)
