@@ -86,7 +86,9 @@ struct Edge16Args {
   int res_rows_pb;
   int res_ld;
   const char* res_tiles;
-  const char* e_tiles;  // raw edge operand of edge16_l1_kernel (== res_tiles in the forecaster)
+  int res_tiles_shared;  // the residual tiles are one set shared by the batch (cached edge embeddings of encoder / decoder / block 0)
+  const char* e_tiles;   // raw edge operand of edge16_l1_kernel (== res_tiles in the forecaster)
+  int e_tiles_shared;
   float* e_out;         // fp32 rows [batch * n_edges, 256] or null
   char* e_out_tiles;    // bf16 edge tiles or null
   float* agg;
@@ -299,9 +301,10 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
     const bool valid = kr < a.n_edges;
     const int k = valid ? kr : a.n_edges - 1;
     const size_t goff = ((size_t)tile * kGroups + g) * 8192 + (size_t)lane * 16;
+    const size_t eoff = a.e_tiles_shared ? ((size_t)eb * kGroups + g) * 8192 + (size_t)lane * 16 : goff;
     bf16x8 bf[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bf[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + goff + s * 1024);
+    for (int s = 0; s < 8; ++s) bf[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + eoff + s * 1024);
     f32x4 acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = ldg4(a.b1 + 16 * t + 4 * q);
@@ -467,11 +470,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     f32x4 resv[RES_TILES ? 1 : kGroups][RES_TILES ? 1 : RT];
     bf16x8 rest[RES_TILES ? kGroups : 1][RES_TILES ? KS : 1];
     if constexpr (RES_TILES) {
+      const size_t rtile = a.res_tiles_shared ? (size_t)eb : tile;
 #pragma unroll
       for (int g = 0; g < kGroups; ++g)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          rest[g][ks] = *(const GW_AS1 bf16x8*)(a.res_tiles + (tile * kGroups + g) * 8192 + (size_t)(s0 + ks) * 1024 + (size_t)lane * 16);
+          rest[g][ks] = *(const GW_AS1 bf16x8*)(a.res_tiles + (rtile * kGroups + g) * 8192 + (size_t)(s0 + ks) * 1024 + (size_t)lane * 16);
     }
     if (stamp) ts[3] = gw_clock();
     // ---- middle layer -> Hbuf2 (the residual rows of the fp32-row form are requested one group per step: a burst of 8+
@@ -516,7 +520,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
       }
 #pragma unroll
       for (int t = 0; t < RT; ++t) o[g][t] = bov[t];
-      layer_group_lds(o[g], wo, h2 + g * 8 * 1024, lane);
+      if constexpr (RES_TILES && NW == 8) {
+        // room for all 8 fragments: one LDS wait per group, and the next group's reads are issued behind this group's MFMAs
+        if (g == 0) load_frags(bfr, h2, lane);
+        layer_group(o[g], wo, bfr);
+        if (g + 1 < kGroups) load_frags(bfr, h2 + (g + 1) * 8 * 1024, lane);
+      } else {
+        layer_group_lds(o[g], wo, h2 + g * 8 * 1024, lane);
+      }
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int t = 0; t < RT; ++t)
@@ -543,13 +554,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
       const int col = 16 * g + j;
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f;  // row q of the wave reads the partial sums of waves q, q + 4, ...; sum_rows combines the rows
 #pragma unroll
-      for (int w4 = 0; w4 < NW; ++w4) {
-        const float2 pr = *(const float2*)(lnp + (w4 * kTileCols + col) * 2);
+      for (int w4 = 0; w4 < NW / 4; ++w4) {
+        const float2 pr = *(const float2*)(lnp + ((q + 4 * w4) * kTileCols + col) * 2);
         s1 += pr.x;
         s2 += pr.y;
       }
+      s1 = sum_rows(s1);
+      s2 = sum_rows(s2);
       const float mean = s1 * (1.0f / 256.0f);
       const float var = fmaxf(s2 * (1.0f / 256.0f) - mean * mean, 0.f);
       const float rstd = 1.0f / sqrtf(var + 1e-5f);
@@ -714,6 +727,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.b1 = w->b1;
   a.w_raw = raw_e ? (const char*)w->w1[2] : nullptr;
   a.e_tiles = raw_e ? (const char*)e_in->ptr : nullptr;
+  a.e_tiles_shared = raw_e && e_in->rows_per_batch == 0;
   a.w_mid = (const char*)w->w_mid;
   a.b_mid = w->b_mid;
   a.w_out = (const char*)w->w_out;
@@ -722,6 +736,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.beta = w->ln_beta;
   if (e_res->layout == GW_LAYOUT_EDGE_TILES_BF16) {
     a.res_tiles = (const char*)e_res->ptr;
+    a.res_tiles_shared = e_res->rows_per_batch == 0;
   } else {
     a.res_ptr = e_res->ptr;
     a.res_rows_pb = e_res->rows_per_batch;

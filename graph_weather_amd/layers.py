@@ -65,8 +65,8 @@ class Feed:
     def operand(self) -> Operand:
         if self.mode == "zero":
             return ops.ZERO
-        if self.mode == "tiles":  # per-sample edge features as bf16 edge tiles (bf16 mode between processor blocks)
-            return Operand(self.tensor, 0, 256, tiles=True)
+        if self.mode == "tiles":  # edge features as bf16 edge tiles (bf16 mode); rows_pb 0 = one tile set shared by the batch
+            return Operand(self.tensor, self.rows_pb, 256, tiles=True)
         return Operand(self.tensor, self.rows_pb, 256, projected=(self.mode == "proj"))
 
     def spec(self) -> OperandSpec:
@@ -300,7 +300,7 @@ class GraphNetBlock(nn.Module):
             e_out = torch.empty(ops.edge_tiles_bytes(batch, n_edges), dtype=torch.uint8, device=device)
         else:
             e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
-        res_op = Operand(e_res, 0, 256, tiles=True) if e_res.dtype == torch.uint8 else Operand(e_res, e_res_rows_pb, 256)
+        res_op = Operand(e_res, e_res_rows_pb, 256, tiles=(e_res.dtype == torch.uint8))
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
                                 e_in.operand(), res_op, n_dst, agg, e_out, tag=tag)
         x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(),
@@ -420,17 +420,20 @@ class GraphProcessor(nn.Module):
                     if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
                         pe = ops.project_forward([mlp_e.packed().w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
                         self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
+                    if tiled and len(self._e0_cache) == 3:  # the residual of the resident bf16 kernel: e as one shared tile set
+                        self._e0_cache = self._e0_cache + (ops.edge_rows_to_tiles(e_cur, 1, n_edges, n_edges),)
                     pe = self._e0_cache[1]
                 e_in = Feed(pe, 0, "proj")
             elif tiled:
                 if e_cur.dtype != torch.uint8:  # per-sample rows handed over by a caller: into the tile format once
                     e_cur = ops.edge_rows_to_tiles(e_cur.contiguous(), batch, n_edges, n_edges)
-                e_in = Feed(e_cur, 0, "tiles")
+                e_in = Feed(e_cur, n_edges, "tiles")
             else:
                 e_in = Feed(e_cur, n_edges, "raw")
             need_e = want_edges or not last
             out_kind = "tiles" if (tiled and need_e and not (last and want_edges)) else need_e
-            x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_cur, 0 if shared else n_edges,
+            e_res = self._e0_cache[3] if (shared and tiled) else e_cur
+            x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_res, 0 if shared else n_edges,
                                Feed(x, n, "raw"), x, n, out_kind, x.device, tag="processor_edge", agg_zeroed=agg_buf)
             if e_new is not None:
                 e_cur, shared = e_new, False
@@ -693,6 +696,12 @@ class AssimilatorDecoder(nn.Module):
             if hit is None or hit[0] != key:
                 self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
             pe = self._cache["dec_pe"][1]
+            if mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and n_e > 0:
+                # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
+                hit = self._cache.get("dec_e_tiles")
+                if hit is None or hit[0] != key:
+                    self._cache["dec_e_tiles"] = (key, ops.edge_rows_to_tiles(e, 1, n_e, n_e))
+                e = self._cache["dec_e_tiles"][1]
         xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
                         tag="decoder_edge")
         res = None

@@ -89,7 +89,8 @@ class Operand:
             return GwOperand(None, None, 0, 0, 0, 0, 0)
         if self.tiles:
             _require(self.tensor, "edge tiles", torch.uint8)
-            return GwOperand(self.tensor.data_ptr(), None, 0, 256, 256, 0, _lib.LAYOUT_EDGE_TILES_BF16)
+            # rows_per_batch: n_edges = one tile set per batch element, 0 = one set shared by the batch
+            return GwOperand(self.tensor.data_ptr(), None, int(self.rows_per_batch), 256, 256, 0, _lib.LAYOUT_EDGE_TILES_BF16)
         _require(self.tensor, "operand")
         if self.index is not None:
             _require(self.index, "operand index", torch.int32)

@@ -85,7 +85,8 @@ typedef struct gw_operand {
                         /* are gather-added into the layer-1 accumulator, no MFMA pass           */
   int32_t layout;       /* GW_LAYOUT_*: ROWS_F32 everywhere except the e_in / e_res operands of  */
                         /* gw_edge_update_forward, which may be EDGE_TILES_BF16 (ptr = tile      */
-                        /* buffer, rows_per_batch / ld / index unused, k = 256)                  */
+                        /* buffer; rows_per_batch = n_edges: one tile set per batch element, 0:  */
+                        /* one set shared by the batch; ld / index unused, k = 256)              */
 } gw_operand;
 
 /* A 3+ layer MLP in packed form: Linear(k_in,h) ReLU [Linear(h,h) ReLU]*n_mid Linear(h,n_out) [LayerNorm]. */

@@ -65,8 +65,8 @@ def test_edge16_matches_bf16_emulation(case):
         assert err_e < 1.5e-3 * y.abs().max().item(), f"{case}: e' max err {err_e:.3e}"
 
 
-@pytest.mark.parametrize("use_dst", [False, True])
-def test_edge16_against_the_oracle(use_dst):
+@pytest.mark.parametrize("use_dst,res_tiles", [(False, False), (True, False), (True, True)])
+def test_edge16_against_the_oracle(use_dst, res_tiles):
     """The same launches against the ORACLE (oracle/reference_math.py: EdgeProcessor.forward + scatter_sum in full precision
     from the raw node / edge rows), not against a model of the kernel: the layer-1 products the kernel gathers are made from
     the raw rows here, so split, gather, both resident layers, LayerNorm, residual and segment sums are all inside the
@@ -106,11 +106,14 @@ def test_edge16_against_the_oracle(use_dst):
     e_out = torch.empty((B * E, 256), device=DEV)
     ops.edge_update_forward(pm, B, st.int().to(DEV), dt.int().to(DEV), Operand(ps.to(DEV), n_src, 256, projected=True),
                             Operand(pd.to(DEV), 0, 256, projected=True) if use_dst else ops.ZERO,
-                            Operand(pe.to(DEV), 0, 256, projected=True), Operand(e.to(DEV), 0, 256), n_dst, agg, e_out)
+                            Operand(pe.to(DEV), 0, 256, projected=True),
+                            # residual: the batch-shared edge rows as fp32 rows, or as ONE shared set of bf16 edge tiles
+                            Operand(ops.edge_rows_to_tiles(e.to(DEV), 1, E, E), 0, 256, tiles=True) if res_tiles else Operand(e.to(DEV), 0, 256),
+                            n_dst, agg, e_out)
     torch.cuda.synchronize()
     err_e = (e_out.cpu().reshape(B, E, 256) - e_ref).abs().max().item() / e_ref.abs().max().item()
     err_a = (agg.cpu().reshape(B, n_dst, 256) - agg_ref).abs().max().item() / agg_ref.abs().max().item()
-    print(f"[edge16 vs oracle] use_dst={use_dst}: e' max-rel {err_e:.2e}, aggregate max-rel {err_a:.2e}")
+    print(f"[edge16 vs oracle] use_dst={use_dst} res_tiles={res_tiles}: e' max-rel {err_e:.2e}, aggregate max-rel {err_a:.2e}")
     assert 1e-5 < err_e <= 2e-2 and err_a <= 2e-2
 
 
@@ -178,8 +181,8 @@ def test_edge16_tile_path_matches_bf16_emulation_and_oracle(E, out_kind):
     elif out_kind == "rows":
         e_out = torch.empty((B * E, 256), device=DEV)
     ops.edge_update_forward(pm, B, st.int().to(DEV), dt.int().to(DEV), Operand(ps.to(DEV), n, 256, projected=True),
-                            Operand(pd.to(DEV), n, 256, projected=True), Operand(tiles, 0, 256, tiles=True),
-                            Operand(tiles, 0, 256, tiles=True), n, agg, e_out)
+                            Operand(pd.to(DEV), n, 256, projected=True), Operand(tiles, E, 256, tiles=True),
+                            Operand(tiles, E, 256, tiles=True), n, agg, e_out)
     torch.cuda.synchronize()
     a = agg.cpu().double().reshape(B, n, 256)
     err_emu = (a - agg_emu).abs().max().item() / agg_emu.abs().max().item()
