@@ -118,7 +118,8 @@ def lib():
                                                  POINTER(GwMlpWeights)]
     L.gw_node_update_forward.restype = c_int
     L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
-                                         POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]
+                                         POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_int32,
+                                         POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]
     L.gw_project_forward.restype = c_int
     L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
                                      c_int32, c_int32, c_void_p, c_void_p, c_void_p]

@@ -154,7 +154,7 @@ __device__ __forceinline__ const float* operand_row16(const float* ptr, const in
 }
 
 // K1S: 32-wide K-steps of a raw layer-1 operand (8: k = 256, 4: k <= 128, 1: k <= 32); HT / OT: hidden / output row tiles.
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE>
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST = false>
 __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds16[];
   constexpr int HTP = (HT + 3) / 4 * 4, OTP = (OT + 3) / 4 * 4;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     for (int g = 0; g < NG; ++g) relu_to_bin<HT>(reinterpret_cast<bf16x8(&)[HKS]>(bin[g]), acc[g]);
     __builtin_amdgcn_sched_barrier(0);
     init_bias16<OT>(o, a.b_out, q);
-    pass16<HKS, BKS, OT, OTP>(o, bin, w_out, nullptr, 0, lds16, parity, lane, wave);
+    pass16<HKS, BKS, OT, OTP>(o, bin, w_out, POST ? (const char*)a.proj_w[0] : nullptr, POST ? H_CS * H_STEP : 0, lds16, parity, lane, wave);
   }
 
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
@@ -337,6 +337,38 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
           }
         }
       }
+    }
+  }
+
+  // ---- POST: the next block's layer-1 products of the new rows, while they are still in registers (see ChainArgs) ----
+  if constexpr (POST) {
+    static_assert(!POST || (OT == 16 && HT == 16 && SHARE_ACC), "POST works on 256-wide rows");
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bin[g][s] = pack8(o[g][2 * s], o[g][2 * s + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.zero_rows != nullptr) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (valid[g]) {
+          float* zrow = a.zero_rows + (size_t)cc[g] * 256;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) stg4(zrow + 16 * t + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+    }
+#pragma unroll 1
+    for (int sl = 0; sl < a.n_post; ++sl) {
+      init_bias16<HT>(acc, nullptr, q);  // (acc aliases o: the new rows have been stored and packed into bin)
+      const char* nx = sl + 1 < a.n_post ? (const char*)a.proj_w[sl + 1] : nullptr;
+      pass16<8, BKS, HT, HTP>(acc, bin, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, lds16, parity, lane, wave);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (valid[g]) {
+          float* prow = a.proj_out[sl] + (size_t)cc[g] * 256;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) stg4(prow + 16 * t + 4 * q, acc[g][t]);
+        }
     }
   }
 
@@ -436,6 +468,8 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
       return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
     case 3:
       return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, true>, a, stream, grid_y, kLdsWeights);
+    case 4:
+      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
   }
   return set_error(GW_E_BADARG, "chain16_launch: bad kind");
 }

@@ -26,9 +26,13 @@ struct ChainArgs {
   int seg_ld[3];
   int seg_k[3];
   int seg_proj[3];     // operand is already multiplied by its layer-1 weight slice: rows are [hidden] wide
-  // single-layer projection mode: blockIdx.y selects the weight slice / output table
+  // single-layer projection mode: blockIdx.y selects the weight slice / output table.
+  // POST mode (node update): after LayerNorm + residual the new rows x' are multiplied, still in registers, by n_post packed
+  // [256, 256] slices - the layer-1 products of the NEXT block's edge MLP (P_s = x' Ws^T, P_d = x' Wd^T) - and written to
+  // proj_out[s]: the separate projection launch of every block and its re-read of x' disappear.
   const float* proj_w[4];
   float* proj_out[4];
+  int n_post;
   // weights
   const float* w1[3];
   const float* b1;
@@ -64,7 +68,7 @@ struct ChainArgs {
   float* save_y;
 };
 
-// bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices).
+// bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices), 4 node update + POST.
 int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
 
 // debug timestamp hook (gw_debug_timestamps) and tuning overrides, defined in gw_kernels.hip

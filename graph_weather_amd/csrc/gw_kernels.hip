@@ -232,7 +232,7 @@ __device__ __forceinline__ const float* operand_row(const float* ptr, const int*
   return ptr + ((size_t)b * (size_t)rows_pb + (size_t)r) * (size_t)ld;
 }
 
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE = false>
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE = false, bool POST = false>
 __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HS = HT * 4;                   // K-steps of a hidden layer
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
         for (int t = 0; t < OT; ++t) rres[t] = ldg4(rrow + 16 * t + 4 * q);
       }
-      mma_pass<HS, OT, false>(o, hin, a.w_out, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
+      mma_pass<HS, OT, false>(o, hin, a.w_out, POST ? a.proj_w[0] : nullptr, POST ? kChunkSteps * HSTEPF : 0, lds, parity, lane, wave,
+                              nullptr, false, nullptr, false, q);
     }
   }
 
@@ -464,6 +465,33 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
           if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[t][r]);
       } else {
         stg4(orow + f0, o[t]);
+      }
+    }
+  }
+
+  // ---- POST: the next block's layer-1 products of the new rows, while they are still in registers ----
+  if constexpr (POST) {
+    static_assert(!POST || (OT == 16 && HT == 16), "POST works on 256-wide rows");
+    float xin[64];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xin[4 * t + r] = o[t < OT ? t : 0][r];
+    if (a.zero_rows != nullptr && valid) {  // the aggregate buffer of the next block's edge update, zero-filled on the side
+      float* zrow = a.zero_rows + (size_t)c * 256;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) stg4(zrow + 16 * t + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+#pragma unroll 1
+    for (int sl = 0; sl < a.n_post; ++sl) {
+      f32x4 pacc[16];
+      init_bias<16>(pacc, nullptr, q);
+      const float* nx = sl + 1 < a.n_post ? a.proj_w[sl + 1] : nullptr;
+      mma_pass<64, 16, false>(pacc, xin, a.proj_w[sl], nx, kChunkSteps * HSTEPF, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
+      if (valid) {
+        float* prow = a.proj_out[sl] + (size_t)c * 256;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) stg4(prow + 16 * t + 4 * q, pacc[t]);
       }
     }
   }
@@ -848,7 +876,8 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
 
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
                            const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
-                           const gw_activation_save* save, void* stream) {
+                           const gw_activation_save* save, int32_t n_post, const float* const* post_w, float* const* post_out,
+                           float* zero_rows, void* stream) {
   if (!x || !agg || !w || !x_out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: more than 2^31-1 rows");
@@ -871,10 +900,21 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.out_ld = out_ld;
   a.out_cols = 256;
   if (int rc = fill_save(a, save, w, "gw_node_update_forward")) return rc;
+  if (n_post < 0 || n_post > 4 || (n_post > 0 && (!post_w || !post_out))) return fail(GW_E_BADARG, "gw_node_update_forward: bad post products");
+  if ((n_post > 0 || zero_rows) && (save || out_ld != 256)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: post products need out_ld 256, no activation saving");
+  if (zero_rows && n_post == 0) return fail(GW_E_BADARG, "gw_node_update_forward: zero_rows comes with post products");
+  for (int i = 0; i < n_post; ++i) {
+    if (!post_w[i] || !post_out[i]) return fail(GW_E_BADARG, "gw_node_update_forward: null post slice / output");
+    a.proj_w[i] = post_w[i];
+    a.proj_out[i] = post_out[i];
+  }
+  a.n_post = n_post;
+  a.zero_rows = zero_rows;
   if (w->weight_dtype == GW_DTYPE_BF16) {
     if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
-    return gw::chain16_launch(2, a, 256, 256, 256, 1, stream);
+    return gw::chain16_launch(n_post > 0 ? 4 : 2, a, 256, 256, 256, 1, stream);
   }
+  if (n_post > 0) return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, 2);
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }
 

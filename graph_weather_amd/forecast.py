@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from .graphs import build_forecast_graphs
-from .layers import Decoder, Encoder, Processor, set_compute_dtype
+from .layers import Decoder, Encoder, Processor, fused_forward, set_compute_dtype
 
 try:  # forecast.py:8,61 - hub mixin gives save_pretrained / from_pretrained / push_to_hub
     from huggingface_hub import PyTorchModelHubMixin
@@ -141,10 +141,5 @@ class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
         if features.dim() != 3 or features.shape[2] < self.output_dim:
             raise RuntimeError("graph_weather_amd: features must be [B, nodes, >= %d channels]" % self.output_dim)
         features = features.contiguous()
-        B = int(features.shape[0])
-        x = self.encoder.encode(features)
-        _, lat_plan = self.encoder._plans(features.device)
-        e_lat = self.encoder.latent_edge_embedding(lat_plan)
-        x, _ = self.processor.graph_processor.run_plan(x, lat_plan, e_lat, True, B, False)
-        G = self.encoder.num_latlons
-        return self.decoder.decode(x, B, residual=features.reshape(B * G, features.shape[2]))
+        B, G = int(features.shape[0]), self.encoder.num_latlons
+        return fused_forward(self.encoder, self.processor, self.decoder, features, features.reshape(B * G, features.shape[2]))

@@ -284,10 +284,12 @@ class GraphNetBlock(nn.Module):
 
     def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
             x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
-            tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+            tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None, post_w=None, post_zero: bool = False):
         """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
         Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``).
-        ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch)."""
+        ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch).
+        ``post_w`` (inference): packed layer-1 slices of the NEXT block's edge MLP - the node update multiplies the new rows by
+        them in the same launch (and zero-fills the next aggregate with ``post_zero``); returns (x', e', products, next_agg)."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
         if _autograd_on(self, x_src.tensor, x_dst.tensor, e_in.tensor, e_res, x_node.tensor, x_res):
             agg, e_out = ag.edge_update(self.edge_model.edge_mlp, plan, batch, (x_src.spec(), x_dst.spec(), e_in.spec()),
@@ -303,8 +305,13 @@ class GraphNetBlock(nn.Module):
         res_op = Operand(e_res, e_res_rows_pb, 256, tiles=(e_res.dtype == torch.uint8))
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
                                 e_in.operand(), res_op, n_dst, agg, e_out, tag=tag)
-        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(),
-                                        ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256),
+        res_x = ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256)
+        if post_w is not None:
+            next_agg = torch.empty((batch * n_dst, 256), dtype=torch.float32, device=device) if post_zero else None
+            x_new, posts = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(), res_x,
+                                                   Operand(agg, n_dst, 256), post_w=post_w, zero_rows=next_agg)
+            return x_new, e_out, posts, next_agg
+        x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(), res_x,
                                         Operand(agg, n_dst, 256))
         return x_new, e_out
 
@@ -352,7 +359,7 @@ class GraphProcessor(nn.Module):
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
     def run_plan(self, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: bool, batch: int,
-                 want_edges: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                 want_edges: bool, pre_proj=None, tail_w=None):
         """Layer 1 of every edge MLP is split (cat[x_s, x_d, e].W1^T = x_s.Ws^T + x_d.Wd^T + e.We^T): the node
         products are computed once per node (shared by its ~7 incident edges) and gathered per edge; when the
         incoming edge features are batch independent (first block after the encoder) their product is cached.
@@ -360,7 +367,11 @@ class GraphProcessor(nn.Module):
         Under autograd, ``use_checkpointing`` (graph_net_block.py:294-297: one checkpoint per block) and
         ``checkpoint_segments`` (processor.py:70-81: -1 = the whole stack, N > 0 = every N blocks) select recomputation:
         the segment's forward runs the inference kernels and keeps only its inputs; its backward re-runs it with the
-        activation saves (autograd.recompute)."""
+        activation saves (autograd.recompute).
+
+        Inference: the layer-1 node products of block i + 1 are made by the node update of block i (``GraphNetBlock.run``
+        ``post_w``); ``pre_proj`` = (P_s, P_d, zeroed aggregate) of the first block when the caller's previous launch made
+        them, ``tail_w`` = packed slices to multiply the final node rows with (returns (x, e, products) then)."""
         _check_native_dims(*self._dims)
         nb = len(self.blocks)
         seg = 0
@@ -372,7 +383,9 @@ class GraphProcessor(nn.Module):
             elif self.use_checkpointing:
                 seg = 1
         if seg <= 0 or nb == 0:
-            x, e_cur, _ = self._run_blocks(0, nb, x, e, e_shared, plan, batch, want_edges)
+            x, e_cur, _, tail = self._run_blocks(0, nb, x, e, e_shared, plan, batch, want_edges, pre_proj, tail_w)
+            if tail_w is not None:
+                return x, (e_cur if want_edges else None), tail
             return x, (e_cur if want_edges else None)
         e_cur, shared = e, e_shared
         for lo in range(0, nb, seg):
@@ -380,21 +393,26 @@ class GraphProcessor(nn.Module):
             need_e = want_edges or hi < nb
 
             def fn(x_, e_, lo=lo, hi=hi, shared=shared, need_e=need_e):
-                xo, eo, _ = self._run_blocks(lo, hi, x_, e_, shared, plan, batch, need_e)
+                xo, eo, _, _ = self._run_blocks(lo, hi, x_, e_, shared, plan, batch, need_e)
                 return (xo, eo) if need_e else (xo,)
 
             outs = ag.recompute(fn, (x, e_cur), nn.ModuleList(list(self.blocks)[lo:hi]))
             x = outs[0]
             if need_e:
                 e_cur, shared = outs[1], False
+        if tail_w is not None:  # (checkpointed training path: the caller's projection stays separate)
+            return x, (e_cur if want_edges else None), None
         return x, (e_cur if want_edges else None)
 
     def _run_blocks(self, lo: int, hi: int, x: torch.Tensor, e: torch.Tensor, e_shared: bool, plan: GraphPlan, batch: int,
-                    want_edges: bool):
-        """Blocks [lo, hi) of the stack; returns (x, e, e_shared) after them (e of the last block only if ``want_edges``)."""
+                    want_edges: bool, pre_proj=None, tail_w=None):
+        """Blocks [lo, hi) of the stack; returns (x, e, e_shared, tail products) after them (e of the last block only if
+        ``want_edges``)."""
         n, n_edges = plan.n_dst, plan.num_edges
         e_cur, shared = e, e_shared
         train = _autograd_on(self, x, e)
+        carried = None if train else pre_proj  # (P_s, P_d, zeroed aggregate) made by the previous node update
+        tail = None
         for i in range(lo, hi):
             blk = self.blocks[i]
             last = i == hi - 1
@@ -405,9 +423,13 @@ class GraphProcessor(nn.Module):
                 ps, pd = ag.project(mlp_e, (0, 1), x, batch * n, n)
             else:
                 pm_e = mlp_e.packed()
-                if mlp_e.compute_dtype == torch.float32:  # the projection launch also zero-fills this block's aggregate
-                    agg_buf = torch.empty((batch * n, 256), dtype=torch.float32, device=x.device)
-                ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n, zero_rows=agg_buf)
+                if carried is not None:
+                    ps, pd, agg_buf = carried
+                    carried = None
+                else:
+                    if mlp_e.compute_dtype == torch.float32:  # the projection launch also zero-fills this block's aggregate
+                        agg_buf = torch.empty((batch * n, 256), dtype=torch.float32, device=x.device)
+                    ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n, zero_rows=agg_buf)
             # bf16 mode (inference): between blocks the per-sample edge features live as bf16 "edge tiles" - the MFMA B-operand
             # order the next block's layer-1 product consumes directly (csrc/gw_edge16.hip); only what crosses the API is rows
             tiled = ((not train) and mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0
@@ -433,11 +455,28 @@ class GraphProcessor(nn.Module):
             need_e = want_edges or not last
             out_kind = "tiles" if (tiled and need_e and not (last and want_edges)) else need_e
             e_res = self._e0_cache[3] if (shared and tiled) else e_cur
-            x, e_new = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_res, 0 if shared else n_edges,
-                               Feed(x, n, "raw"), x, n, out_kind, x.device, tag="processor_edge", agg_zeroed=agg_buf)
+            # what the node update of this block also produces (inference): the next block's layer-1 node products
+            post_w, post_zero = None, False
+            if not train:
+                pm_n = blk.node_model.node_mlp.packed()
+                if i + 1 < len(self.blocks):
+                    nxt = self.blocks[i + 1].edge_model.edge_mlp.packed()
+                    if nxt.weight_dtype == pm_n.weight_dtype and i + 1 < hi:
+                        post_w, post_zero = [nxt.w1[0], nxt.w1[1]], True
+                elif tail_w is not None and all(w_.dtype == pm_n.w_out.dtype for w_ in tail_w):
+                    post_w = list(tail_w)
+            res = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_res, 0 if shared else n_edges,
+                          Feed(x, n, "raw"), x, n, out_kind, x.device, tag="processor_edge", agg_zeroed=agg_buf,
+                          post_w=post_w, post_zero=post_zero)
+            x, e_new = res[0], res[1]
+            if post_w is not None:
+                if post_zero:
+                    carried = (res[2][0], res[2][1], res[3])
+                else:
+                    tail = res[2]
             if e_new is not None:
                 e_cur, shared = e_new, False
-        return x, e_cur, shared
+        return x, e_cur, shared, tail
 
     def _plan_for(self, edge_index: torch.Tensor, num_nodes: int) -> GraphPlan:
         key = (edge_index.data_ptr(), tuple(edge_index.shape), _ver(edge_index), num_nodes)
@@ -524,8 +563,9 @@ class Encoder(nn.Module):
         return self._cached("lat_e", list(self.latent_edge_encoder.parameters()),
                             lambda: self.latent_edge_encoder.table(plan.edge_attr))
 
-    def encode(self, features: torch.Tensor) -> torch.Tensor:
-        """encoder.py:199-223 -> mesh node features [(B*M), D] (batch-major, reversed-rank mesh order)."""
+    def encode(self, features: torch.Tensor, post_w=None):
+        """encoder.py:199-223 -> mesh node features [(B*M), D] (batch-major, reversed-rank mesh order).  ``post_w`` (inference,
+        fused forward): packed layer-1 slices of the first processor block - returns (x, products, zeroed aggregate)."""
         if features.dim() != 3 or features.shape[1] != self.num_latlons:
             raise RuntimeError("features must be [B, %d, input_dim]" % self.num_latlons)
         B, G, F = (int(s) for s in features.shape)
@@ -537,6 +577,11 @@ class Encoder(nn.Module):
         blk = self.graph_processor.blocks[0]
         _check_native_dims(*self.graph_processor._dims)
         pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
+        if post_w is not None:
+            x, _, posts, agg0 = blk.run(B, enc_plan, Feed(xg, G, "raw"), Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e, 0,
+                                        Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge",
+                                        post_w=post_w, post_zero=True)
+            return x, posts, agg0
         x, _ = blk.run(B, enc_plan, Feed(xg, G, "raw"), Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e, 0,
                        Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge")
         return x
@@ -668,8 +713,9 @@ class AssimilatorDecoder(nn.Module):
         return self._cache["dec_e"][1]
 
     def decode(self, processor_features: torch.Tensor, batch_size: int,
-               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """assimilator_decoder.py:173-200 (+ decoder.py:93 when ``residual`` [B*G, ld] is given)."""
+               residual: Optional[torch.Tensor] = None, ps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """assimilator_decoder.py:173-200 (+ decoder.py:93 when ``residual`` [B*G, ld] is given).  ``ps`` (inference, fused
+        forward): the layer-1 product of the mesh rows with this decoder's edge MLP, made by the processor's last launch."""
         B, G, M = batch_size, self.num_latlons, self.num_h3
         if processor_features.shape[0] != B * M:
             raise RuntimeError("processor_features must have batch*num_h3 rows")
@@ -690,7 +736,8 @@ class AssimilatorDecoder(nn.Module):
             pe = ag.project(mlp_e, (2,), e, n_e, n_e)[0]
         else:
             pm_e = mlp_e.packed()
-            ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M)[0]
+            if ps is None:
+                ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M)[0]
             key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
             hit = self._cache.get("dec_pe")
             if hit is None or hit[0] != key:
@@ -717,6 +764,33 @@ class AssimilatorDecoder(nn.Module):
 
     def forward(self, processor_features: torch.Tensor, batch_size: int) -> torch.Tensor:
         return self.decode(processor_features, batch_size)
+
+
+def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "AssimilatorDecoder", features: torch.Tensor,
+                  residual: torch.Tensor) -> torch.Tensor:
+    """encoder -> processor -> decoder of the forecaster / GraphCast wrapper in native layouts.  Inference: every node update
+    also makes the layer-1 node products (and zero-fills the aggregate) of the block that follows it - the encoder's for the
+    first processor block, each processor block's for the next, the last one's for the decoder - so no projection launch runs
+    between blocks.  Under autograd the blocks keep their separate differentiable projections."""
+    B = int(features.shape[0])
+    gp = processor.graph_processor
+    _, lat_plan = encoder._plans(features.device)
+    e_lat = encoder.latent_edge_embedding(lat_plan)
+    fuse = (not _autograd_on(encoder, features) and not _autograd_on(gp) and not _autograd_on(decoder) and len(gp.blocks) > 0
+            and gp.checkpoint_segments == 0)
+    if fuse:
+        enc_n = encoder.graph_processor.blocks[0].node_model.node_mlp.packed()
+        first = gp.blocks[0].edge_model.edge_mlp.packed()
+        dec_e = decoder.graph_processor.blocks[0].edge_model.edge_mlp.packed()
+        last_n = gp.blocks[-1].node_model.node_mlp.packed()
+        fuse = first.weight_dtype == enc_n.weight_dtype and dec_e.weight_dtype == last_n.weight_dtype
+    if not fuse:
+        x = encoder.encode(features)
+        x, _ = gp.run_plan(x, lat_plan, e_lat, True, B, False)
+        return decoder.decode(x, B, residual=residual)
+    x, posts, agg0 = encoder.encode(features, post_w=[first.w1[0], first.w1[1]])
+    x, _, tail = gp.run_plan(x, lat_plan, e_lat, True, B, False, pre_proj=(posts[0], posts[1], agg0), tail_w=[dec_e.w1[0]])
+    return decoder.decode(x, B, residual=residual, ps=None if tail is None else tail[0])
 
 
 class Decoder(AssimilatorDecoder):

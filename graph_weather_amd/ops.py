@@ -291,18 +291,30 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
 
 
 def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, x_res: Operand, agg: Operand,
-                        out: Optional[torch.Tensor] = None, save: Optional[SavedActivations] = None) -> torch.Tensor:
-    """graph_net_block.py:189-191 (NodeProcessor after aggregation)."""
+                        out: Optional[torch.Tensor] = None, save: Optional[SavedActivations] = None,
+                        post_w: Optional[Sequence[torch.Tensor]] = None, zero_rows: Optional[torch.Tensor] = None):
+    """graph_net_block.py:189-191 (NodeProcessor after aggregation).  With ``post_w`` (packed [256, 256] slices of the NEXT
+    block's layer-1 weight) the products of the new rows with them are computed in the same launch: returns
+    (x_new, [products]); ``zero_rows`` [n_rows, 256] is zero-filled on the side (the next block's aggregate)."""
+    import ctypes
+
     dev = agg.tensor.device
     if out is None:
         out = torch.empty((n_rows, pm.n_out), dtype=torch.float32, device=dev)
     _require(out, "out")
     wc = pm.c((x.k > 0 and not x.projected, True, False))
+    n_post = 0 if post_w is None else len(post_w)
+    outs, wp, op = [], None, None
+    if n_post:
+        outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=dev) for _ in range(n_post)]
+        wp = (ctypes.c_void_p * n_post)(*[w_.data_ptr() for w_ in post_w])
+        op = (ctypes.c_void_p * n_post)(*[o_.data_ptr() for o_ in outs])
     with on_device_of(out):
         _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), x_res.c(), agg.c(), wc, out.data_ptr(),
-                                                     int(out.stride(0)), None if save is None else save.c(), _stream(out)),
+                                                     int(out.stride(0)), None if save is None else save.c(), n_post, wp, op,
+                                                     None if zero_rows is None else zero_rows.data_ptr(), _stream(out)),
                    "gw_node_update_forward")
-    return out
+    return (out, outs) if post_w is not None else out
 
 
 def normalized_mse_forward(pred: torch.Tensor, target: torch.Tensor, lat_weights: torch.Tensor,

@@ -165,7 +165,14 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
  * 190 - the x-slice of layer 1 is skipped); x_res = raw node rows for the residual (NULL or k == 0: none). */
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
                            const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
-                           const struct gw_activation_save* save /* may be NULL */, void* stream);
+                           const struct gw_activation_save* save /* may be NULL */,
+                           int32_t n_post /* 0..4 */, const float* const* post_w, float* const* post_out,
+                           float* zero_rows /* may be NULL */, void* stream);
+/* n_post > 0: while the new rows are still in registers they are multiplied by n_post packed [256, 256] slices (packing and
+ * dtype of w) and the products written to post_out[s] [n_rows, 256]: post_out[s][j] = x_new[j] . post_w[s]^T - the layer-1
+ * products of the NEXT block's edge MLP over the node table (see gw_project_forward), so that GraphProcessor's loop
+ * (graph_net_block.py:293-301) needs no projection launch between blocks.  zero_rows: [n_rows, 256] filled with zeros on the
+ * side (the next block's aggregate buffer).  Inference only (save must be NULL), out_ld 256. */
 
 /* ---- NormalizedMSELoss.forward (losses.py:66-94, normalize on/off) ---------------------------------------
  * loss = mean_{b,n}( w_lat[n / num_lon] * mean_c( (pred-target)^2 [/ var_c] ) ); *loss_out must be zeroed. */

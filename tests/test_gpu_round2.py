@@ -291,3 +291,33 @@ def test_flat_adamw_is_one_launch_and_matches_torch_adamw():
         xa, _ = a(x, ei, ea)
         xb, _ = b(x, ei, ea)
     assert _rel(xa, xb) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_node_update_post_products_equal_the_separate_projection(dtype):
+    """gw_node_update_forward with n_post > 0 (the next block's layer-1 products made while x' is in registers, next aggregate
+    zero-filled on the side) against the two-launch form: node update, then gw_project_forward on its output."""
+    from graph_weather_amd import ops
+    from graph_weather_amd.ops import Operand
+
+    torch.manual_seed(0)
+    blk = gw.build_graph_processor_block(256, 256, 256, 256, 2, 2, "LayerNorm")
+    nxt = gw.build_graph_processor_block(256, 256, 256, 256, 2, 2, "LayerNorm")
+    deterministic_fill_(blk, seed=3)
+    deterministic_fill_(nxt, seed=4)
+    gw.set_compute_dtype(blk, dtype)
+    gw.set_compute_dtype(nxt, dtype)
+    blk, nxt = blk.to(DEV), nxt.to(DEV)
+    B, n = 3, 777  # ragged: not a multiple of the 64 / 128 column tiles
+    x = torch.randn(B * n, 256, device=DEV)
+    agg = torch.randn(B * n, 256, device=DEV)
+    pm_n, pm_e = blk.node_model.node_mlp.packed(), nxt.edge_model.edge_mlp.packed()
+    ref = ops.node_update_forward(pm_n, B * n, n, Operand(x, n, 256), Operand(x, n, 256), Operand(agg, n, 256))
+    ps_ref, pd_ref = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(ref, n, 256), B * n, n)
+    zero = torch.full((B * n, 256), 7.0, device=DEV)
+    out, (ps, pd) = ops.node_update_forward(pm_n, B * n, n, Operand(x, n, 256), Operand(x, n, 256), Operand(agg, n, 256),
+                                            post_w=[pm_e.w1[0], pm_e.w1[1]], zero_rows=zero)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(ps, ps_ref) and torch.equal(pd, pd_ref)
+    assert (zero == 0).all()
