@@ -301,6 +301,8 @@ def main(argv=None, backend="nccl", device=None, model_factory=None):
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None, help="override the matrix-product dtype")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE metric (default); train = forward + loss + backward + gradient all-reduce + AdamW")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams of the mesh stack in the forward (0 = automatic: per-sample "
+                                                           "chains on 2 streams for fp32 and batch >= 2; 1 = one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c5 measurements and the cold-cache step")
     args = ap.parse_args(argv)
@@ -345,6 +347,8 @@ def main(argv=None, backend="nccl", device=None, model_factory=None):
     model = model.to(dev).eval()
     if cfg["precision"] == "bf16":
         model.set_compute_dtype(torch.bfloat16)
+    if args.streams and hasattr(model, "processor"):
+        model.processor.graph_processor.streams = args.streams
     feats = seeded_features(batch, len(lat_lons), 102, seed=42 + rank).to(dev)  # resident in HBM before timing
 
     def barrier():

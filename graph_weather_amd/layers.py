@@ -354,8 +354,10 @@ class GraphProcessor(nn.Module):
             self.blocks.append(build_graph_processor_block(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge,
                                                            hidden_layers_node, hidden_layers_edge, norm_type))
         self.checkpoint_segments = 0  # processor.py:70-81, set through Processor.set_checkpoint_segments
+        self.streams = 0  # HIP streams of the fused inference forward: 0 = automatic (see forward_streams), 1 = one stream
         self._plan_cache = None
         self._e0_cache = None
+        self._side_streams = {}
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
     def run_plan(self, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: bool, batch: int,
@@ -404,6 +406,43 @@ class GraphProcessor(nn.Module):
             return x, (e_cur if want_edges else None), None
         return x, (e_cur if want_edges else None)
 
+    def forward_streams(self, batch: int) -> int:
+        """Streams the fused inference forward runs this stack on: ``self.streams`` if set, else 2 for fp32 matrix products and
+        batch >= 2 (mesh-sized fp32 launches leave workgroup slots idle in their last round; the bf16 kernels are persistent
+        and occupy every CU by themselves), else 1."""
+        if self.streams > 0:
+            return max(1, min(int(self.streams), batch))
+        fp32 = all(b.edge_model.edge_mlp.compute_dtype == torch.float32 for b in self.blocks)
+        return 2 if (fp32 and batch >= 2) else 1
+
+    def side_streams(self, device, n: int):
+        key = (str(device), n)
+        if key not in self._side_streams:
+            self._side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return self._side_streams[key]
+
+    def prepare_shared(self, e: torch.Tensor, plan: GraphPlan) -> None:
+        """Everything the per-sample chains share, made on the current stream: packed weights of every block and the cached
+        product / tile form of the batch-independent edge features of the first block."""
+        for blk in self.blocks:
+            blk.edge_model.edge_mlp.packed()
+            blk.node_model.node_mlp.packed()
+        if len(self.blocks):
+            self._shared_e0(self.blocks[0], e, plan.num_edges)
+
+    def _shared_e0(self, blk, e_cur: torch.Tensor, n_edges: int):
+        """(We . e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights)."""
+        mlp_e = blk.edge_model.edge_mlp
+        pm_e = mlp_e.packed()
+        tiled = mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and n_edges > 0
+        key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key())
+        if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
+            pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
+            self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
+        if tiled and len(self._e0_cache) == 3:  # the residual of the resident bf16 kernel: e as one shared tile set
+            self._e0_cache = self._e0_cache + (ops.edge_rows_to_tiles(e_cur, 1, n_edges, n_edges),)
+        return self._e0_cache
+
     def _run_blocks(self, lo: int, hi: int, x: torch.Tensor, e: torch.Tensor, e_shared: bool, plan: GraphPlan, batch: int,
                     want_edges: bool, pre_proj=None, tail_w=None):
         """Blocks [lo, hi) of the stack; returns (x, e, e_shared, tail products) after them (e of the last block only if
@@ -438,13 +477,7 @@ class GraphProcessor(nn.Module):
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
                 else:
-                    key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key())
-                    if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
-                        pe = ops.project_forward([mlp_e.packed().w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
-                        self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
-                    if tiled and len(self._e0_cache) == 3:  # the residual of the resident bf16 kernel: e as one shared tile set
-                        self._e0_cache = self._e0_cache + (ops.edge_rows_to_tiles(e_cur, 1, n_edges, n_edges),)
-                    pe = self._e0_cache[1]
+                    pe = self._shared_e0(blk, e_cur, n_edges)[1]
                 e_in = Feed(pe, 0, "proj")
             elif tiled:
                 if e_cur.dtype != torch.uint8:  # per-sample rows handed over by a caller: into the tile format once
@@ -789,8 +822,38 @@ def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "Assimila
         x, _ = gp.run_plan(x, lat_plan, e_lat, True, B, False)
         return decoder.decode(x, B, residual=residual)
     x, posts, agg0 = encoder.encode(features, post_w=[first.w1[0], first.w1[1]])
-    x, _, tail = gp.run_plan(x, lat_plan, e_lat, True, B, False, pre_proj=(posts[0], posts[1], agg0), tail_w=[dec_e.w1[0]])
-    return decoder.decode(x, B, residual=residual, ps=None if tail is None else tail[0])
+    n_streams = gp.forward_streams(B)
+    if n_streams <= 1:
+        x, _, tail = gp.run_plan(x, lat_plan, e_lat, True, B, False, pre_proj=(posts[0], posts[1], agg0), tail_w=[dec_e.w1[0]])
+        return decoder.decode(x, B, residual=residual, ps=None if tail is None else tail[0])
+    # The mesh stack as independent per-sample chains on separate HIP streams (batch elements never interact,
+    # encoder.py:212-218).  One batched launch of a mesh-sized kernel fills the chip unevenly - 1 287 64-column tiles on 512
+    # workgroup slots are 2.5 rounds that cost 3, a node update has 184 workgroups for 256 CUs - and each launch waits for the
+    # previous one; with the samples on different streams one chain's tail round and small launches run beside the other
+    # chain's full rounds.  Everything shared (packed weights, cached products) is made on the main stream before the fork.
+    dev = features.device
+    M = encoder.num_h3
+    main = torch.cuda.current_stream(dev)
+    gp.prepare_shared(e_lat, lat_plan)
+    streams = gp.side_streams(dev, n_streams)
+    base, rem = divmod(B, n_streams)
+    xs, tails, lo = [], [], 0
+    for i, st in enumerate(streams):
+        hi = lo + base + (1 if i < rem else 0)
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            pre = (posts[0][lo * M:hi * M], posts[1][lo * M:hi * M], agg0[lo * M:hi * M])
+            xo, _, tl = gp.run_plan(x[lo * M:hi * M], lat_plan, e_lat, True, hi - lo, False, pre_proj=pre, tail_w=[dec_e.w1[0]])
+        xs.append(xo)
+        tails.append(tl[0])
+        lo = hi
+    for st in streams:
+        main.wait_stream(st)
+        for t in (x, posts[0], posts[1], agg0):
+            t.record_stream(st)  # allocated on the main stream, read on a side stream
+    for t in xs + tails:
+        t.record_stream(main)  # allocated on a side stream, read on the main stream
+    return decoder.decode(torch.cat(xs), B, residual=residual, ps=torch.cat(tails))
 
 
 class Decoder(AssimilatorDecoder):

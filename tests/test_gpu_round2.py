@@ -321,3 +321,31 @@ def test_node_update_post_products_equal_the_separate_projection(dtype):
     assert torch.equal(out, ref)
     assert torch.equal(ps, ps_ref) and torch.equal(pd, pd_ref)
     assert (zero == 0).all()
+
+
+def test_per_sample_streams_give_the_single_stream_forecast():
+    """The fused inference forward runs the mesh stack as per-sample chains on side streams (fp32, batch >= 2): same forecast
+    as on one stream, for stream counts that do and do not divide the batch; repeated calls reuse buffers across streams."""
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    model = model.to(DEV).eval()
+    gp = model.processor.graph_processor
+    feats = seeded_features(5, len(lat_lons), 102, seed=11).to(DEV)
+    assert gp.forward_streams(5) == 2 and gp.forward_streams(1) == 1
+    with torch.no_grad():
+        gp.streams = 1
+        y1 = model(feats)
+        outs = {}
+        for n in (2, 3, 5):
+            gp.streams = n
+            for _ in range(3):
+                outs[n] = model(feats)
+        gp.streams = 0
+        y_auto = model(feats)
+    torch.cuda.synchronize()
+    for n, y in outs.items():
+        assert _rel(y, y1) <= 1e-5, n
+    assert _rel(y_auto, y1) <= 1e-5
+    model.set_compute_dtype(torch.bfloat16)
+    assert gp.forward_streams(5) == 1  # the persistent bf16 kernels fill the chip by themselves
