@@ -17,6 +17,7 @@ from .layers import (  # noqa: F401
     Processor,
     build_graph_processor_block,
     set_compute_dtype,
+    set_deterministic,
 )
 from .graphcast import GraphCast, GraphCastConfig  # noqa: F401
 from .losses import NormalizedMSELoss  # noqa: F401

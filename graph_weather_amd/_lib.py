@@ -18,6 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 ABI_VERSION = 10
 DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16 = 0, 1
+EDGE_DETERMINISTIC = 1
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
@@ -108,14 +109,14 @@ def lib():
     L.gw_edge_update_forward.restype = c_int
     L.gw_edge_update_forward.argtypes = [c_int32, c_int32, c_void_p, c_void_p, POINTER(GwOperand), POINTER(GwOperand),
                                          POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_int32, c_void_p,
-                                         c_int32, POINTER(GwActivationSave), c_void_p, c_size_t, c_void_p]
+                                         c_int32, POINTER(GwActivationSave), c_void_p, c_size_t, c_int32, c_void_p]
     L.gw_edge_tiles_bytes.restype = c_size_t
     L.gw_edge_tiles_bytes.argtypes = [c_int32, c_int32]
     L.gw_edge_rows_to_tiles.restype = c_int
     L.gw_edge_rows_to_tiles.argtypes = [c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]
     L.gw_edge_update_workspace_bytes.restype = c_size_t
     L.gw_edge_update_workspace_bytes.argtypes = [c_int32, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
-                                                 POINTER(GwMlpWeights)]
+                                                 POINTER(GwMlpWeights), c_int32]
     L.gw_node_update_forward.restype = c_int
     L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
                                          POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_int32,

@@ -78,6 +78,7 @@ struct EdgeArgs {
   int res_ld;
   float* e_out;
   float* agg;
+  float* carry;  // deterministic segment sums: per-tile carry records (gw_internal.hpp), NULL = atomics
   // training: activations saved for the backward (gw_activation_save; NULL in inference); n_mid == 1 only
   float* save_h;
   long long save_stride;
@@ -535,6 +536,29 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
     const int gdv = gdl[lane];
     const int gdn = gdl[lane < kColsPerWG - 1 ? lane + 1 : lane];
     const unsigned long long ends = __ballot(lane == kColsPerWG - 1 || gdn != gdv);  // bit i: a run ends with column i
+    // deterministic mode: is the first / last run of this tile open towards the neighbouring tile (same destination row)?
+    bool open_lo = true, open_hi = true;  // atomics mode: assume so
+    float* rec = nullptr;
+    if (a.carry != nullptr) {
+      rec = a.carry + (size_t)tile * kCarryFloats;
+      const int c_prev = tile_c0 - 1, c_next = tile_c0 + kColsPerWG;
+      int gd_prev = -2, gd_next = -2;
+      if (c_prev >= 0) {
+        const int bp = c_prev / a.n_edges;
+        gd_prev = bp * a.n_dst + ldgi(a.dst + (c_prev - bp * a.n_edges));
+      }
+      if (c_next < a.n_cols) {
+        const int bn = c_next / a.n_edges;
+        gd_next = bn * a.n_dst + ldgi(a.dst + (c_next - bn * a.n_edges));
+      }
+      open_lo = gd_prev == __builtin_amdgcn_readlane(gdv, 0);
+      open_hi = gd_next == __builtin_amdgcn_readlane(gdv, kColsPerWG - 1);
+      if (f == 0) {  // header: no slot used yet (the same thread fills it in below)
+        rec[512] = __int_as_float(-1);
+        rec[513] = __int_as_float(-1);
+        rec[514] = __int_as_float(0);
+      }
+    }
     float run = 0.f;
     bool first = true;
 #pragma unroll
@@ -544,8 +568,25 @@ __global__ __launch_bounds__(kThreads, 2) void edge_kernel(const EdgeArgs a) {
         const int cur = __builtin_amdgcn_readlane(gdv, i);
         if (cur >= 0) {
           float* dstp = a.agg + (size_t)cur * 256 + f;
-          if (first || i == kColsPerWG - 1) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else stg1(dstp, run);
+          const bool lo = first && open_lo, hi = i == kColsPerWG - 1 && open_hi;
+          if (rec != nullptr) {
+            if (lo) {  // continues from the previous tile: slot 0 (and the chain runs on through this tile if it is open high too)
+              rec[f] = run;
+              if (f == 0) {
+                rec[512] = __int_as_float(cur);
+                if (hi) rec[514] = __int_as_float(1);
+              }
+            } else if (hi) {  // a segment that starts here and continues in the next tile: slot 1
+              rec[256 + f] = run;
+              if (f == 0) rec[513] = __int_as_float(cur);
+            } else {
+              stg1(dstp, run);
+            }
+          } else if (first || i == kColsPerWG - 1) {
+            __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            stg1(dstp, run);
+          }
         }
         first = false;
         run = 0.f;
@@ -601,9 +642,38 @@ bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const 
   return impl != 0;
 }
 
+// ---- deterministic segment sums: carry records -> totals, one workgroup per chain start, in tile order ----
+__global__ __launch_bounds__(256) void segment_fixup_kernel(long long n_tiles, const float* __restrict__ carry, float* __restrict__ agg) {
+  const long long t = blockIdx.x;
+  const float* rec = carry + (size_t)t * kCarryFloats;
+  const int row = __float_as_int(rec[513]);
+  if (row < 0) return;  // no segment starts in this tile and leaves it
+  const int f = threadIdx.x;
+  float acc = rec[256 + f];
+  for (long long u = t + 1; u < n_tiles; ++u) {
+    const float* r = carry + (size_t)u * kCarryFloats;
+    if (__float_as_int(r[512]) != row) break;  // (cannot happen for a well-formed chain; keeps a malformed one finite)
+    acc += r[f];
+    if (__float_as_int(r[514]) != 1) break;  // the segment ends in tile u
+  }
+  agg[(size_t)row * 256 + f] = acc;
+}
+
+size_t segment_carry_bytes(int64_t n_tiles) { return (size_t)n_tiles * kCarryFloats * sizeof(float); }
+
+int segment_fixup_launch(int64_t n_tiles, const float* carry, float* agg, void* stream) {
+  if (n_tiles <= 0) return GW_OK;
+  hipLaunchKernelGGL(segment_fixup_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, (long long)n_tiles, carry, agg);
+  return check_launch("segment_fixup_kernel launch");
+}
+
+size_t edge_fast_carry_bytes(int32_t batch, int32_t n_edges) {
+  return segment_carry_bytes(((int64_t)batch * n_edges + kColsPerWG - 1) / kColsPerWG);
+}
+
 int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                      const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                     float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, void* stream) {
+                     float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, float* carry, void* stream) {
   EdgeArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;
@@ -643,6 +713,7 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
   a.res_ld = e_res->ld;
   a.e_out = e_out;
   a.agg = agg;
+  a.carry = carry;
   if (save) {
     a.save_h = save->hidden;
     a.save_stride = save->hidden_stride;
@@ -672,13 +743,13 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
     a.xcd_base = (xcd_map != 0 && tiles >= 64) ? tiles / 8 : 0;
     a.xcd_rem = tiles % 8;
   }
-  if (raw) {
-    if (n_proj == 1) return launch(edge_kernel<true, 1>, a, stream);
-    return launch(edge_kernel<true, 2>, a, stream);
-  }
-  if (n_proj == 1) return launch(edge_kernel<false, 1>, a, stream);
-  if (n_proj == 2) return launch(edge_kernel<false, 2>, a, stream);
-  return launch(edge_kernel<false, 3>, a, stream);
+  int rc;
+  if (raw) rc = n_proj == 1 ? launch(edge_kernel<true, 1>, a, stream) : launch(edge_kernel<true, 2>, a, stream);
+  else if (n_proj == 1) rc = launch(edge_kernel<false, 1>, a, stream);
+  else if (n_proj == 2) rc = launch(edge_kernel<false, 2>, a, stream);
+  else rc = launch(edge_kernel<false, 3>, a, stream);
+  if (rc != GW_OK || carry == nullptr) return rc;
+  return segment_fixup_launch((a.n_cols + kColsPerWG - 1) / kColsPerWG, carry, agg, stream);
 }
 
 }  // namespace gw

@@ -92,6 +92,7 @@ struct Edge16Args {
   float* e_out;         // fp32 rows [batch * n_edges, 256] or null
   char* e_out_tiles;    // bf16 edge tiles or null
   float* agg;
+  float* carry;  // deterministic segment sums: per-tile carry records (gw_internal.hpp), NULL = atomics; 4-wave kernel only
   char* h1g;  // workspace: layer-1 activations, [batch * neb tiles][4 groups][8 K-steps][64 lanes][8 bf16]
   int skip;                 // tuning builds only (GW_EDGE16_SKIP): 1 = no aggregate writes
   unsigned long long* dbg;  // gw_debug_timestamps(kind 3): phase clocks of each workgroup's third tile
@@ -619,6 +620,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
       const bool mid_open = HALVES == 2 && ((ends >> (COLS - 1)) & 1ull) == 0;        // a segment straddles columns 31 | 32
       const unsigned long long mine = (ends >> c0) | (1ull << (COLS - 1));              // ... the thread's walk ends there anyway
       if (stamp) ts[13] = gw_clock();
+      // deterministic mode (carry records instead of atomics, NW == 4 only: one thread walks all 64 columns): is the first /
+      // last run open towards the neighbouring tile of the same batch element?
+      bool det_lo = false, det_hi = false;
+      float* rec = nullptr;
+      if (HALVES == 1 && a.carry != nullptr) {
+        rec = a.carry + tile * kCarryFloats;
+        const int gd_prev = eb > 0 ? b * a.n_dst + ldgi(a.dst + k0 - 1) : -2;
+        const int gd_next = k0 + kTileCols < a.n_edges ? b * a.n_dst + ldgi(a.dst + k0 + kTileCols) : -2;
+        det_lo = gd_prev == __builtin_amdgcn_readlane(gdv, 0);
+        det_hi = gd_next == __builtin_amdgcn_readlane(gdv, kTileCols - 1);
+        if (f == 0) {
+          rec[512] = __int_as_float(-1);
+          rec[513] = __int_as_float(-1);
+          rec[514] = __int_as_float(0);
+        }
+      }
       float run = 0.f;
       bool first = true;
 #pragma unroll
@@ -628,10 +645,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
           const int cur = __builtin_amdgcn_readlane(gdv, c0 + i);
           if (cur >= 0 && GW_SKIP(a) != 1) {
             float* dstp = a.agg + (size_t)cur * 256 + f;
-            const bool open_lo = first && (hh == 0 || mid_open);                  // may continue before this thread's columns
-            const bool open_hi = i == COLS - 1 && (hh == HALVES - 1 || mid_open);  // ... or after them
-            if (open_lo || open_hi) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else stg1(dstp, run);
+            if (rec != nullptr) {
+              const bool lo = first && det_lo, hi = i == COLS - 1 && det_hi;
+              if (lo) {
+                rec[f] = run;
+                if (f == 0) {
+                  rec[512] = __int_as_float(cur);
+                  if (hi) rec[514] = __int_as_float(1);
+                }
+              } else if (hi) {
+                rec[256 + f] = run;
+                if (f == 0) rec[513] = __int_as_float(cur);
+              } else {
+                stg1(dstp, run);
+              }
+            } else {
+              const bool open_lo = first && (hh == 0 || mid_open);                  // may continue before this thread's columns
+              const bool open_hi = i == COLS - 1 && (hh == HALVES - 1 || mid_open);  // ... or after them
+              if (open_lo || open_hi) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else stg1(dstp, run);
+            }
           }
           first = false;
           run = 0.f;
@@ -694,6 +727,9 @@ bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_
 size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges) {
   return (size_t)batch * (size_t)((n_edges + kTileCols - 1) / kTileCols) * (size_t)kHBytes;
 }
+size_t edge16_workspace_bytes_det(int32_t batch, int32_t n_edges) {
+  return edge16_workspace_bytes(batch, n_edges) + segment_carry_bytes((int64_t)batch * ((n_edges + kTileCols - 1) / kTileCols));
+}
 
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                          void* stream) {
@@ -705,7 +741,7 @@ int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int3
 
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, void* stream) {
+                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, bool deterministic, void* stream) {
   Edge16Args a;
   memset(&a, 0, sizeof(a));
   a.batch = batch;
@@ -746,6 +782,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.e_out_tiles = (char*)e_out_tiles;
   a.agg = agg;
   a.h1g = (char*)workspace;
+  if (deterministic) a.carry = (float*)((char*)workspace + edge16_workspace_bytes(batch, n_edges));  // behind the layer-1 tiles
 #ifdef GW_TUNING
   {
     static const int skip = GW_TUNE("GW_EDGE16_SKIP", 0);
@@ -770,7 +807,11 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   // launch 2: the resident layers
   static const int nw = GW_TUNE("GW_EDGE16_NW", 8);
   const bool rt = a.res_tiles != nullptr;
-  if (nw == 4) return rt ? launch_resident(edge16_kernel<4, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false>, 256, n_wg, a, stream);
+  if (nw == 4 || deterministic) {  // the deterministic walk is a whole-tile walk per thread: the 4-wave form
+    const int rc = rt ? launch_resident(edge16_kernel<4, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false>, 256, n_wg, a, stream);
+    if (rc != GW_OK || !deterministic) return rc;
+    return segment_fixup_launch((int64_t)batch * a.neb, a.carry, agg, stream);
+  }
   return rt ? launch_resident(edge16_kernel<8, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false>, 512, n_wg, a, stream);
 }
 

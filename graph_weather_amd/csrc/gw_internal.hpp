@@ -102,19 +102,33 @@ struct DeviceOnce {
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
 
+// Deterministic segment sums (GW_EDGE_DETERMINISTIC): runs of a 64-column tile that continue in a neighbouring tile are not
+// added to agg with atomics (whose order is not fixed) but parked in a carry record per tile; segment_fixup_launch then adds
+// the records of every multi-tile segment in tile order and stores the total.  Record of tile t (kCarryFloats floats):
+//   [0, 256)    partial sum of the tile's FIRST run if it continues from tile t - 1 ("open low")
+//   [256, 512)  partial sum of the tile's LAST run if it continues in tile t + 1 and is not that same open-low run
+//   [512]       destination row (global) of slot 0 or -1        [513] destination row of slot 1 or -1
+//   [514]       1 if the tile is ONE run that is open at both ends (slot 0 holds it, the chain goes on through it)
+constexpr int kCarryFloats = 528;  // 2 x 256 + header, 16-byte aligned
+size_t segment_carry_bytes(int64_t n_tiles);
+int segment_fixup_launch(int64_t n_tiles, const float* carry, float* agg, void* stream);
+
 // Fast path of gw_edge_update_forward (gw_edge.hip): at most one raw operand, the others pre-projected or zero.
 // Returns GW_E_UNSUPPORTED (without touching the error string) when the operand combination is not eligible.
 bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w);
 int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                      const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                     float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, void* stream);
+                     float* e_out, float* agg, int32_t n_dst, const gw_activation_save* save, float* carry /* deterministic mode */,
+                     void* stream);
+size_t edge_fast_carry_bytes(int32_t batch, int32_t n_edges);
 
 // bf16 edge update with register-resident weights (gw_edge16.hip)
 bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w);
 size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges);
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, void* stream);
+                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, bool deterministic, void* stream);
+size_t edge16_workspace_bytes_det(int32_t batch, int32_t n_edges);  // layer-1 tiles + carry records
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                          void* stream);
 

@@ -790,9 +790,12 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
 }
 
 size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
-                                      const gw_operand* e_in, const gw_mlp_weights* w) {
+                                      const gw_operand* e_in, const gw_mlp_weights* w, int32_t flags) {
   if (batch <= 0 || n_edges <= 0 || !x_src || !x_dst || !e_in || !w) return 0;
-  return gw::edge16_eligible(x_src, x_dst, e_in, w) ? gw::edge16_workspace_bytes(batch, n_edges) : 0;
+  const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
+  if (gw::edge16_eligible(x_src, x_dst, e_in, w)) return det ? gw::edge16_workspace_bytes_det(batch, n_edges) : gw::edge16_workspace_bytes(batch, n_edges);
+  if (det && w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) return gw::edge_fast_carry_bytes(batch, n_edges);
+  return 0;
 }
 
 size_t gw_edge_tiles_bytes(int32_t batch, int32_t n_edges) {
@@ -810,7 +813,8 @@ int gw_edge_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w, void* e_out_any, int32_t e_out_layout, float* agg,
-                           int32_t n_dst, const gw_activation_save* save, void* workspace, size_t workspace_bytes, void* stream) {
+                           int32_t n_dst, const gw_activation_save* save, void* workspace, size_t workspace_bytes, int32_t flags,
+                           void* stream) {
   if (batch <= 0 || n_edges < 0 || n_dst <= 0) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if (n_edges == 0) return GW_OK;  // nothing to add: agg stays as the caller zeroed it
   if (!src || !dst || !x_src || !x_dst || !e_in || !e_res || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
@@ -834,21 +838,28 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   if (x_src->layout != GW_LAYOUT_ROWS_F32 || x_dst->layout != GW_LAYOUT_ROWS_F32)
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: node operands must be fp32 rows");
   float* e_out = tiles_out ? nullptr : (float*)e_out_any;
+  const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
+  const size_t ws16 = det ? gw::edge16_workspace_bytes_det(batch, n_edges) : gw::edge16_workspace_bytes(batch, n_edges);
+  if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");
   if (tiles_in || tiles_out) {
-    if (save || !workspace || !gw::edge16_eligible(x_src, x_dst, e_in, w) || workspace_bytes < gw::edge16_workspace_bytes(batch, n_edges))
+    if (save || !workspace || !gw::edge16_eligible(x_src, x_dst, e_in, w) || workspace_bytes < ws16)
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
                                     "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");
     return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, tiles_out ? e_out_any : nullptr, agg,
-                             n_dst, workspace, stream);
+                             n_dst, workspace, det, stream);
   }
   if (w->weight_dtype == GW_DTYPE_F32 && (!save || w->n_mid == 1) && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) {
     if (save && (!save->hidden || !save->pre_norm || save->hidden_ld < 256 || save->hidden_ld % 4 != 0))
       return fail(GW_E_BADARG, "gw_edge_update_forward: bad gw_activation_save");
-    return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, save, stream);
+    if (det && (!workspace || workspace_bytes < gw::edge_fast_carry_bytes(batch, n_edges)))
+      return fail(GW_E_BADARG, "gw_edge_update_forward: deterministic mode needs the workspace of gw_edge_update_workspace_bytes");
+    return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, save,
+                                det ? (float*)workspace : nullptr, stream);
   }
-  if (!save && workspace && gw::edge16_eligible(x_src, x_dst, e_in, w) &&
-      workspace_bytes >= gw::edge16_workspace_bytes(batch, n_edges))
-    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace, stream);
+  if (!save && workspace && gw::edge16_eligible(x_src, x_dst, e_in, w) && workspace_bytes >= ws16)
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace, det, stream);
+  if (det) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums exist on the fast edge kernels only "
+                                         "(at most one raw operand, native 256 widths) and need their workspace");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;

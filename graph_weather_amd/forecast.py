@@ -104,6 +104,13 @@ class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
         set_compute_dtype(self, dtype)
         return self
 
+    def set_deterministic(self, flag: bool = True) -> "GraphWeatherForecaster":
+        """Bitwise reproducible inference forward - see ``layers.set_deterministic``."""
+        from .layers import set_deterministic
+
+        set_deterministic(self, flag)
+        return self
+
     def _create_grid_mapping(self, unique_lats, unique_lons):
         """forecast.py:178-192 (vectorised; identical (row, col) pairs)."""
         lo_lat, hi_lat = min(unique_lats), max(unique_lats)

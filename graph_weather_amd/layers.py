@@ -76,6 +76,17 @@ class Feed:
 FEED_ZERO = Feed(None, 0, "zero")
 
 
+def set_deterministic(module: nn.Module, flag: bool = True) -> nn.Module:
+    """Bitwise run-to-run reproducible forward (inference): the segment sums of every message-passing block under ``module``
+    use per-tile carry records added in tile order instead of fp32 atomics, whose order is not fixed (include/gw_amd.h:
+    GW_EDGE_DETERMINISTIC).  The reference's ``scatter_add_`` is order-nondeterministic on a GPU as well - this is an extra,
+    at a small cost (the carry records, one more small launch per edge update; the bf16 path uses its 4-wave kernel)."""
+    for m in module.modules():
+        if isinstance(m, GraphNetBlock):
+            m.deterministic = bool(flag)
+    return module
+
+
 def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
     """Select the matrix-product dtype of every MLP under ``module``: ``torch.float32`` (default, the reference's
     arithmetic) or ``torch.bfloat16`` (bf16 MFMA with fp32 accumulation; parameters, activations in HBM, LayerNorm,
@@ -281,6 +292,7 @@ class GraphNetBlock(nn.Module):
         super().__init__()
         self.edge_model = edge_model
         self.node_model = node_model
+        self.deterministic = False  # set_deterministic(): reproducible segment sums
 
     def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
             x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
@@ -304,7 +316,7 @@ class GraphNetBlock(nn.Module):
             e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
         res_op = Operand(e_res, e_res_rows_pb, 256, tiles=(e_res.dtype == torch.uint8))
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
-                                e_in.operand(), res_op, n_dst, agg, e_out, tag=tag)
+                                e_in.operand(), res_op, n_dst, agg, e_out, tag=tag, deterministic=self.deterministic)
         res_x = ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256)
         if post_w is not None:
             next_agg = torch.empty((batch * n_dst, 256), dtype=torch.float32, device=device) if post_zero else None

@@ -258,9 +258,10 @@ def edge_rows_to_tiles(rows: torch.Tensor, batch: int, n_edges: int, rows_per_ba
 
 def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
                         e_in: Operand, e_res: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
-                        tag: Optional[str] = None, save: Optional[SavedActivations] = None) -> None:
+                        tag: Optional[str] = None, save: Optional[SavedActivations] = None, deterministic: bool = False) -> None:
     """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed.
-    ``e_out``: None, fp32 rows [batch * n_edges, 256], or a uint8 buffer of ``edge_tiles_bytes`` (bf16 edge tiles)."""
+    ``e_out``: None, fp32 rows [batch * n_edges, 256], or a uint8 buffer of ``edge_tiles_bytes`` (bf16 edge tiles).
+    ``deterministic``: bitwise reproducible segment sums (carry records + a fix-up launch instead of atomics)."""
     _require(src, "src", torch.int32)
     _require(dst, "dst", torch.int32)
     _require(agg, "agg")
@@ -274,9 +275,10 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
     n_edges = int(src.shape[0])
     wc = pm.c((x_src.k > 0 and not x_src.projected, x_dst.k > 0 and not x_dst.projected, e_in.k > 0 and not e_in.projected))
     xs, xd, ei = x_src.c(), x_dst.c(), e_in.c()
+    flags = _lib.EDGE_DETERMINISTIC if deterministic else 0
     ws, ws_bytes = None, 0
     if save is None:  # scratch for the kernel the library would like to use (the library never allocates)
-        ws_bytes = int(_lib.lib().gw_edge_update_workspace_bytes(batch, n_edges, xs, xd, ei, wc))
+        ws_bytes = int(_lib.lib().gw_edge_update_workspace_bytes(batch, n_edges, xs, xd, ei, wc, flags))
         if ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=agg.device)
     ev = TIMER.start(tag) if TIMER is not None else None
@@ -284,7 +286,7 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
         _lib.check(_lib.lib().gw_edge_update_forward(batch, n_edges, src.data_ptr(), dst.data_ptr(), xs, xd, ei,
                                                      e_res.c(), wc, None if e_out is None else e_out.data_ptr(), e_out_layout,
                                                      agg.data_ptr(), n_dst, None if save is None else save.c(),
-                                                     None if ws is None else ws.data_ptr(), ws_bytes, _stream(agg)),
+                                                     None if ws is None else ws.data_ptr(), ws_bytes, flags, _stream(agg)),
                    "gw_edge_update_forward")
     if ev is not None:
         TIMER.stop(tag, ev)

@@ -52,6 +52,13 @@ extern "C" {
 #define GW_LAYOUT_ROWS_F32 0
 #define GW_LAYOUT_EDGE_TILES_BF16 1
 
+/* flags of gw_edge_update_forward.  GW_EDGE_DETERMINISTIC: the segment sums (scatter_sum, graph_net_block.py:188) are
+ * bitwise reproducible from run to run - partial sums of segments that cross a 64-edge tile are parked in per-tile carry
+ * records and added in tile order by a second small launch, instead of meeting in fp32 atomics whose order is not fixed
+ * (torch_scatter's scatter_add_ on a GPU is order-nondeterministic too; this is an extra).  Needs the workspace of
+ * gw_edge_update_workspace_bytes(..., flags). */
+#define GW_EDGE_DETERMINISTIC 1
+
 /* Library / ABI version and last error text (thread local). */
 int gw_version(void);
 const char* gw_last_error(void);
@@ -145,7 +152,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
                            void* e_out /* NULL, or fp32 rows [batch*n_edges,256], or bf16 edge tiles (e_out_layout) */,
                            int32_t e_out_layout /* GW_LAYOUT_* of e_out */, float* agg /* [batch*n_dst,256] */,
                            int32_t n_dst, const struct gw_activation_save* save /* may be NULL */,
-                           void* workspace /* may be NULL */, size_t workspace_bytes, void* stream);
+                           void* workspace /* may be NULL */, size_t workspace_bytes, int32_t flags /* GW_EDGE_* */, void* stream);
 /* Edge tiles (GW_LAYOUT_EDGE_TILES_BF16) are consumed and produced by the bf16 path with register-resident weights only:
  * bf16 weights, one middle layer, x_src / x_dst pre-projected or zero, and the workspace of gw_edge_update_workspace_bytes. */
 size_t gw_edge_tiles_bytes(int32_t batch, int32_t n_edges);
@@ -157,7 +164,7 @@ int gw_edge_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int
  * tiles (32 KiB per 64 edges and batch element).  0 = none needed; the library never allocates (the caller's allocator
  * owns all device memory).  Without the workspace the call still works, on the streaming kernel. */
 size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
-                                      const gw_operand* e_in, const gw_mlp_weights* w);
+                                      const gw_operand* e_in, const gw_mlp_weights* w, int32_t flags);
 
 /* ---- NodeProcessor.forward after aggregation (graph_net_block.py:189-191) -------------------------------
  *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x_res[b, j]

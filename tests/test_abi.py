@@ -37,8 +37,8 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.gw_pack_linear(None, 256, 256, 0, 256, None, None) == -1
     assert b"bad arguments" in L.gw_last_error()
-    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, 0, None, 1, None, None, 0, None) == -1
-    assert L.gw_edge_update_workspace_bytes(2, 100, None, None, None, None) == 0
+    assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, 0, None, 1, None, None, 0, 0, None) == -1
+    assert L.gw_edge_update_workspace_bytes(2, 100, None, None, None, None, 0) == 0
     assert L.gw_project_forward(10, 10, None, 1, None, None, 256, 0, None, None, None) == -1
     assert L.gw_pack_linear_bf16(None, 256, 256, 0, 256, None, None) == -1
     assert L.gw_packed_bytes_bf16(256, 0, 256) == 8 * 16 * 1024  # 8 K-steps x 16 row tiles x 1 KiB
@@ -79,16 +79,23 @@ def test_edge_update_workspace_query_is_host_logic():
     zero = GwOperand(None, None, 0, 0, 0, 0, 0)
     w = GwMlpWeights()
     w.hidden, w.n_mid, w.n_out, w.weight_dtype, w.ln_width = 256, 1, 256, DTYPE_BF16, 0
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 3 * 3 * 32768  # ceil(130 / 64) = 3 tiles
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w) == 3 * 3 * 32768
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w) == 0   # raw fp32 rows: the streaming kernel
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 3 * 3 * 32768  # ceil(130 / 64) = 3 tiles
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 0) == 3 * 3 * 32768
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w, 0) == 0   # raw fp32 rows: the streaming kernel
     w.w1[2] = 1
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, tiles, w) == 3 * 3 * 32768  # raw edge operand as bf16 tiles: layer-1 kernel
-    assert L.gw_edge_update_workspace_bytes(3, 130, tiles, proj, proj, w) == 0  # node operands are never tiles
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, tiles, w, 0) == 3 * 3 * 32768  # raw edge operand as bf16 tiles: layer-1 kernel
+    assert L.gw_edge_update_workspace_bytes(3, 130, tiles, proj, proj, w, 0) == 0  # node operands are never tiles
     assert L.gw_edge_tiles_bytes(3, 130) == 3 * 3 * 32768
+    # deterministic segment sums: carry records of 528 floats per 64-column tile on top (bf16: tiles per batch element)
+    w.w1[2] = None
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 1) == 3 * 3 * (32768 + 528 * 4)
     w.weight_dtype = DTYPE_F32
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0   # fp32: the streaming kernels, no scratch
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w, 1) == 7 * 528 * 4   # fp32: ceil(390 / 64) tiles over the flat columns
+    assert L.gw_edge_update_workspace_bytes(3, 130, raw, proj, raw, w, 1) == 0   # two raw operands: the general kernel has no deterministic mode
+    w.weight_dtype = DTYPE_BF16
+    w.weight_dtype = DTYPE_F32
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 0   # fp32: the streaming kernels, no scratch
     w.weight_dtype, w.n_mid = DTYPE_BF16, 2
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 0
     w.n_mid, w.ln_width = 1, 128
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w) == 0   # zero-padded narrow models: general kernel
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 0   # zero-padded narrow models: general kernel

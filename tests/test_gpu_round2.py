@@ -97,6 +97,16 @@ def test_c5_quarter_degree_against_the_chunked_oracle():
     r = _rel(y - start, ref - start)
     print(f"[parity] C5 0.25deg res 3 B=1: fp32 max-rel {r:.2e} on {rows.numel()} rows")
     assert r <= FP32_REL
+    # deterministic segment sums: bitwise run to run at this size (3 446 grid points end in one polar mesh cell: a destination
+    # segment of the encoder graph that spans 54 tiles), and the same forecast as the atomics mode up to summation order
+    fd = feats.to(DEV)
+    with torch.no_grad():
+        y_atomic = model(fd)
+        model.set_deterministic(True)
+        y_a = model(fd)
+        y_b = model(fd)
+    assert torch.equal(y_a, y_b), "deterministic mode must be bitwise reproducible"
+    assert _rel(y_a - fd[..., :78], y_atomic - fd[..., :78]) <= 1e-5
 
 
 # ---- gradients: fixed bars against the oracle's autograd in fp64 and in fp32 -----------------------------------------------
@@ -349,3 +359,45 @@ def test_per_sample_streams_give_the_single_stream_forecast():
     assert _rel(y_auto, y1) <= 1e-5
     model.set_compute_dtype(torch.bfloat16)
     assert gp.forward_streams(5) == 1  # the persistent bf16 kernels fill the chip by themselves
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deterministic_segment_sums_are_bitwise_reproducible(dtype):
+    """set_deterministic(): carry records + a fix-up launch instead of atomics.  A graph with hub destinations whose segments
+    span several 64-edge tiles (the case atomics make order dependent), fp32 and bf16 kernels: identical bits on every run,
+    the oracle's values, and the atomics mode's values up to summation order."""
+    gp = gw.GraphProcessor(mp_iterations=3, in_dim_node=256, in_dim_edge=256, hidden_dim_node=256, hidden_dim_edge=256)
+    deterministic_fill_(gp, seed=8)
+    p = {"gp." + k: v.clone() for k, v in gp.state_dict().items()}
+    gw.set_compute_dtype(gp, dtype)
+    gp = gp.to(DEV)
+    rs = np.random.RandomState(3)
+    n, e = 90, 2500
+    x = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
+    src = rs.randint(0, n, size=e)
+    dst = np.where(rs.rand(e) < 0.5, rs.choice([7, 8, 60], size=e), rs.randint(0, n, size=e))  # three hubs of ~400 edges each
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    ea = torch.from_numpy(rs.standard_normal((e, 256)).astype(np.float32))
+    xr, er = om.graph_processor(p, "gp", x, ei, ea)
+    with torch.no_grad():
+        x0, e0 = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
+        gw.set_deterministic(gp, True)
+        runs = [gp(x.to(DEV), ei.to(DEV), ea.to(DEV)) for _ in range(4)]
+    for xa, ea_ in runs[1:]:
+        assert torch.equal(xa, runs[0][0]) and torch.equal(ea_, runs[0][1])
+    bar = FP32_REL if dtype == torch.float32 else 3e-2
+    assert _rel(runs[0][0], xr) <= bar and _rel(runs[0][1], er) <= bar
+    assert _rel(runs[0][0], x0) <= (1e-5 if dtype == torch.float32 else 5e-3)
+    # the whole forecaster, batch 3 (tiles of the fp32 kernel cross batch elements)
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    model = model.to(DEV).eval()
+    model.set_compute_dtype(dtype)
+    feats = seeded_features(3, len(lat_lons), 102, seed=5).to(DEV)
+    with torch.no_grad():
+        y_atomic = model(feats)
+        model.set_deterministic(True)
+        ys = [model(feats) for _ in range(3)]
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert _rel(ys[0] - feats[..., :78], y_atomic - feats[..., :78]) <= (1e-5 if dtype == torch.float32 else 5e-3)
