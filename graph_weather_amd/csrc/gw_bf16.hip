@@ -400,6 +400,30 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
       const int gdv = gdl[lane];
       const int gdn = gdl[lane < 63 ? lane + 1 : lane];
       const unsigned long long ends = __ballot(lane == 63 || gdn != gdv);
+      // deterministic mode: carry records instead of atomics (gw_internal.hpp; same scheme as gw_edge.hip)
+      bool open_lo = true, open_hi = true;
+      float* rec = nullptr;
+      if (a.carry != nullptr) {
+        const int chunk_c0 = tile_c0 + g * 64;
+        rec = a.carry + (size_t)(chunk_c0 >> 6) * kCarryFloats;
+        const int c_prev = chunk_c0 - 1, c_next = chunk_c0 + 64;
+        int gd_prev = -2, gd_next = -2;
+        if (c_prev >= 0 && c_prev < a.n_cols) {
+          const int bp = c_prev / a.cols_per_batch;
+          gd_prev = bp * a.agg_rows_pb + ldgi(a.agg_idx + (c_prev - bp * a.cols_per_batch));
+        }
+        if (c_next < a.n_cols) {
+          const int bn = c_next / a.cols_per_batch;
+          gd_next = bn * a.agg_rows_pb + ldgi(a.agg_idx + (c_next - bn * a.cols_per_batch));
+        }
+        open_lo = gd_prev == __builtin_amdgcn_readlane(gdv, 0);
+        open_hi = gd_next == __builtin_amdgcn_readlane(gdv, 63);
+        if (f == 0 && chunk_c0 < a.n_cols) {
+          rec[512] = __int_as_float(-1);
+          rec[513] = __int_as_float(-1);
+          rec[514] = __int_as_float(0);
+        }
+      }
       float run = 0.f;
       bool first = true;
 #pragma unroll
@@ -409,8 +433,25 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
           const int cur = __builtin_amdgcn_readlane(gdv, i);
           if (cur >= 0) {
             float* dstp = a.agg + (size_t)cur * 256 + f;
-            if (first || i == 63) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else stg1(dstp, run);
+            if (rec != nullptr) {
+              const bool lo = first && open_lo, hi = i == 63 && open_hi;
+              if (lo) {
+                rec[f] = run;
+                if (f == 0) {
+                  rec[512] = __int_as_float(cur);
+                  if (hi) rec[514] = __int_as_float(1);
+                }
+              } else if (hi) {
+                rec[256 + f] = run;
+                if (f == 0) rec[513] = __int_as_float(cur);
+              } else {
+                stg1(dstp, run);
+              }
+            } else if (first || i == 63) {
+              __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              stg1(dstp, run);
+            }
           }
           first = false;
           run = 0.f;

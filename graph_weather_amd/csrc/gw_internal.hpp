@@ -61,6 +61,7 @@ struct ChainArgs {
   // single-layer mode: rows [n_cols, 256] to fill with zeros on the side (the aggregate buffer of the edge update that
   // consumes these products: saves a separate fill launch per block)
   float* zero_rows;
+  float* carry;  // bf16 edge update: deterministic segment sums (per-tile carry records, see below); NULL = atomics
   // training: activations saved for the backward (gw_activation_save), NULL in inference
   float* save_h;
   long long save_stride;

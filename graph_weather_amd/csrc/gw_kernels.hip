@@ -795,6 +795,7 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
   if (gw::edge16_eligible(x_src, x_dst, e_in, w)) return det ? gw::edge16_workspace_bytes_det(batch, n_edges) : gw::edge16_workspace_bytes(batch, n_edges);
   if (det && w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) return gw::edge_fast_carry_bytes(batch, n_edges);
+  if (det && w->weight_dtype == GW_DTYPE_BF16) return gw::edge_fast_carry_bytes(batch, n_edges);  // the general bf16 kernel (e.g. the encoder's raw node operand)
   return 0;
 }
 
@@ -858,8 +859,9 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   }
   if (!save && workspace && gw::edge16_eligible(x_src, x_dst, e_in, w) && workspace_bytes >= ws16)
     return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace, det, stream);
-  if (det) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums exist on the fast edge kernels only "
-                                         "(at most one raw operand, native 256 widths) and need their workspace");
+  if (det && (w->weight_dtype != GW_DTYPE_BF16 || !workspace || workspace_bytes < gw::edge_fast_carry_bytes(batch, n_edges)))
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums exist on the fast fp32 edge kernel (at most one "
+                                  "raw operand, native 256 widths) and on the bf16 kernels, and need their workspace");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = batch * n_edges;
@@ -880,7 +882,9 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   if (int rc = fill_save(a, save, w, "gw_edge_update_forward")) return rc;
   if (w->weight_dtype == GW_DTYPE_BF16) {
     if (a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
-    return gw::chain16_launch(1, a, 256, 256, 256, 1, stream);
+    if (det) a.carry = (float*)workspace;
+    if (int rc = gw::chain16_launch(1, a, 256, 256, 256, 1, stream)) return rc;
+    return det ? gw::segment_fixup_launch(((int64_t)a.n_cols + 63) / 64, a.carry, agg, stream) : GW_OK;
   }
   return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream, 1, 1);
 }
