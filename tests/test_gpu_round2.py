@@ -387,7 +387,7 @@ def test_deterministic_segment_sums_are_bitwise_reproducible(dtype):
         assert torch.equal(xa, runs[0][0]) and torch.equal(ea_, runs[0][1])
     bar = FP32_REL if dtype == torch.float32 else 3e-2
     assert _rel(runs[0][0], xr) <= bar and _rel(runs[0][1], er) <= bar
-    assert _rel(runs[0][0], x0) <= (1e-5 if dtype == torch.float32 else 5e-3)
+    assert _rel(runs[0][0], x0) <= (1e-5 if dtype == torch.float32 else BF16_BUDGET)
     # the whole forecaster, batch 3 (tiles of the fp32 kernel cross batch elements)
     lat_lons = regular_lat_lons(10.0)
     model = gw.GraphWeatherForecaster(lat_lons)
@@ -400,4 +400,6 @@ def test_deterministic_segment_sums_are_bitwise_reproducible(dtype):
         model.set_deterministic(True)
         ys = [model(feats) for _ in range(3)]
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
-    assert _rel(ys[0] - feats[..., :78], y_atomic - feats[..., :78]) <= (1e-5 if dtype == torch.float32 else 5e-3)
+    # bf16: a different (fixed) summation order moves sums by an fp32 ulp, which flips bf16 roundings downstream - both
+    # forecasts are inside the bf16 budget of the oracle, and so is their distance
+    assert _rel(ys[0] - feats[..., :78], y_atomic - feats[..., :78]) <= (1e-5 if dtype == torch.float32 else BF16_BUDGET)
