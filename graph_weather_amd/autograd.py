@@ -338,7 +338,8 @@ class EdgeUpdateFunction(torch.autograd.Function):
         add = de_out.contiguous() if (ctx.want_edges and de_out is not None and de_out.numel()) else None
         dn = gather_rows(dagg.contiguous(), plan.n_dst, plan.dst, B, E, add)
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, True, params[-2], grads, mlp, mlp.out_dim)
+        has_norm = mlp._norm() is not None
+        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         tensors = (x_src, x_dst, e_in)
@@ -395,7 +396,8 @@ class NodeUpdateFunction(torch.autograd.Function):
         batch = n // rpb
         dout = dout.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, True, params[-2], grads, ctx.mlp, ctx.mlp.out_dim)
+        has_norm = ctx.mlp._norm() is not None
+        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, ctx.mlp, ctx.mlp.out_dim)
         W0 = params[0]
         gW0 = torch.zeros_like(W0)
         (xlo, xhi), (alo, ahi) = mlp.native_splits()

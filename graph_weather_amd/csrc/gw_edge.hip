@@ -635,7 +635,7 @@ bool edge_fast_eligible(const gw_operand* x_src, const gw_operand* x_dst, const 
     n_proj += is_proj(ops[i]) ? 1 : 0;
   }
   if (n_raw > 1 || n_proj < 1) return false;
-  if (w->n_mid < 1) return false;
+  if (w->n_mid < 1 || !w->ln_gamma) return false;  // (no LayerNorm: the general kernel)
   if (w->ln_width > 0 && w->ln_width != 256) return false;  // zero-padded narrow models: masked statistics live in the general kernel
   static int impl = -1;  // GW_EDGE_IMPL=0 forces the general chain kernel (A/B measurements, tests of both paths)
   if (impl < 0) impl = GW_TUNE("GW_EDGE_IMPL", 1);

@@ -711,7 +711,7 @@ namespace gw {
 
 // Eligible: bf16 weights, one middle layer, and layer 1 = projected operands (+ at most the edge operand raw, as bf16 tiles).
 bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in, const gw_mlp_weights* w) {
-  if (w->weight_dtype != GW_DTYPE_BF16 || w->n_mid != 1) return false;
+  if (w->weight_dtype != GW_DTYPE_BF16 || w->n_mid != 1 || !w->ln_gamma) return false;
   if (w->ln_width > 0 && w->ln_width != 256) return false;
   if (is_raw16(x_src) || is_raw16(x_dst)) return false;
   if (x_src->layout != GW_LAYOUT_ROWS_F32 || x_dst->layout != GW_LAYOUT_ROWS_F32) return false;

@@ -821,8 +821,9 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   if (!src || !dst || !x_src || !x_dst || !e_in || !e_res || !w || !agg) return fail(GW_E_BADARG, "gw_edge_update_forward: bad arguments");
   if ((int64_t)batch * n_edges >= (int64_t)1 << 31 || (int64_t)batch * n_dst >= (int64_t)1 << 31)
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: batch*edges exceeds int32");
-  if (w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || !w->ln_beta || !w->b1 || !w->w_out || !w->b_out)
-    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: only hidden=256, out=256, LayerNorm is implemented");
+  if (w->hidden != 256 || w->n_out != 256 || (w->ln_gamma == nullptr) != (w->ln_beta == nullptr) || !w->b1 || !w->w_out || !w->b_out)
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: only hidden=256, out=256 is implemented");
+  // norm_type=None (graph_net_block.py:50-59 allows it): the general kernels run without the LayerNorm epilogue
   if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: at least 2 hidden layers (n_mid >= 1) are required");
   const gw_operand* ops[3] = {x_src, x_dst, e_in};
   for (int i = 0; i < 3; ++i) {
@@ -881,7 +882,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg_rows_pb = n_dst;
   if (int rc = fill_save(a, save, w, "gw_edge_update_forward")) return rc;
   if (w->weight_dtype == GW_DTYPE_BF16) {
-    if (a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
+    if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
     if (det) a.carry = (float*)workspace;
     if (int rc = gw::chain16_launch(1, a, 256, 256, 256, 1, stream)) return rc;
     return det ? gw::segment_fixup_launch(((int64_t)a.n_cols + 63) / 64, a.carry, agg, stream) : GW_OK;

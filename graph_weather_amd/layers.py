@@ -341,10 +341,11 @@ def build_graph_processor_block(in_dim_node=128, in_dim_edge=128, hidden_dim_nod
 
 
 def _check_native_dims(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge, norm_type):
-    if max(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge) > 256 or norm_type != "LayerNorm":
+    if max(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge) > 256 or norm_type not in ("LayerNorm", None):
         raise NotImplementedError(
             "graph_weather_amd: the HIP message-passing kernels handle node / edge / hidden widths up to 256 (narrower "
-            "models run zero-padded to 256) with LayerNorm; wider models and norm_type=None are not implemented")
+            "models run zero-padded to 256) with LayerNorm or no norm (the only norm_type values torch.nn resolves, "
+            "graph_net_block.py:50-59); wider models are not implemented")
 
 
 def _pad256(t: torch.Tensor) -> torch.Tensor:
@@ -446,7 +447,8 @@ class GraphProcessor(nn.Module):
         """(We . e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights)."""
         mlp_e = blk.edge_model.edge_mlp
         pm_e = mlp_e.packed()
-        tiled = mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and n_edges > 0
+        tiled = (mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None
+                 and n_edges > 0)
         key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key())
         if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
             pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
@@ -484,7 +486,7 @@ class GraphProcessor(nn.Module):
             # bf16 mode (inference): between blocks the per-sample edge features live as bf16 "edge tiles" - the MFMA B-operand
             # order the next block's layer-1 product consumes directly (csrc/gw_edge16.hip); only what crosses the API is rows
             tiled = ((not train) and mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0
-                     and n_edges > 0)
+                     and pm_e.gamma is not None and n_edges > 0)
             if shared:
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
@@ -788,7 +790,7 @@ class AssimilatorDecoder(nn.Module):
             if hit is None or hit[0] != key:
                 self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
             pe = self._cache["dec_pe"][1]
-            if mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and n_e > 0:
+            if mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and n_e > 0:
                 # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
                 hit = self._cache.get("dec_e_tiles")
                 if hit is None or hit[0] != key:

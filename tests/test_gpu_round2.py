@@ -403,3 +403,34 @@ def test_deterministic_segment_sums_are_bitwise_reproducible(dtype):
     # bf16: a different (fixed) summation order moves sums by an fp32 ulp, which flips bf16 roundings downstream - both
     # forecasts are inside the bf16 budget of the oracle, and so is their distance
     assert _rel(ys[0] - feats[..., :78], y_atomic - feats[..., :78]) <= (1e-5 if dtype == torch.float32 else BF16_BUDGET)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_processor_without_norm(dtype):
+    """norm_type=None (graph_net_block.py:50-59: the MLPs end in their last Linear): forward against the oracle, fp32 backward
+    against the oracle's fp64 autograd."""
+    gp = gw.GraphProcessor(mp_iterations=2, in_dim_node=256, in_dim_edge=256, hidden_dim_node=256, hidden_dim_edge=256, norm_type=None)
+    deterministic_fill_(gp, seed=12)
+    assert not any(isinstance(m, torch.nn.LayerNorm) for m in gp.modules())
+    p = {"gp." + k: v.clone() for k, v in gp.state_dict().items()}
+    rs = np.random.RandomState(2)
+    n, e = 130, 900
+    x = torch.from_numpy(0.5 * rs.standard_normal((n, 256)).astype(np.float32))
+    ea = torch.from_numpy(0.5 * rs.standard_normal((e, 256)).astype(np.float32))
+    ei = torch.from_numpy(np.stack([rs.randint(0, n, size=e), rs.randint(0, n, size=e)]).astype(np.int64))
+    xr, er = om.graph_processor(p, "gp", x, ei, ea)
+    gw.set_compute_dtype(gp, dtype)
+    gp = gp.to(DEV)
+    with torch.no_grad():
+        xo, eo = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
+    bar = FP32_REL if dtype == torch.float32 else 3e-2
+    assert _rel(xo, xr) <= bar and _rel(eo, er) <= bar
+    if dtype != torch.float32:
+        return
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in p.items()}
+    xr64, er64 = om.graph_processor(ref, "gp", x.double(), ei, ea.double())
+    (xr64.square().sum() + er64.square().sum()).backward()
+    xo, eo = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
+    (xo.square().sum() + eo.square().sum()).backward()
+    for k, prm in gp.named_parameters():
+        assert _l2(prm.grad, ref["gp." + k].grad) <= GRAD_L2_REL, k
