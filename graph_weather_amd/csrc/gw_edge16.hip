@@ -291,10 +291,16 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  // XCD-local walk: workgroup i runs on XCD i % 8 (each XCD has its own L2); XCD x takes the contiguous range of groups
+  // [x n / 8, (x + 1) n / 8) - whole batch elements, walked in destination order - so the P_d rows of consecutive
+  // destination-sorted edges and the P_s rows of their mesh neighbourhoods stay in that XCD's L2 instead of every L2 seeing
+  // the whole node tables.
   const int n_groups = a.batch * a.neb * kGroups;
-  const int stride = gridDim.x * kL1Waves;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int g_lo = (int)((long long)n_groups * xcd / 8), g_hi = (int)((long long)n_groups * (xcd + 1) / 8);
+  const int stride = nslot * kL1Waves;
 #pragma unroll 1
-  for (int u = blockIdx.x * kL1Waves + wave; u < n_groups; u += stride) {
+  for (int u = g_lo + slot * kL1Waves + wave; u < g_hi; u += stride) {
     const int tile = u >> 2, g = u & 3;
     const int b = tile / a.neb;
     const int eb = tile - b * a.neb;

@@ -9,7 +9,7 @@ rocprofv3 -L > $GRAFT_REPO_ROOT/$OUT/counters_list.txt 2>&1
 run_pass () {
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/run_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $GRAFT_REPO_ROOT/$OUT/run_$name.log 2>&1
   echo "rc=$?" >> $GRAFT_REPO_ROOT/$OUT/run_$name.log
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
