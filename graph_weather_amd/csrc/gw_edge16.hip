@@ -371,7 +371,11 @@ __global__ __launch_bounds__(256) void rows_to_tiles_kernel(int batch, int n_edg
 
 // RES_TILES: the residual e comes from bf16 edge tiles (a.res_tiles) instead of fp32 rows (a.res_ptr) - a template parameter
 // so that only one set of prefetch registers exists.
-template <int NW, bool RES_TILES>
+// GATHER: layer 1 is a pure gather-add (every operand projected: encoder-free forecaster decoder, first processor block) and
+// is done HERE, at the top of each tile - relu(b1 + sum of projected rows) -> bf16 -> Hbuf1 - instead of by a separate launch
+// through a workspace in HBM: at batch 16 that workspace round trip (3.7 GB written and 3.7 GB read for the 1 degree decoder)
+// was two thirds of the decoder's HBM traffic (profiles/r02_pmc_c3_edge16_v1.json).
+template <int NW, bool RES_TILES, bool GATHER>
 __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Args a) {
   constexpr int RT = 16 / NW;         // output row tiles (16 features) per wave
   constexpr int PPW = 32 / NW;        // LDS-DMA pieces (1 KiB) of a 32 KiB tile per wave
@@ -428,11 +432,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     glds16_asm_s((const float*)(src + piece * 1024), (unsigned)lane * 16u,
                  __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kOffH1 + par * kHBytes + piece * 1024)));
   };
-  if (slot < tw.n_units) {
+  if (!GATHER && slot < tw.n_units) {
     const char* src = a.h1g + tile_index(slot) * kHBytes;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) prefetch_piece(src, 0, i);
   }
+  // GATHER: thread -> (column, 16-byte piece) pairs of the tile: 8 lanes read one 128-byte line of a projected row (as in
+  // edge16_gather_kernel); the row indices of a tile are fetched one tile ahead.
+  constexpr int GP = GATHER ? 512 / (64 * NW) : 1;  // column passes (1 for 512 threads, 2 for 256)
+  const int gpiece = threadIdx.x & 7;
+  int gidx[GP][3];
+  auto load_gather_indices = [&](int u) {
+    const int eb = tw.eb_start + u / a.batch;
+#pragma unroll
+    for (int cp = 0; cp < GP; ++cp) {
+      const int kr = eb * kTileCols + cp * (8 * NW) + (int)(threadIdx.x >> 3);
+      const int k = kr < a.n_edges ? kr : a.n_edges - 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        gidx[cp][p] = p < a.n_proj ? (a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k)) : 0;
+    }
+  };
+  if (GATHER && slot < tw.n_units) load_gather_indices(slot);
 
   int par = 0;
 #pragma unroll 1
@@ -441,18 +462,52 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     const int b = u - (u / a.batch) * a.batch;
     const int k0 = eb * kTileCols;
     const size_t tile = (size_t)(b * a.neb + eb);
-    const char* h1 = lds + kOffH1 + par * kHBytes;
+    const char* h1 = lds + kOffH1 + (GATHER ? 0 : par * kHBytes);
 
     unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool stamp = a.dbg != nullptr && u == slot + 2 * nslot;
     if (stamp) ts[0] = gw_clock();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its stores of the previous tile) are done
+    const bool more = u + nslot < tw.n_units;
+    if constexpr (GATHER) {
+      // ---- layer 1 of this tile: relu(b1 + sum_p P_p[row_p]) -> bf16 -> Hbuf1 (its readers of the previous tile left it
+      // before that tile's barrier (2)) ----
+      int gp4 = 4 * gpiece;
+      asm volatile("" : "+v"(gp4));  // (keeps the piece-offset table bases out of the kernel-lifetime registers)
+#pragma unroll
+      for (int cp = 0; cp < GP; ++cp) {
+        const int col = cp * (8 * NW) + (int)(threadIdx.x >> 3);
+        const bool cvalid = k0 + col < a.n_edges;
+        f32x4 z[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) z[s] = ldg4(a.b1 + 32 * s + gp4);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (p < a.n_proj) {
+            const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
+            f32x4 v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) z[s] += v[s];
+          }
+        char* out = lds + kOffH1 + (col >> 4) * 8192 + (16 * (gpiece & 3) + (col & 15)) * 16 + (gpiece >> 2) * 8;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
+          *(bf16x4*)(out + s * 1024) = v;
+        }
+      }
+      if (more) load_gather_indices(u + nslot);  // in flight during the rest of the tile
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its stores of the previous tile) are done
+    }
     if (stamp) ts[1] = gw_clock();
-    wg_barrier();  // (1) Hbuf1[par] complete; every wave has left the previous tile's last phase
+    wg_barrier();  // (1) Hbuf1 complete; every wave has left the previous tile's last phase
     if (stamp) ts[2] = gw_clock();
     // next tile -> Hbuf1[par ^ 1] (last read before barrier (2) of the previous tile), a few pieces per group step below
-    const bool more = u + nslot < tw.n_units;
-    const char* nsrc = more ? a.h1g + tile_index(u + nslot) * kHBytes : nullptr;
+    const char* nsrc = (!GATHER && more) ? a.h1g + tile_index(u + nslot) * kHBytes : nullptr;
 
     f32x4 bmv[RT];  // (after barrier (1): on the first tile it also publishes the parameter block)
 #pragma unroll
@@ -521,7 +576,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     f32x4 o[kGroups][RT];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
-      if (more) {
+      if (!GATHER && more) {
 #pragma unroll
         for (int i = 0; i < PPW / kGroups; ++i) prefetch_piece(nsrc, par ^ 1, (PPW / kGroups) * g + i);
       }
@@ -733,8 +788,17 @@ bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_
 size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges) {
   return (size_t)batch * (size_t)((n_edges + kTileCols - 1) / kTileCols) * (size_t)kHBytes;
 }
-size_t edge16_workspace_bytes_det(int32_t batch, int32_t n_edges) {
-  return edge16_workspace_bytes(batch, n_edges) + segment_carry_bytes((int64_t)batch * ((n_edges + kTileCols - 1) / kTileCols));
+// tuning builds: GW_EDGE16_FUSE_GATHER=0 restores the two-launch form (gather kernel + workspace) of the all-projected case
+static bool fuse_gather_on() {
+  static const bool on = GW_TUNE("GW_EDGE16_FUSE_GATHER", 1) != 0;
+  return on;
+}
+// Workspace of an edge16 call: the layer-1 tiles (only when a separate launch makes them: raw edge operand, or the
+// two-launch gather form), then the carry records of the deterministic mode.
+size_t edge16_workspace_needed(int32_t batch, int32_t n_edges, const gw_operand* e_in, bool deterministic) {
+  const bool raw_e = e_in->k > 0 && e_in->projected == 0;
+  const size_t h1 = (raw_e || !fuse_gather_on()) ? edge16_workspace_bytes(batch, n_edges) : 0;
+  return h1 + (deterministic ? segment_carry_bytes((int64_t)batch * ((n_edges + kTileCols - 1) / kTileCols)) : 0);
 }
 
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
@@ -788,7 +852,8 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.e_out_tiles = (char*)e_out_tiles;
   a.agg = agg;
   a.h1g = (char*)workspace;
-  if (deterministic) a.carry = (float*)((char*)workspace + edge16_workspace_bytes(batch, n_edges));  // behind the layer-1 tiles
+  if (deterministic)  // behind the layer-1 tiles, if this call has any
+    a.carry = (float*)((char*)workspace + ((raw_e || !fuse_gather_on()) ? edge16_workspace_bytes(batch, n_edges) : 0));
 #ifdef GW_TUNING
   {
     static const int skip = GW_TUNE("GW_EDGE16_SKIP", 0);
@@ -800,25 +865,30 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     a.dbg_cap = g_dbg_cap;
   }
   static const int n_wg = (GW_TUNE("GW_EDGE16_WGS", 256) + 7) / 8 * 8;  // persistent workgroups: one per CU, a multiple of 8 (XCD round-robin)
+  const bool fuse_gather = fuse_gather_on();
   // launch 1: layer 1 -> workspace tiles
   if (raw_e) {
     static DeviceOnce once_l1;
     if (once_l1.first()) (void)hipFuncSetAttribute((const void*)edge16_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipLaunchKernelGGL(edge16_l1_kernel, dim3((unsigned)n_wg), dim3(64 * kL1Waves), 128 * 1024, (hipStream_t)stream, a);
     if (int rc = check_launch("edge16_l1_kernel launch")) return rc;
-  } else {
+  } else if (!fuse_gather) {
     hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)a.neb), dim3(256), 0, (hipStream_t)stream, a);  // one workgroup per edge block
     if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
   }
   // launch 2: the resident layers
   static const int nw = GW_TUNE("GW_EDGE16_NW", 8);
   const bool rt = a.res_tiles != nullptr;
+  const bool ga = !raw_e && fuse_gather;  // layer 1 gathered inside the resident kernel
+  int rc;
   if (nw == 4 || deterministic) {  // the deterministic walk is a whole-tile walk per thread: the 4-wave form
-    const int rc = rt ? launch_resident(edge16_kernel<4, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false>, 256, n_wg, a, stream);
+    if (ga) rc = rt ? launch_resident(edge16_kernel<4, true, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, true>, 256, n_wg, a, stream);
+    else rc = rt ? launch_resident(edge16_kernel<4, true, false>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, false>, 256, n_wg, a, stream);
     if (rc != GW_OK || !deterministic) return rc;
     return segment_fixup_launch((int64_t)batch * a.neb, a.carry, agg, stream);
   }
-  return rt ? launch_resident(edge16_kernel<8, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false>, 512, n_wg, a, stream);
+  if (ga) return rt ? launch_resident(edge16_kernel<8, true, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, true>, 512, n_wg, a, stream);
+  return rt ? launch_resident(edge16_kernel<8, true, false>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, false>, 512, n_wg, a, stream);
 }
 
 }  // namespace gw

@@ -129,7 +129,8 @@ size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges);
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
                   float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, bool deterministic, void* stream);
-size_t edge16_workspace_bytes_det(int32_t batch, int32_t n_edges);  // layer-1 tiles + carry records
+size_t edge16_workspace_needed(int32_t batch, int32_t n_edges, const gw_operand* e_in, bool deterministic);  // layer-1 tiles (if a
+                                                                                  // separate launch makes them) + carry records
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                          void* stream);
 

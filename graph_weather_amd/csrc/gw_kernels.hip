@@ -793,7 +793,7 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
                                       const gw_operand* e_in, const gw_mlp_weights* w, int32_t flags) {
   if (batch <= 0 || n_edges <= 0 || !x_src || !x_dst || !e_in || !w) return 0;
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
-  if (gw::edge16_eligible(x_src, x_dst, e_in, w)) return det ? gw::edge16_workspace_bytes_det(batch, n_edges) : gw::edge16_workspace_bytes(batch, n_edges);
+  if (gw::edge16_eligible(x_src, x_dst, e_in, w)) return gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) return gw::edge_fast_carry_bytes(batch, n_edges);
   if (det && w->weight_dtype == GW_DTYPE_BF16) return gw::edge_fast_carry_bytes(batch, n_edges);  // the general bf16 kernel (e.g. the encoder's raw node operand)
   return 0;
@@ -841,10 +841,10 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: node operands must be fp32 rows");
   float* e_out = tiles_out ? nullptr : (float*)e_out_any;
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
-  const size_t ws16 = det ? gw::edge16_workspace_bytes_det(batch, n_edges) : gw::edge16_workspace_bytes(batch, n_edges);
+  const size_t ws16 = gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");
   if (tiles_in || tiles_out) {
-    if (save || !workspace || !gw::edge16_eligible(x_src, x_dst, e_in, w) || workspace_bytes < ws16)
+    if (save || (ws16 > 0 && (!workspace || workspace_bytes < ws16)) || !gw::edge16_eligible(x_src, x_dst, e_in, w))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
                                     "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");
     return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, tiles_out ? e_out_any : nullptr, agg,
@@ -858,7 +858,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
     return gw::edge_fast_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, agg, n_dst, save,
                                 det ? (float*)workspace : nullptr, stream);
   }
-  if (!save && workspace && gw::edge16_eligible(x_src, x_dst, e_in, w) && workspace_bytes >= ws16)
+  if (!save && gw::edge16_eligible(x_src, x_dst, e_in, w) && (ws16 == 0 || (workspace && workspace_bytes >= ws16)))
     return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace, det, stream);
   if (det && (w->weight_dtype != GW_DTYPE_BF16 || !workspace || workspace_bytes < gw::edge_fast_carry_bytes(batch, n_edges)))
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums exist on the fast fp32 edge kernel (at most one "

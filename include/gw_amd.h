@@ -159,10 +159,11 @@ size_t gw_edge_tiles_bytes(int32_t batch, int32_t n_edges);
 /* rows [batch (rows_per_batch > 0) or shared (0)][n_edges, ld] fp32 -> tiles (bf16, round to nearest even; padding edges 0). */
 int gw_edge_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                           void* stream);
-/* Scratch device memory (16-byte aligned, contents irrelevant) that lets gw_edge_update_forward pick its fastest kernel
- * for these operands - today the bf16 path with register-resident weights, which stages the layer-1 activations of all
- * tiles (32 KiB per 64 edges and batch element).  0 = none needed; the library never allocates (the caller's allocator
- * owns all device memory).  Without the workspace the call still works, on the streaming kernel. */
+/* Scratch device memory (16-byte aligned, contents irrelevant) gw_edge_update_forward needs for these operands and flags:
+ * the bf16 path with a raw edge operand (bf16 tiles) stages the layer-1 activations of all tiles between its two launches
+ * (32 KiB per 64 edges and batch element); deterministic segment sums park one carry record per tile.  0 = none needed
+ * (e.g. the bf16 path whose operands are all projected gathers them inside its one persistent launch); the library never
+ * allocates (the caller's allocator owns all device memory). */
 size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
                                       const gw_operand* e_in, const gw_mlp_weights* w, int32_t flags);
 

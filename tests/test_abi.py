@@ -79,8 +79,8 @@ def test_edge_update_workspace_query_is_host_logic():
     zero = GwOperand(None, None, 0, 0, 0, 0, 0)
     w = GwMlpWeights()
     w.hidden, w.n_mid, w.n_out, w.weight_dtype, w.ln_width = 256, 1, 256, DTYPE_BF16, 0
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 3 * 3 * 32768  # ceil(130 / 64) = 3 tiles
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 0) == 3 * 3 * 32768
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 0  # all projected: gathered inside the one launch
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 0) == 0
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w, 0) == 0   # raw fp32 rows: the streaming kernel
     w.w1[2] = 1
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, tiles, w, 0) == 3 * 3 * 32768  # raw edge operand as bf16 tiles: layer-1 kernel
@@ -88,7 +88,10 @@ def test_edge_update_workspace_query_is_host_logic():
     assert L.gw_edge_tiles_bytes(3, 130) == 3 * 3 * 32768
     # deterministic segment sums: carry records of 528 floats per 64-column tile on top (bf16: tiles per batch element)
     w.w1[2] = None
-    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 1) == 3 * 3 * (32768 + 528 * 4)
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 1) == 3 * 3 * 528 * 4
+    w.w1[2] = 1
+    assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, tiles, w, 1) == 3 * 3 * (32768 + 528 * 4)
+    w.w1[2] = None
     w.weight_dtype = DTYPE_F32
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w, 1) == 7 * 528 * 4   # fp32: ceil(390 / 64) tiles over the flat columns
     assert L.gw_edge_update_workspace_bytes(3, 130, raw, proj, raw, w, 1) == 0   # two raw operands: the general kernel has no deterministic mode

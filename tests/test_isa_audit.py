@@ -61,8 +61,8 @@ def test_edge16_kernels_keep_their_weights_in_accumulation_registers(tmp_path):
         return (int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)),
                 int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)))
 
-    names = re.findall(r"^(_Z\w*edge16_kernelILi\d+ELb[01]E\w*):", text, re.M)
-    assert len(names) == 4, names
+    names = re.findall(r"^(_Z\w*edge16_kernelILi\d+ELb[01]ELb[01]E\w*):", text, re.M)
+    assert len(names) == 8, names  # waves 4 / 8 x residual rows / tiles x layer 1 from a workspace / gathered in the kernel
     for name in names:
         nw = int(re.search(r"edge16_kernelILi(\d+)E", name).group(1))
         scratch, vgpr = meta_of(name)
