@@ -59,7 +59,7 @@ constexpr int kOffStage = kOffH2;
 constexpr int kOffGd = kOffStage + kTileCols * kStageLd * 4;
 constexpr int kOffLn = kOffGd + kTileCols * 4;
 constexpr int kOffPar = kOffLn + 8 * kTileCols * 8;    // after [wave <= 8][column] (sum, sum of squares): b_mid, b_out, gamma, beta
-constexpr int kLdsTotal = kOffPar + 4 * 256 * 4;
+constexpr int kLdsTotal = kOffPar + 5 * 256 * 4;       // ... and b1 (GATHER form)
 static_assert(kTileCols * kStageLd * 4 >= kHBytes, "staging area covers Hbuf2");
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
 
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     par_w[256 + i] = a.b_out[i];
     par_w[512 + i] = a.gamma[i];
     par_w[768 + i] = a.beta[i];
+    par_w[1024 + i] = a.b1[i];
   }
   const float* const par_l = (const float*)(lds + kOffPar) + f0;  // this lane's slice: + 256 * which + 16 * t
 
@@ -453,7 +454,63 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
         gidx[cp][p] = p < a.n_proj ? (a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k)) : 0;
     }
   };
-  if (GATHER && slot < tw.n_units) load_gather_indices(slot);
+  // GATHER: layer 1 of a tile = relu(b1 + sum_p P_p[row_p]) -> bf16 -> Hbuf1[buffer], at the top of the tile.  The rows it
+  // reads were touched one tile earlier by gather_warm() (one 4-byte load per thread and table: thread (column, piece) touches
+  // line `piece` of the column's row), so they come from this XCD's L2 instead of paying the HBM round trip of the
+  // batch-shared tables; the row indices are fetched one tile ahead as well.
+  auto gather_finish = [&](int u, int buffer, bool more) {
+    const int eb = tw.eb_start + u / a.batch;
+    const int b = u - (u / a.batch) * a.batch;
+    int gp4 = 4 * gpiece;
+    asm volatile("" : "+v"(gp4));
+    const float* b1l = (const float*)(lds + kOffPar) + 1024 + gp4;
+#pragma unroll
+    for (int cp = 0; cp < GP; ++cp) {
+      const int col = cp * (8 * NW) + (int)(threadIdx.x >> 3);
+      const bool cvalid = eb * kTileCols + col < a.n_edges;
+      char* out = lds + kOffH1 + buffer * kHBytes + (col >> 4) * 8192 + (16 * (gpiece & 3) + (col & 15)) * 16 + (gpiece >> 2) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // K-steps 4 h .. 4 h + 3 at a time: registers
+        f32x4 z[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) z[s] = *(const f32x4*)(b1l + 32 * (4 * h + s));
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          if (p < a.n_proj) {  // (all tables' loads of this half are in flight together)
+            const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
+            f32x4 v[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = ldg4(row + 32 * (4 * h + s));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) z[s] += v[s];
+          }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
+          *(bf16x4*)(out + (4 * h + s) * 1024) = v;
+        }
+      }
+    }
+    if (more) load_gather_indices(u + nslot);  // the indices of the tile after this one: in flight for a whole tile
+  };
+  int warm = 0;
+  auto gather_warm = [&](int u) {  // (call when the indices of tile u have arrived: gidx)
+    const int b = u - (u / a.batch) * a.batch;
+#pragma unroll
+    for (int cp = 0; cp < GP; ++cp)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (p < a.n_proj) {
+          const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p];
+          warm ^= ldgi((const int*)(row + 32 * gpiece));
+        }
+  };
+  if (GATHER && slot < tw.n_units) {
+    load_gather_indices(slot);
+    __syncthreads();  // the parameter block (b1) is visible
+  }
 
   int par = 0;
 #pragma unroll 1
@@ -469,37 +526,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     if (stamp) ts[0] = gw_clock();
     const bool more = u + nslot < tw.n_units;
     if constexpr (GATHER) {
-      // ---- layer 1 of this tile: relu(b1 + sum_p P_p[row_p]) -> bf16 -> Hbuf1 (its readers of the previous tile left it
-      // before that tile's barrier (2)) ----
-      int gp4 = 4 * gpiece;
-      asm volatile("" : "+v"(gp4));  // (keeps the piece-offset table bases out of the kernel-lifetime registers)
-#pragma unroll
-      for (int cp = 0; cp < GP; ++cp) {
-        const int col = cp * (8 * NW) + (int)(threadIdx.x >> 3);
-        const bool cvalid = k0 + col < a.n_edges;
-        f32x4 z[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) z[s] = ldg4(a.b1 + 32 * s + gp4);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          if (p < a.n_proj) {
-            const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
-            f32x4 v[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) z[s] += v[s];
-          }
-        char* out = lds + kOffH1 + (col >> 4) * 8192 + (16 * (gpiece & 3) + (col & 15)) * 16 + (gpiece >> 2) * 8;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
-          *(bf16x4*)(out + s * 1024) = v;
-        }
-      }
-      if (more) load_gather_indices(u + nslot);  // in flight during the rest of the tile
+      gather_finish(u, 0, more);  // layer 1 of this tile -> Hbuf1[0] (its readers of the previous tile left before barrier (2))
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its stores of the previous tile) are done
     }
@@ -567,6 +594,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     }
     wg_barrier();  // (2) Hbuf2 complete, Hbuf1 free
     if (stamp) ts[8] = gw_clock();
+    if constexpr (GATHER) {
+      if (more) gather_warm(u + nslot);  // the next tile's rows -> L2 (its indices, requested at the top of this tile, are here)
+    }
 
     f32x4 bov[RT];
 #pragma unroll
@@ -672,9 +702,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
       asm volatile("" : "+v"(f));  // keeps agg + f out of the kernel-lifetime registers (it was hoisted out of the tile loop and spilled)
       const int hh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
       const int c0 = hh * COLS;
-      float vv[COLS];
+      constexpr int VH = COLS;  // columns read from LDS at a time
+      float vv[VH];
 #pragma unroll
-      for (int i = 0; i < COLS; ++i) vv[i] = stage[(c0 + i) * kStageLd + f];
+      for (int i = 0; i < VH; ++i) vv[i] = stage[(c0 + i) * kStageLd + f];
       const int gdv = gdl[lane];
       const int gdn = gdl[lane < kTileCols - 1 ? lane + 1 : lane];
       const unsigned long long ends = __ballot(lane == kTileCols - 1 || gdn != gdv);  // bit i: a segment ends with column i
@@ -701,7 +732,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
       bool first = true;
 #pragma unroll
       for (int i = 0; i < COLS; ++i) {
-        run += vv[i];
+        if (VH < COLS && i > 0 && i % VH == 0) {  // next batch of staged values
+#pragma unroll
+          for (int i2 = 0; i2 < VH; ++i2) vv[i2] = stage[(c0 + i + i2) * kStageLd + f];
+        }
+        run += vv[i % VH];
         if (__builtin_expect((mine >> i) & 1ull, 0)) {
           const int cur = __builtin_amdgcn_readlane(gdv, c0 + i);
           if (cur >= 0 && GW_SKIP(a) != 1) {

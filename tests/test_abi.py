@@ -79,6 +79,7 @@ def test_edge_update_workspace_query_is_host_logic():
     zero = GwOperand(None, None, 0, 0, 0, 0, 0)
     w = GwMlpWeights()
     w.hidden, w.n_mid, w.n_out, w.weight_dtype, w.ln_width = 256, 1, 256, DTYPE_BF16, 0
+    w.ln_gamma, w.ln_beta = 1, 1  # (LayerNorm present: the resident bf16 kernels need it; pointers only have to be non-null here)
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, zero, proj, w, 0) == 0  # all projected: gathered inside the one launch
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, proj, w, 0) == 0
     assert L.gw_edge_update_workspace_bytes(3, 130, proj, proj, raw, w, 0) == 0   # raw fp32 rows: the streaming kernel
