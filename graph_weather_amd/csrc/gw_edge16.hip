@@ -469,28 +469,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
       const int col = cp * (8 * NW) + (int)(threadIdx.x >> 3);
       const bool cvalid = eb * kTileCols + col < a.n_edges;
       char* out = lds + kOffH1 + buffer * kHBytes + (col >> 4) * 8192 + (16 * (gpiece & 3) + (col & 15)) * 16 + (gpiece >> 2) * 8;
+      // every load of the tile in flight at once: ONE round trip (two half-tile passes measured 7.4 k cycles against 5.9 k)
+      f32x4 z[8], v[8];  // table 0 lands in z, table 1 in v: both in flight together (64 registers)
+      {
+        const float* row = a.p_ptr[0] + ((size_t)b * (size_t)a.p_rows_pb[0] + (size_t)gidx[cp][0]) * (size_t)a.p_ld[0] + gp4;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {  // K-steps 4 h .. 4 h + 3 at a time: registers
-        f32x4 z[4];
+        for (int s = 0; s < 8; ++s) z[s] = ldg4(row + 32 * s);
+      }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) z[s] = *(const f32x4*)(b1l + 32 * (4 * h + s));
+      for (int p = 1; p < 3; ++p)
+        if (p < a.n_proj) {
+          const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          if (p < a.n_proj) {  // (all tables' loads of this half are in flight together)
-            const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
-            f32x4 v[4];
+          for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) v[s] = ldg4(row + 32 * (4 * h + s));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) z[s] += v[s];
-          }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
-          *(bf16x4*)(out + (4 * h + s) * 1024) = v;
+          for (int s = 0; s < 8; ++s) z[s] += v[s];
         }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) z[s] += *(const f32x4*)(b1l + 32 * s);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bf16x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
+        *(bf16x4*)(out + s * 1024) = o4;
       }
     }
     if (more) load_gather_indices(u + nslot);  // the indices of the tile after this one: in flight for a whole tile
