@@ -519,9 +519,13 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
 
 extern "C" {
 
+// K-steps (32 input features each) of a packed bf16 slice: the layer-1 kernels exist for 1, 4 and 8 steps (k <= 32, k <= 128,
+// 256) and stream exactly that many, so a narrower slice is zero-padded to its variant's step count (see gw_packed_floats).
+static int packed_steps_bf16(int kseg) { return kseg <= 32 ? 1 : (kseg <= 128 ? 4 : (kseg + 31) / 32); }
+
 size_t gw_packed_bytes_bf16(int n_out, int k_lo, int k_hi) {
   const int kseg = k_hi - k_lo;
-  const int nsteps = (kseg + 31) / 32;
+  const int nsteps = packed_steps_bf16(kseg);
   const int ntp = (((n_out + 15) / 16) + 3) / 4 * 4;
   return (size_t)nsteps * ntp * 1024;
 }
@@ -530,7 +534,7 @@ int gw_pack_linear_bf16(const float* w, int n_out, int k_total, int k_lo, int k_
   if (!w || !out || n_out <= 0 || k_lo < 0 || k_hi <= k_lo || k_hi > k_total)
     return gw::set_error(GW_E_BADARG, "gw_pack_linear_bf16: bad arguments");
   const int kseg = k_hi - k_lo;
-  const int nsteps = (kseg + 31) / 32;
+  const int nsteps = packed_steps_bf16(kseg);
   const int ntp = (((n_out + 15) / 16) + 3) / 4 * 4;
   const size_t total = (size_t)nsteps * ntp * 512;
   int grid = (int)((total + 255) / 256);

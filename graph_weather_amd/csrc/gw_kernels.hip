@@ -693,9 +693,14 @@ int gw_debug_timestamps(void* buffer, int capacity_workgroups, int kind) {
 }
 const char* gw_last_error(void) { return g_err; }
 
+// K-steps (4 input features each) of a packed slice: the layer-1 kernels exist for 4, 28 and 64+ steps (k <= 16, k <= 112, wider)
+// and stream exactly that many from the pack, so a narrower slice is zero-padded to its variant's step count (a 78-wide
+// input - GraphCast, graphcast/model.py:21 - used to get 20 steps and the 28-step kernel read 32 KB past its end).
+static int packed_steps_f32(int kseg) { return kseg <= 16 ? 4 : (kseg <= 112 ? 28 : ((kseg + 15) / 16) * 4); }
+
 size_t gw_packed_floats(int n_out, int k_lo, int k_hi) {
   const int kseg = k_hi - k_lo;
-  const int nsteps = ((kseg + 15) / 16) * 4;
+  const int nsteps = packed_steps_f32(kseg);
   const int nt = (n_out + 15) / 16;
   const int nt4 = (nt + 3) / 4;
   return (size_t)nsteps * nt4 * 256;
@@ -704,7 +709,7 @@ size_t gw_packed_floats(int n_out, int k_lo, int k_hi) {
 int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, float* out, void* stream) {
   if (!w || !out || n_out <= 0 || k_lo < 0 || k_hi <= k_lo || k_hi > k_total) return fail(GW_E_BADARG, "gw_pack_linear: bad arguments");
   const int kseg = k_hi - k_lo;
-  const int nsteps = ((kseg + 15) / 16) * 4;
+  const int nsteps = packed_steps_f32(kseg);
   const int nt4 = (((n_out + 15) / 16) + 3) / 4;
   const size_t total = (size_t)nsteps * nt4 * 256;
   int grid = (int)((total + 255) / 256);

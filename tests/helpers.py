@@ -51,7 +51,7 @@ def pack_linear_ref(w: np.ndarray, k_lo: int, k_hi: int) -> np.ndarray:
     """numpy statement of gw_pack_linear's layout: out[s][b4][lane][i]."""
     n_out = w.shape[0]
     kseg = k_hi - k_lo
-    nsteps = ((kseg + 15) // 16) * 4
+    nsteps = 4 if kseg <= 16 else (28 if kseg <= 112 else ((kseg + 15) // 16) * 4)  # padded to the layer-1 kernel variant's steps
     nt = (n_out + 15) // 16
     nt4 = (nt + 3) // 4
     out = np.zeros((nsteps, nt4, 64, 4), dtype=np.float32)
@@ -94,7 +94,7 @@ def pack_linear_bf16_ref(w: np.ndarray, k_lo: int, k_hi: int) -> np.ndarray:
     """numpy statement of gw_pack_linear_bf16's layout: out[s][tile][lane][i] (float32 values before rounding)."""
     n_out = w.shape[0]
     kseg = k_hi - k_lo
-    nsteps = (kseg + 31) // 32
+    nsteps = 1 if kseg <= 32 else (4 if kseg <= 128 else (kseg + 31) // 32)  # padded to the layer-1 kernel variant's steps
     ntp = (((n_out + 15) // 16) + 3) // 4 * 4
     out = np.zeros((nsteps, ntp, 64, 8), dtype=np.float32)
     for s in range(nsteps):

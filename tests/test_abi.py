@@ -30,6 +30,8 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert L.gw_packed_floats(256, 0, 256) == 256 * 256
     assert L.gw_packed_floats(78, 0, 128) == 32 * 2 * 256
     assert L.gw_packed_floats(256, 0, 102) == 28 * 4 * 256
+    assert L.gw_packed_floats(256, 0, 78) == 28 * 4 * 256   # padded to the 28-step layer-1 kernel (k <= 112), not 20 steps
+    assert L.gw_packed_floats(256, 0, 3) == 4 * 4 * 256
     assert L.gw_padded_n(78) == 96
 
 
@@ -44,6 +46,7 @@ def test_argument_validation_without_gpu():
     assert L.gw_packed_bytes_bf16(256, 0, 256) == 8 * 16 * 1024  # 8 K-steps x 16 row tiles x 1 KiB
     assert L.gw_packed_bytes_bf16(78, 0, 128) == 4 * 8 * 1024    # 5 tiles padded to 8
     assert L.gw_packed_bytes_bf16(256, 0, 102) == 4 * 16 * 1024
+    assert L.gw_packed_bytes_bf16(256, 0, 78) == 4 * 16 * 1024   # padded to the 4-step layer-1 kernel (k <= 128), not 3 steps
 
 
 def test_product_has_no_cpu_path():

@@ -40,7 +40,7 @@ def test_extension_is_loaded():
     assert torch.cuda.is_available()
 
 
-@pytest.mark.parametrize("n_out,k_total,k_lo,k_hi", [(256, 768, 256, 512), (256, 102, 0, 102), (78, 128, 0, 128), (256, 2, 0, 2)])
+@pytest.mark.parametrize("n_out,k_total,k_lo,k_hi", [(256, 768, 256, 512), (256, 102, 0, 102), (78, 128, 0, 128), (256, 2, 0, 2), (256, 78, 0, 78)])
 def test_pack_linear_matches_layout_statement(n_out, k_total, k_lo, k_hi):
     rs = np.random.RandomState(0)
     w = rs.standard_normal((n_out, k_total)).astype(np.float32)
@@ -286,7 +286,7 @@ def test_quarter_degree_stress_properties():
 BF16_REL = 3e-2
 
 
-@pytest.mark.parametrize("n_out,k_total,k_lo,k_hi", [(256, 768, 256, 512), (256, 102, 0, 102), (78, 128, 0, 128), (256, 2, 0, 2)])
+@pytest.mark.parametrize("n_out,k_total,k_lo,k_hi", [(256, 768, 256, 512), (256, 102, 0, 102), (78, 128, 0, 128), (256, 2, 0, 2), (256, 78, 0, 78)])
 def test_pack_linear_bf16_matches_layout_statement(n_out, k_total, k_lo, k_hi):
     from .helpers import pack_linear_bf16_ref
 
