@@ -8,7 +8,7 @@ from .helpers import k_of, mfma_16x16x4_emulate, pack_linear_ref
 
 def _layer(wp, in_regs, nt):
     """in_regs: [nsteps, 64] per-lane B operands. returns acc [nt, 4, 64]."""
-    nsteps = wp.shape[0]
+    nsteps = min(wp.shape[0], len(in_regs))  # the pack may be zero-padded beyond the operand's K-steps (gw_packed_floats)
     acc = np.zeros((nt, 4, 64))
     for s in range(nsteps):
         for t in range(nt):
