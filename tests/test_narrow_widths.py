@@ -91,4 +91,4 @@ def test_widths_beyond_the_kernels_raise():
     with pytest.raises(NotImplementedError):
         gw.MLP(300, 128, 128)._layout()
     with pytest.raises(NotImplementedError):
-        gw.GraphProcessor(1, 128, 128, 128, 128, norm_type=None).run_plan(None, None, None, True, 1, False)
+        gw.GraphProcessor(1, 300, 128, 128, 128).run_plan(None, None, None, True, 1, False)  # (norm_type=None is supported now)
