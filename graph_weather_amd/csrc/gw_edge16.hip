@@ -17,20 +17,21 @@
 // of fp32 rows, every access a fully coalesced 1 KiB per wave instruction, no conversion anywhere.
 //
 // Launches of one edge update:
-//  1. layer 1 -> workspace tiles of relu(z1) in bf16:
-//     edge16_gather_kernel  (every operand projected: encoder, decoder, first processor block) - pure gather-add, or
-//     edge16_l1_kernel      (processor blocks 1..: the per-sample edge features are a raw operand) - W_e lives in LDS
-//                           (128 KiB, loaded once per persistent workgroup), every wave works on its own 16-column groups
-//                           with no inter-wave synchronisation: b1 + P_s[src] + P_d[dst] gathered into the accumulators,
-//                           128 MFMAs against the edge tile, relu, bf16, one 16-byte store per K-step.
-//  2. edge16_kernel<NW> (persistent, W_mid and W_out in registers: wave w keeps rows 256/NW * w .. of both matrices as MFMA
-//     A fragments in AGPRs for the whole kernel) - per tile: the 32 KiB of layer-1 activations arrive by LDS-DMA, prefetched
-//     one tile ahead | barrier | middle layer -> Hbuf2 | barrier | output layer, LayerNorm partial sums through LDS |
-//     barrier | LayerNorm, residual, [e' tile store], staging | barrier | per-feature segment sums (plain stores for segments
-//     inside the tile, atomics for the two that may continue in a neighbour) [| e' rows from the staged tile].
-//     NW = 8 (512 threads, two waves per SIMD, 128 weight registers each) is the default: the phases outside the matrix
-//     products are instruction-issue bound with one wave per SIMD (measured round 1: ~3100 instructions per tile and wave
-//     at ~7 cycles each), a partner wave on the same SIMD fills those stalls.  NW = 4 is kept for A/B runs (tuning builds).
+//  A. every operand projected (decoder, first processor block): ONE launch, edge16_kernel<NW, RES, GATHER = true> - layer 1
+//     is a pure gather-add and is done at the top of each tile inside the persistent kernel (see GATHER below).
+//  B. the per-sample edge features are a raw operand (processor blocks 1..): two launches -
+//     edge16_l1_kernel: W_e lives in LDS (128 KiB, loaded once per persistent workgroup), every wave works on its own
+//       16-column groups with no inter-wave synchronisation: b1 + P_s[src] + P_d[dst] gathered into the accumulators, 128 MFMAs
+//       against the edge tile, relu, bf16, one 16-byte store per K-step into a workspace of layer-1 tiles;
+//     edge16_kernel<NW, RES, GATHER = false>: those tiles arrive by LDS-DMA, prefetched one tile ahead.
+//     (edge16_gather_kernel + GATHER = false is the round-1 two-launch form of case A, kept for A/B runs in tuning builds.)
+//  edge16_kernel (persistent, W_mid and W_out in registers: wave w keeps rows 256/NW * w .. of both matrices as MFMA A
+//     fragments in AGPRs for the whole kernel) - per tile: layer-1 activations in Hbuf1 | barrier | middle layer -> Hbuf2 |
+//     barrier | output layer, LayerNorm partial sums through LDS | barrier | LayerNorm, residual, [e' tile store], staging |
+//     barrier | per-feature segment sums (plain stores for segments inside the tile, atomics - or carry records in the
+//     deterministic mode - for the two that may continue in a neighbour) [| e' rows from the staged tile].
+//     NW = 8 (512 threads, two waves per SIMD, 128 weight registers each) is the default; NW = 4 is the deterministic form
+//     (one thread walks a whole tile) and the A/B form of tuning builds.
 // Tiles are walked batch-innermost and XCD-aware: the workgroups of an XCD work on the same edge blocks of all batch
 // elements at a time, so rows of batch-shared tables are fetched from HBM once and hit in that XCD's L2 afterwards.
 // Everything outside the matrix products is fp32, as in gw_bf16.hip.
