@@ -38,12 +38,10 @@ for name in ("fetch", "write", "sq", "grbm"):
         if not m: continue
         kind = m.group(1)
         i = pos[kind]; pos[kind] += 1
-        per_fwd = {"edge16_l1_kernel": 8, "edge16_gather_kernel": 2}.get(kind, 10)
-        slot = i % per_fwd
-        if kind.startswith("edge16_kernel"):
-            label = "block0" if slot == 0 else ("decoder" if slot == 9 else "blocks1-8")
-        elif kind == "edge16_gather_kernel":
-            label = "block0" if slot == 0 else "decoder"
+        # per forward: <.., GATHER = true> twice (first processor block, decoder), <.., GATHER = false> and the layer-1
+        # kernel once per processor block 1..8
+        if kind.startswith("edge16_kernel") and kind.rstrip(">").endswith("true"):
+            label = "block0" if i % 2 == 0 else "decoder"
         else:
             label = "blocks1-8"
         for r in rs:
