@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16 = 0, 1
 EDGE_DETERMINISTIC = 1
@@ -27,6 +27,7 @@ EXPORTS = [
     "gw_edge_rows_to_tiles", "gw_node_update_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
     "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step", "gw_nudging_forward", "gw_nudging_backward",
+    "gw_linear_forward", "gw_layernorm_forward", "gw_add_rows", "gw_gather_rows_wide", "gw_segment_sum_rows_wide",
 ]
 
 GEMM_NN, GEMM_TN = 0, 1
@@ -151,6 +152,19 @@ def lib():
     L.gw_nudging_backward.restype = c_int
     L.gw_nudging_backward.argtypes = [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.gw_linear_forward.restype = c_int
+    L.gw_linear_forward.argtypes = [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                    c_void_p]
+    L.gw_layernorm_forward.restype = c_int
+    L.gw_layernorm_forward.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                       c_void_p]
+    L.gw_add_rows.restype = c_int
+    L.gw_add_rows.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p]
+    L.gw_gather_rows_wide.restype = c_int
+    L.gw_gather_rows_wide.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]
+    L.gw_segment_sum_rows_wide.restype = c_int
+    L.gw_segment_sum_rows_wide.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_void_p]
     if L.gw_version() != ABI_VERSION:
         raise RuntimeError("graph_weather_amd: libgw_amd.so ABI version mismatch")
     _lib = L

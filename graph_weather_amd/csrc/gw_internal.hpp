@@ -134,6 +134,12 @@ size_t edge16_workspace_needed(int32_t batch, int32_t n_edges, const gw_operand*
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                          void* stream);
 
+// widths above 256 of gw_layernorm_backward / gw_relu_backward (gw_wide.hip)
+int ln_bwd_wide_launch(int64_t rows, int32_t width, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y, const float* gamma,
+                       float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream);
+int relu_mask_wide_launch(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
+                          int32_t ld_dz, void* stream);
+
 }  // namespace gw
 
 #endif  // GW_INTERNAL_HPP

@@ -652,8 +652,12 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
 
 int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
                      int32_t ld_dz, float* db, void* stream) {
-  if (!dh || rows < 0 || width <= 0 || width > 256) return fail(GW_E_BADARG, "gw_relu_backward: bad arguments (width <= 256)");
+  if (!dh || rows < 0 || width <= 0) return fail(GW_E_BADARG, "gw_relu_backward: bad arguments");
   if (rows == 0) return GW_OK;
+  if (width > 256) {  // wide models (gw_wide.hip): mask only - their bias gradient is the column sum of the weight-gradient GEMM
+    if (db != nullptr || dz == nullptr) return fail(GW_E_UNSUPPORTED, "gw_relu_backward: widths above 256 take dz and no db");
+    return relu_mask_wide_launch(rows, width, dh, ld_dh, h, ld_h, dz, ld_dz, stream);
+  }
   const int strip = 256;  // few blocks per column: the bias-gradient atomics of all blocks hit the same 256 addresses
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, width,
                      dh, ld_dh, h, ld_h, dz, ld_dz, db, strip);
@@ -662,9 +666,10 @@ int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh
 
 int gw_layernorm_backward(int64_t rows, int32_t width, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y,
                           const float* gamma, float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream) {
-  if (!dn || !y || !gamma || !dy || rows < 0 || width <= 0 || width > 256 || ld_dn < width || ld_y < width || ld_dy < width)
-    return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments (width 1..256)");
+  if (!dn || !y || !gamma || !dy || rows < 0 || width <= 0 || ld_dn < width || ld_y < width || ld_dy < width)
+    return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments");
   if (rows == 0) return GW_OK;
+  if (width > 256) return ln_bwd_wide_launch(rows, width, dn, ld_dn, y, ld_y, gamma, dy, ld_dy, dgamma, dbeta, stream);
   const int strip = 512;
   const dim3 grid((unsigned)((rows + strip - 1) / strip));
   if (width == 256 && (ld_dn | ld_y | ld_dy) % 4 == 0) {

@@ -22,6 +22,7 @@ from torch import nn
 
 from . import autograd as ag
 from . import ops
+from . import wide
 from .autograd import OperandSpec
 from .graphs import ForecastGraphs, GraphPlan, build_forecast_graphs
 from .ops import Operand, PackedMLP
@@ -235,6 +236,8 @@ class MLP(nn.Module):
     def run(self, x2: torch.Tensor, n_rows: int, rows_per_batch: int, residual: Optional[Operand] = None) -> torch.Tensor:
         """Rows through the kernel variant: [n_rows, in_dim] -> [n_rows, native_out()] (the padded table layout for
         narrow ``as_table`` MLPs); differentiable when grad mode is on."""
+        if wide.is_wide(self):  # widths above 256: layer by layer on the generic kernels (wide.py), unpadded rows
+            return wide.mlp_rows(self, x2, None if residual is None else residual.tensor[:, :self.out_dim])
         k = self.native_k()
         if k > x2.shape[1]:
             x2 = torch.nn.functional.pad(x2, (0, k - x2.shape[1]))  # inputs of 113..255 features: zero columns
@@ -259,6 +262,8 @@ class MLP(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """graph_net_block.py:63-77."""
         lead = x.shape[:-1]
+        if wide.is_wide(self):
+            return wide.mlp_rows(self, x.reshape(-1, x.shape[-1]).contiguous()).reshape(*lead, self.out_dim)
         y = self.table(x)
         if y.shape[1] != self.out_dim:
             y = y[:, :self.out_dim]
@@ -351,6 +356,8 @@ def _check_native_dims(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edg
 def _pad256(t: torch.Tensor) -> torch.Tensor:
     """A [rows, width <= 256] tensor in the 256-float table layout of the kernels (zero columns appended)."""
     t = t.contiguous()
+    if t.shape[1] > 256:
+        raise RuntimeError("graph_weather_amd: a %d-wide table reached the 256-wide kernels" % int(t.shape[1]))
     return t if t.shape[1] == 256 else torch.nn.functional.pad(t, (0, 256 - t.shape[1]))
 
 
@@ -387,6 +394,9 @@ class GraphProcessor(nn.Module):
         Inference: the layer-1 node products of block i + 1 are made by the node update of block i (``GraphNetBlock.run``
         ``post_w``); ``pre_proj`` = (P_s, P_d, zeroed aggregate) of the first block when the caller's previous launch made
         them, ``tail_w`` = packed slices to multiply the final node rows with (returns (x, e, products) then)."""
+        if wide.processor_is_wide(self):
+            x, e_out = wide.run_blocks(self, x, plan, e, e_shared, batch, want_edges)
+            return (x, e_out) if tail_w is None else (x, e_out, None)
         _check_native_dims(*self._dims)
         nb = len(self.blocks)
         seg = 0
@@ -544,6 +554,11 @@ class GraphProcessor(nn.Module):
         tests/models/test_gradient_checkpointing.py:62-86): edges are dst-sorted once per edge_index tensor."""
         plan = self._plan_for(edge_index, int(x.shape[0]))
         dn, de = int(x.shape[1]), int(edge_attr.shape[1])
+        if wide.processor_is_wide(self):
+            x_out, e_out = wide.run_blocks(self, x.contiguous(), plan, edge_attr[plan.perm].contiguous(), False, 1, True)
+            e_ref = torch.empty_like(e_out)
+            e_ref[plan.perm] = e_out
+            return x_out, e_ref
         e_sorted = _pad256(edge_attr)[plan.perm].contiguous()
         x_out, e_out = self.run_plan(_pad256(x), plan, e_sorted, False, 1, True)
         e_ref = torch.empty_like(e_out)
@@ -616,6 +631,8 @@ class Encoder(nn.Module):
         if features.dim() != 3 or features.shape[1] != self.num_latlons:
             raise RuntimeError("features must be [B, %d, input_dim]" % self.num_latlons)
         B, G, F = (int(s) for s in features.shape)
+        if wide.encoder_is_wide(self):
+            return wide.encode(self, features)
         feats = features.contiguous().reshape(B * G, F)
         enc_plan, _ = self._plans(features.device)
         xg = self.node_encoder.run(feats, B * G, G)  # grid rows only
@@ -663,9 +680,9 @@ class Encoder(nn.Module):
         e_sorted = self.latent_edge_embedding(lat_plan)
         e_ref = torch.empty_like(e_sorted)
         e_ref[lat_plan.perm] = e_sorted
-        if self.output_dim != 256:
+        if x.shape[1] != self.output_dim:
             x = x[:, :self.output_dim]
-        if self.output_edge_dim != 256:
+        if e_ref.shape[1] != self.output_edge_dim:
             e_ref = e_ref[:, :self.output_edge_dim]
         ei = self.graphs.lat_edge_index.to(features.device)
         if self.efficient_batching:
@@ -703,7 +720,10 @@ class Processor(nn.Module):
                 efficient_batching: bool = False) -> torch.Tensor:
         """processor.py:83-128."""
         dn = int(x.shape[1])
-        x, edge_attr = _pad256(x), _pad256(edge_attr)
+        if wide.processor_is_wide(self.graph_processor):
+            x, edge_attr = x.contiguous(), edge_attr.contiguous()
+        else:
+            x, edge_attr = _pad256(x), _pad256(edge_attr)
         if efficient_batching and batch_size is not None and batch_size > 1:
             n = int(x.shape[0]) // batch_size
             plan = self.graph_processor._plan_for(edge_index, n)
@@ -713,7 +733,7 @@ class Processor(nn.Module):
             plan = self.graph_processor._plan_for(edge_index, int(x.shape[0]))
             e_sorted = edge_attr[plan.perm].contiguous()
             out, _ = self.graph_processor.run_plan(x, plan, e_sorted, False, 1, False)
-        return out if dn == 256 else out[:, :dn]
+        return out if out.shape[1] == dn else out[:, :dn]
 
 
 class AssimilatorDecoder(nn.Module):
@@ -767,6 +787,8 @@ class AssimilatorDecoder(nn.Module):
         if processor_features.shape[0] != B * M:
             raise RuntimeError("processor_features must have batch*num_h3 rows")
         dev = processor_features.device
+        if wide.decoder_is_wide(self):
+            return wide.decode(self, processor_features, B, residual=residual)
         processor_features = _pad256(processor_features)
         plan = self._plan(dev)
         e = self.edge_embedding(plan)
@@ -821,6 +843,8 @@ def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "Assimila
     between blocks.  Under autograd the blocks keep their separate differentiable projections."""
     B = int(features.shape[0])
     gp = processor.graph_processor
+    if wide.encoder_is_wide(encoder) or wide.processor_is_wide(gp) or wide.decoder_is_wide(decoder):
+        return wide.forward(encoder, processor, decoder, features, residual)
     _, lat_plan = encoder._plans(features.device)
     e_lat = encoder.latent_edge_embedding(lat_plan)
     fuse = (not _autograd_on(encoder, features) and not _autograd_on(gp) and not _autograd_on(decoder) and len(gp.blocks) > 0

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 10
+#define GW_ABI_VERSION 11
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -212,11 +212,13 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
                 float* c, int32_t ldc, float* colsum_a /* TN only, may be NULL: colsum_a[m] += sum_k A[k][m] (bias gradient) */,
                 void* stream);
 /* nn.ReLU backward fused with the nn.Linear bias gradient: dz = dh * (h > 0) (h NULL: dz = dh), db[c] += sum_r dz[r][c].
- * dz may alias dh or be NULL (bias gradient only); db may be NULL. width <= 256. */
+ * dz may alias dh or be NULL (bias gradient only); db may be NULL.  width > 256 (wide models): dz required, db must be NULL
+ * (their bias gradient is colsum_a of the weight-gradient GEMM). */
 int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
                      int32_t ld_dz, float* db, void* stream);
 /* nn.LayerNorm(width, eps 1e-5) backward from the saved pre-norm rows y: dy; dgamma += , dbeta += (may be NULL).
- * width 1..256 (256: the message-passing MLPs; other widths: LayerNorm on an output head, regional_forecast.py:223-230). */
+ * width 256: the message-passing MLPs; other widths <= 256: LayerNorm on an output head (regional_forecast.py:223-230);
+ * 257..4096: wide models. */
 int gw_layernorm_backward(int64_t rows, int32_t width, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y,
                           const float* gamma, float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream);
 /* Dual of the segment sum (graph_net_block.py:188): out[b, k, :] = table[b, idx[k], :] (+ add[b, k, :]); 256-float rows;
@@ -249,6 +251,28 @@ int gw_nudging_forward(int64_t rows, int32_t feat, int32_t hidden, const float* 
 int gw_nudging_backward(int64_t rows, int32_t feat, int32_t hidden, const float* in, int32_t ld_in, const float* w1, const float* w1t,
                         const float* b1, const float* w2, const float* b2, const float* dout, float* d_in, int32_t ld_din, float* dz,
                         float* hid, float* dcorr, void* stream);
+
+/* =====================================================================================================================
+ * Models wider than 256 features (the reference's training script builds 1024-wide ones, train/run.py:493-497) run layer
+ * by layer on the generic kernels below (csrc/gw_wide.hip) instead of the fused ones: same arithmetic as graph_net_block.py,
+ * nothing fused across layers.  All fp32 row-major, any width.
+ * ===================================================================================================================== */
+/* nn.Linear (+ nn.ReLU): out[r, :n] = act(x[r, :k] . w^T + bias); w = nn.Linear.weight as it lies in memory ([n, k], row
+ * stride ldw); bias may be NULL; relu 0 / 1.  fp32 MFMA, fp32 accumulate. */
+int gw_linear_forward(int64_t rows, int32_t k, int32_t n, const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias,
+                      int32_t relu, float* out, int32_t ldo, void* stream);
+/* nn.LayerNorm(width, eps 1e-5, affine) (+ res, the residual add of graph_net_block.py:135/:191); width <= 4096. */
+int gw_layernorm_forward(int64_t rows, int32_t width, const float* y, int32_t ld_y, const float* gamma, const float* beta,
+                         const float* res, int32_t ld_res, float* out, int32_t ld_out, void* stream);
+/* out = a + b (residual add behind an MLP without norm). */
+int gw_add_rows(int64_t rows, int32_t width, const float* a, int32_t lda, const float* b, int32_t ldb, float* out, int32_t ldo,
+                void* stream);
+/* gw_gather_rows / gw_segment_sum_rows for rows of any width (row strides ld / ldo); the segment sum walks the CSR in one
+ * fixed order (no atomics: bitwise reproducible). */
+int gw_gather_rows_wide(int32_t batch, int32_t n_idx, int32_t width, const float* table, int32_t ld, int32_t rows_per_batch,
+                        const int32_t* idx, float* out, int32_t ldo, void* stream);
+int gw_segment_sum_rows_wide(int32_t batch, int32_t batch_out, int32_t n_seg, int32_t width, const float* rows, int32_t ld,
+                             int32_t rows_per_batch_in, const int32_t* perm, const int32_t* ptr, float* out, int32_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

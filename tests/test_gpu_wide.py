@@ -1,0 +1,229 @@
+"""Models wider than the fused kernels' 256 features (the reference's training script builds 1024-wide ones,
+train/run.py:493-497): ``graph_weather_amd/wide.py`` over ``csrc/gw_wide.hip``.  Kernels against fp64 torch on the CPU at
+ragged shapes, autograd nodes against torch autograd, modules and the forecaster against the oracle (forward 1e-5 on the
+delta scale like the native path; gradients with the bars of tests/test_gpu_backward.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import graph_weather_amd as gw  # noqa: E402
+from graph_weather_amd import wide  # noqa: E402
+from graph_weather_amd.graphs import plan_from_coo  # noqa: E402
+from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons  # noqa: E402
+from oracle import reference_math as om  # noqa: E402
+
+from .test_gpu_backward import _check_param_grads, _rel  # noqa: E402
+from .test_gpu_parity import _close  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _t(rs, *shape, scale=1.0):
+    return torch.from_numpy((scale * rs.standard_normal(shape)).astype(np.float32))
+
+
+@pytest.mark.parametrize("rows,k,n,relu,bias", [(1000, 102, 300, True, True), (777, 3072, 1024, True, True), (1, 2, 512, False, True),
+                                                (130, 1024, 78, False, False), (129, 257, 129, True, True), (4096, 512, 512, False, True)])
+def test_linear_forward_against_float64(rows, k, n, relu, bias):
+    rs = np.random.RandomState(rows + k)
+    x, w = _t(rs, rows, k), _t(rs, n, k, scale=1.0 / np.sqrt(k))
+    b = _t(rs, n) if bias else None
+    ref = x.double() @ w.double().t() + (0 if b is None else b.double())
+    if relu:
+        ref = torch.relu(ref)
+    got = wide.linear_forward(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), relu).cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, f"linear {rows}x{k}->{n}: {err:.2e}"
+
+
+def test_linear_forward_with_row_strides():
+    """Operands that are column slices of wider tensors (row stride > width): the decoder's residual, weight column ranges."""
+    rs = np.random.RandomState(3)
+    xw, ww = _t(rs, 300, 700), _t(rs, 260, 900, scale=0.05)
+    x, w = xw[:, 100:612], ww[:, 4:516]
+    ref = x.double() @ w.double().t()
+    got = wide.linear_forward(xw.to(DEV)[:, 100:612], ww.to(DEV)[:, 4:516], None, False).cpu().double()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("rows,width,res", [(333, 300, True), (1000, 1024, True), (5, 4096, False), (64, 257, False), (77, 78, True)])
+def test_layernorm_forward_and_backward_against_torch(rows, width, res):
+    rs = np.random.RandomState(width)
+    y, g, b = _t(rs, rows, width), 1 + _t(rs, width, scale=0.1), _t(rs, width, scale=0.1)
+    r = _t(rs, rows, width) if res else None
+    dout = _t(rs, rows, width)
+    yr, gr, br = (t.double().requires_grad_(True) for t in (y, g, b))
+    ref = torch.nn.functional.layer_norm(yr, (width,), gr, br, 1e-5) + (0 if r is None else r.double())
+    ref.backward(dout.double())
+    yd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (y, g, b))
+    rd = None if r is None else r.to(DEV).requires_grad_(True)
+    out = wide._LayerNorm.apply(yd, gd, bd, rd)
+    out.backward(dout.to(DEV))
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-5
+    assert _rel(yd.grad, yr.grad) < 1e-4 and _rel(gd.grad, gr.grad) < 1e-4 and _rel(bd.grad, br.grad) < 1e-4
+    if rd is not None:
+        assert torch.equal(rd.grad.cpu(), dout)
+
+
+def test_gather_and_segment_sum_at_any_width_and_their_gradients():
+    rs = np.random.RandomState(8)
+    B, n_src, n_dst, E, W = 3, 40, 25, 333, 300
+    src = rs.randint(0, n_src, size=E)
+    dst = np.where(rs.rand(E) < 0.3, 7, rs.randint(0, n_dst, size=E))
+    plan = plan_from_coo(src, dst, n_src, n_dst).to(DEV)
+    table, shared, rows = _t(rs, B * n_src, W), _t(rs, n_src, W), _t(rs, B * E, W)
+    s, d = plan.src.long().cpu(), plan.dst.long().cpu()
+    # gather per sample / shared, with gradient
+    for tb, rows_pb in ((table, n_src), (shared, 0)):
+        td = tb.to(DEV).requires_grad_(True)
+        got = wide._Gather.apply(td, plan.src, B, rows_pb, E, plan.src_sorted())
+        tr = tb.double().requires_grad_(True)
+        ref = tr.reshape(B, n_src, W)[:, s].reshape(B * E, W) if rows_pb else tr[s].repeat(B, 1)
+        assert torch.equal(got.detach().cpu().double(), ref.detach())
+        gw_ = _t(rs, B * E, W)
+        got.backward(gw_.to(DEV))
+        ref.backward(gw_.double())
+        assert _rel(td.grad, tr.grad) < 1e-5
+    # segment sum by destination, with gradient
+    rd = rows.to(DEV).requires_grad_(True)
+    got = wide._SegmentSum.apply(rd, plan, B)
+    rr = rows.double().requires_grad_(True)
+    ref = torch.zeros(B, n_dst, W, dtype=torch.float64).index_add(1, d, rr.reshape(B, E, W)).reshape(B * n_dst, W)
+    assert (got.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4
+    g2 = _t(rs, B * n_dst, W)
+    got.backward(g2.to(DEV))
+    ref.backward(g2.double())
+    assert _rel(rd.grad, rr.grad) < 1e-6
+    again = wide._SegmentSum.apply(rd.detach(), plan, B)
+    assert torch.equal(again, got.detach())  # one summation order: bitwise reproducible
+
+
+@pytest.mark.parametrize("i,o,h,layers,norm", [(102, 320, 384, 2, "LayerNorm"), (300, 78, 300, 2, None), (1024, 1024, 1024, 2, "LayerNorm"),
+                                                (2, 512, 64, 1, "LayerNorm"), (700, 100, 128, 3, "LayerNorm")])
+def test_wide_mlp_forward_and_backward(i, o, h, layers, norm):
+    m = gw.MLP(i, o, h, layers, norm)
+    deterministic_fill_(m, seed=i + o)
+    rs = np.random.RandomState(h)
+    x, dy = _t(rs, 333, i), _t(rs, 333, o)
+    ref = {"m." + k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    y_ref = om.mlp(ref, "m", xr)
+    y_ref.backward(dy.double())
+    m = m.to(DEV)
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    assert y.shape == (333, o)
+    _close(y, y_ref, what=f"wide MLP {i}->{h}x{layers}->{o} (inference)")
+    xd = x.to(DEV).requires_grad_(True)
+    y = m(xd)
+    y.backward(dy.to(DEV))
+    worst = {}
+    _check_param_grads(m, ref, "m.", worst)
+    assert _rel(xd.grad, xr.grad) < 2e-3
+
+
+def test_wide_graph_processor_random_coo():
+    gp = gw.GraphProcessor(mp_iterations=2, in_dim_node=320, in_dim_edge=288, hidden_dim_node=384, hidden_dim_edge=300)
+    deterministic_fill_(gp, seed=4)
+    ref = {"gp." + k: v.detach().double().requires_grad_(True) for k, v in gp.state_dict().items()}
+    rs = np.random.RandomState(5)
+    n, e = 150, 900
+    x, ea = _t(rs, n, 320), _t(rs, e, 288)
+    ei = torch.from_numpy(np.stack([rs.randint(0, n, size=e), np.where(rs.rand(e) < 0.2, 3, rs.randint(0, n, size=e))]).astype(np.int64))
+    gx, ge = _t(rs, n, 320), _t(rs, e, 288)
+    xr, er = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    xo_r, eo_r = om.graph_processor(ref, "gp", xr, ei, er)
+    ((xo_r * gx.double()).sum() + (eo_r * ge.double()).sum()).backward()
+    gp = gp.to(DEV)
+    with torch.no_grad():
+        xo, eo = gp(x.to(DEV), ei.to(DEV), ea.to(DEV))
+    assert xo.shape == (n, 320) and eo.shape == (e, 288)
+    _close(xo, xo_r, what="wide GraphProcessor nodes")
+    _close(eo, eo_r, what="wide GraphProcessor edges")
+    xd, ed = x.to(DEV).requires_grad_(True), ea.to(DEV).requires_grad_(True)
+    xo, eo = gp(xd, ei.to(DEV), ed)
+    ((xo * gx.to(DEV)).sum() + (eo * ge.to(DEV)).sum()).backward()
+    worst = {}
+    _check_param_grads(gp, ref, "gp.", worst)
+    assert _rel(xd.grad, xr.grad) < 2e-3 and _rel(ed.grad, er.grad) < 2e-3
+
+
+def _wide_forecaster(lat_lons, **over):
+    kw = dict(feature_dim=20, aux_dim=5, node_dim=320, edge_dim=288, num_blocks=2, hidden_dim_processor_node=384,
+              hidden_dim_processor_edge=300, hidden_dim_decoder=272)
+    kw.update(over)
+    model = gw.GraphWeatherForecaster(lat_lons, **kw)
+    deterministic_fill_(model, seed=9)
+    return model
+
+
+def test_wide_forecaster_matches_oracle_forward_and_backward():
+    lat_lons = regular_lat_lons(15.0)
+    model = _wide_forecaster(lat_lons)
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    g64 = om.graphs_to_dtype(model.encoder.graphs.as_oracle_dict(), torch.float64)
+    rs = np.random.RandomState(1)
+    feats, dy = _t(rs, 2, len(lat_lons), 25), _t(rs, 2, len(lat_lons), 20)
+    y_ref = om.forecaster_forward(ref, g64, feats.double(), feature_dim=20)
+    (y_ref * dy.double()).sum().backward()
+    model = model.to(DEV)
+    with torch.no_grad():
+        y = model(feats.to(DEV))
+    res = feats[..., :20]
+    _close(y.cpu() - res, y_ref.detach().float() - res, what="wide forecaster (inference)")
+    model.train()
+    y = model(feats.to(DEV))
+    (y * dy.to(DEV)).sum().backward()
+    worst = {}
+    _check_param_grads(model, ref, "", worst, bar=4e-3)
+    # compositional API at the real widths (tests/test_model.py:106-119)
+    with torch.no_grad():
+        x, ei, ea = model.encoder(feats.to(DEV))
+        assert x.shape[1] == 320 and ea.shape[1] == 288
+        out = model.decoder(model.processor(x, ei, ea), feats.to(DEV)[..., :20])
+    _close(out, y, rel=1e-5, what="wide compositional")
+    # checkpointing (forecast.py use_checkpointing, processor.py:70-81) changes memory, not results
+    model.processor.set_checkpoint_segments(1)
+    model.zero_grad()
+    y2 = model(feats.to(DEV))
+    (y2 * dy.to(DEV)).sum().backward()
+    assert torch.equal(y2, y)
+    worst = {}
+    _check_param_grads(model, ref, "", worst, bar=4e-3)
+    # no bf16 form of the wide path: loud
+    with pytest.raises(NotImplementedError, match="bf16"):
+        model.set_compute_dtype(torch.bfloat16)
+        with torch.no_grad():
+            model(feats.to(DEV))
+
+
+def test_reference_training_script_widths_one_step():
+    """The constructor call of the reference's train/run.py:486-501 (1024-wide nodes, edges, hidden layers and decoder) on a
+    10 degree grid: forward against the oracle, then loss.backward() + optimizer step like train/run.py:509-521."""
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons, feature_dim=20, aux_dim=4, edge_dim=1024, hidden_dim_processor_edge=1024, node_dim=1024,
+                                      hidden_dim_processor_node=1024, hidden_dim_decoder=1024, num_blocks=2)
+    deterministic_fill_(model, seed=2)
+    ref = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = model.encoder.graphs.as_oracle_dict()
+    rs = np.random.RandomState(2)
+    feats, target = _t(rs, 2, len(lat_lons), 24), _t(rs, 2, len(lat_lons), 20)
+    y_ref = om.forecaster_forward(ref, g, feats, feature_dim=20)
+    model = model.to(DEV)
+    with torch.no_grad():
+        y = model(feats.to(DEV))
+    res = feats[..., :20]
+    _close(y.cpu() - res, y_ref.float() - res, what="1024-wide forecaster")
+    criterion = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=torch.ones(20), device=DEV).to(DEV)
+    opt = gw.AdamW(model.parameters(), lr=1e-3)
+    model.train()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = criterion(model(feats.to(DEV)), target.to(DEV))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -85,10 +85,20 @@ def test_gradients_reach_the_real_parameters_through_the_padding():
         assert torch.allclose(v, ref["m." + k].grad, atol=1e-10), k
 
 
-def test_widths_beyond_the_kernels_raise():
+def test_widths_beyond_the_fused_kernels_take_the_wide_path():
+    """Widths above 256 (the reference's train/run.py:493-497 builds 1024) are not a fused-kernel layout; the modules route
+    them to graph_weather_amd/wide.py, which - like every other path - has no CPU form."""
+    from graph_weather_amd import wide
+
     with pytest.raises(NotImplementedError):
         gw.MLP(8, 300, 128)._layout()
     with pytest.raises(NotImplementedError):
         gw.MLP(300, 128, 128)._layout()
-    with pytest.raises(NotImplementedError):
-        gw.GraphProcessor(1, 300, 128, 128, 128).run_plan(None, None, None, True, 1, False)  # (norm_type=None is supported now)
+    assert wide.is_wide(gw.MLP(8, 300, 128)) and wide.is_wide(gw.MLP(300, 128, 128)) and wide.is_wide(gw.MLP(8, 8, 257))
+    assert not wide.is_wide(gw.MLP(256, 256, 256)) and not wide.is_wide(gw.MLP(102, 78, 128))
+    gp = gw.GraphProcessor(1, 300, 128, 128, 128)
+    assert wide.processor_is_wide(gp) and not wide.processor_is_wide(gw.GraphProcessor(1, 256, 256, 256, 256))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gw.MLP(8, 300, 128)(torch.zeros(4, 8))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gp(torch.zeros(5, 300), torch.zeros((2, 4), dtype=torch.int64), torch.zeros(4, 128))
