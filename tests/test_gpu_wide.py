@@ -217,13 +217,13 @@ def test_reference_training_script_widths_one_step():
     res = feats[..., :20]
     _close(y.cpu() - res, y_ref.float() - res, what="1024-wide forecaster")
     criterion = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=torch.ones(20), device=DEV).to(DEV)
-    opt = gw.AdamW(model.parameters(), lr=1e-3)
+    opt = gw.AdamW(model.parameters(), lr=2e-5)
     model.train()
     losses = []
-    for _ in range(3):
+    for _ in range(4):
         opt.zero_grad()
         loss = criterion(model(feats.to(DEV)), target.to(DEV))
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
