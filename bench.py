@@ -216,6 +216,7 @@ def run_extra(name, dev, steps, warmup):
     from graph_weather_amd.utils import seeded_features
 
     cfg = CONFIGS[name]
+    torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     model, lat_lons = build_model(cfg, dev)
     graphs = model.encoder.graphs
@@ -234,6 +235,41 @@ def run_extra(name, dev, steps, warmup):
            "graph_build_s": build_s, "dominant_kernel": r["kernel"], "launch_ms": r["launch_ms"], "frac": r["frac"], "peak": r["peak"],
            "step_frac": r["step_frac"], "other_kernels_ms": r["other_kernels_ms"], "gather_scatter_frac": r["gather_scatter"]["frac"],
            "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
+           "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}
+    del model, feats
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_wide(dev, steps=3, warmup=2):
+    """The reference training script's model widths (train/run.py:493-497: nodes, edges, hidden layers and decoder 1024 wide) on
+    the 1 degree grid, batch 1: the layer-by-layer path of graph_weather_amd/wide.py (generic fp32-MFMA kernels, nothing fused).
+    FLOPs are the reference's own arithmetic for those widths (no layer-1 split there; the decoder's zero operand is skipped)."""
+    import gc
+
+    import graph_weather_amd as gw
+    from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features
+
+    W = 1024
+    torch.cuda.reset_peak_memory_stats(dev)
+    lat_lons = regular_lat_lons(1.0)
+    model = gw.GraphWeatherForecaster(lat_lons, edge_dim=W, hidden_dim_processor_edge=W, node_dim=W, hidden_dim_processor_node=W,
+                                      hidden_dim_decoder=W)
+    deterministic_fill_(model, seed=0)
+    model = model.to(dev).eval()
+    g = model.encoder.graphs
+    G, M = g.num_grid, g.num_mesh
+    e_enc, e_lat, e_dec = g.enc_plan.num_edges, g.lat_plan.num_edges, g.dec_plan.num_edges
+    mlp = lambda i, h, o, rows: 2.0 * rows * (i * h + h * h + h * o)  # noqa: E731
+    flops = (mlp(102, W, W, G) + mlp(3 * W, W, W, e_enc) + mlp(2 * W, W, W, M) + 9 * (mlp(3 * W, W, W, e_lat) + mlp(2 * W, W, W, M))
+             + mlp(2 * W, W, W, e_dec) + mlp(W, W, W, G) + mlp(W, W, 78, G))
+    feats = seeded_features(1, len(lat_lons), 102, seed=42).to(dev)
+    elapsed, _ = time_forward(model, feats, steps, warmup, torch.cuda.synchronize, kernel_timer=False)
+    ms = 1e3 * elapsed / steps
+    out = {"workload": "1deg grid, widths 1024 (train/run.py:493-497), batch 1, fp32, wide (layer-by-layer) path",
+           "value": steps / elapsed, "unit": "forecasts/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+           "gflop_per_forecast": flops / 1e9, "tflops": flops / (ms * 1e-3) / 1e12, "step_frac": flops / (ms * 1e-3) / (PEAK_F32_MATRIX_TFLOPS * 1e12),
            "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}
     del model, feats
     gc.collect()
@@ -405,7 +441,8 @@ def main(argv=None, backend="nccl", device=None, model_factory=None):
             del model, feats
             gc.collect()
             torch.cuda.empty_cache()
-            out["extra"] = {"c3": run_extra("c3", dev, steps=10, warmup=3), "c5": run_extra("c5", dev, steps=5, warmup=2)}
+            out["extra"] = {"c3": run_extra("c3", dev, steps=10, warmup=3), "c5": run_extra("c5", dev, steps=5, warmup=2),
+                            "wide1024": run_wide(dev)}
         if world == 1 and not args.no_cpu_baseline and cfg["grid"] == 1.0:
             out["cpu_baseline"] = cpu_baseline(lat_lons, cpu_state, graphs)
         else:
