@@ -135,9 +135,17 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     n_lin = (len(weights) - (2 if has_norm else 0)) // 2
     if n_lin < 2:
         raise RuntimeError("MLP needs at least one hidden layer")
+    # every parameter gradient of this MLP is accumulated into (GEMMs with atomics, column sums): ONE zero fill for all of
+    # them - views of a single buffer - instead of one launch per parameter; grads[0] (W0) is handed to the caller zeroed
+    zbuf = torch.zeros(sum(int(w.numel()) for w in weights), dtype=torch.float32, device=dout.device)
+    zs, off = [], 0
+    for w in weights:
+        zs.append(zbuf[off:off + int(w.numel())].view(w.shape))
+        off += int(w.numel())
+    grads[0] = zs[0]
     if has_norm:
-        grads[-2] = torch.zeros_like(weights[-2])
-        grads[-1] = torch.zeros_like(weights[-1])
+        grads[-2] = zs[-2]
+        grads[-1] = zs[-1]
         d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1], ln_width)
     else:
         d = dout.contiguous()
@@ -146,14 +154,13 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     for l in range(n_lin - 1, 0, -1):
         W = weights[2 * l]
         h_prev = saved.hidden[l - 1]  # relu output feeding Linear_l, [rows, in_l]
-        gW = torch.zeros_like(W)
-        gb = torch.zeros_like(weights[2 * l + 1])
+        gW, gb = zs[2 * l], zs[2 * l + 1]
         gemm_tn_acc(d, h_prev, gW, colsum=gb)
         grads[2 * l], grads[2 * l + 1] = gW, gb
         d = (input_grad(mlp, l, d, W, 0, int(W.shape[1]), relu_of=h_prev) if mlp is not None
              else relu_backward(gemm_nn(d, W, int(W.shape[1])), h_prev, None))
     # Linear_0's bias gradient: column sums of dz0 (its weight gradient is the caller's: it depends on the operands)
-    grads[1] = torch.zeros_like(weights[1])
+    grads[1] = zs[1]
     relu_backward(d, None, grads[1])
     return d, d.device
 
@@ -181,7 +188,7 @@ class MLPRowsFunction(torch.autograd.Function):
         dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
                                      ctx.mlp.out_dim)
         W0 = params[0]
-        gW0 = torch.zeros_like(W0)
+        gW0 = grads[0]  # zeroed by _mlp_chain_backward
         gemm_tn_acc(dz0, x2, gW0)
         grads[0] = gW0
         dx = input_grad(ctx.mlp, 0, dz0, W0, 0, int(W0.shape[1])) if ctx.needs_input_grad[1] else None
@@ -341,7 +348,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
         has_norm = mlp._norm() is not None
         dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim)
         W0 = params[0]
-        gW0 = torch.zeros_like(W0)
+        gW0 = grads[0]  # zeroed by _mlp_chain_backward
         tensors = (x_src, x_dst, e_in)
         n_rows_tab = (plan.n_src, plan.n_dst, E)
         dts: List[Optional[torch.Tensor]] = [None, None, None]
@@ -399,7 +406,7 @@ class NodeUpdateFunction(torch.autograd.Function):
         has_norm = ctx.mlp._norm() is not None
         dz0, _ = _mlp_chain_backward(dout, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, ctx.mlp, ctx.mlp.out_dim)
         W0 = params[0]
-        gW0 = torch.zeros_like(W0)
+        gW0 = grads[0]  # zeroed by _mlp_chain_backward
         (xlo, xhi), (alo, ahi) = mlp.native_splits()
         gemm_tn_acc(dz0, agg, gW0, c_col0=alo)
         dagg = input_grad(mlp, 0, dz0, W0, alo, ahi) if ctx.needs_input_grad[7] else None
