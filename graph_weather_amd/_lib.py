@@ -27,7 +27,7 @@ EXPORTS = [
     "gw_edge_rows_to_tiles", "gw_node_update_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
     "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step", "gw_nudging_forward", "gw_nudging_backward",
-    "gw_linear_forward", "gw_layernorm_forward", "gw_add_rows", "gw_gather_rows_wide", "gw_segment_sum_rows_wide",
+    "gw_linear_forward", "gw_linear_gather_forward", "gw_layernorm_forward", "gw_add_rows", "gw_gather_rows_wide", "gw_segment_sum_rows_wide",
 ]
 
 GEMM_NN, GEMM_TN = 0, 1
@@ -156,8 +156,12 @@ def lib():
     L.gw_linear_forward.argtypes = [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                     c_void_p]
     L.gw_layernorm_forward.restype = c_int
-    L.gw_layernorm_forward.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
-                                       c_void_p]
+    L.gw_layernorm_forward.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p,
+                                       c_int32, c_void_p]
+    L.gw_linear_gather_forward.restype = c_int
+    L.gw_linear_gather_forward.argtypes = [c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), c_int32, c_void_p,
+                                           c_int32, c_void_p]
     L.gw_add_rows.restype = c_int
     L.gw_add_rows.argtypes = [c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p]
     L.gw_gather_rows_wide.restype = c_int

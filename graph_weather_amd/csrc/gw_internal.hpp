@@ -138,7 +138,7 @@ int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int3
 int ln_bwd_wide_launch(int64_t rows, int32_t width, const float* dn, int32_t ld_dn, const float* y, int32_t ld_y, const float* gamma,
                        float* dy, int32_t ld_dy, float* dgamma, float* dbeta, void* stream);
 int relu_mask_wide_launch(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
-                          int32_t ld_dz, void* stream);
+                          int32_t ld_dz, float* db, void* stream);
 
 }  // namespace gw
 

@@ -654,10 +654,7 @@ int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh
                      int32_t ld_dz, float* db, void* stream) {
   if (!dh || rows < 0 || width <= 0) return fail(GW_E_BADARG, "gw_relu_backward: bad arguments");
   if (rows == 0) return GW_OK;
-  if (width > 256) {  // wide models (gw_wide.hip): mask only - their bias gradient is the column sum of the weight-gradient GEMM
-    if (db != nullptr || dz == nullptr) return fail(GW_E_UNSUPPORTED, "gw_relu_backward: widths above 256 take dz and no db");
-    return relu_mask_wide_launch(rows, width, dh, ld_dh, h, ld_h, dz, ld_dz, stream);
-  }
+  if (width > 256) return relu_mask_wide_launch(rows, width, dh, ld_dh, h, ld_h, dz, ld_dz, db, stream);  // wide models (gw_wide.hip)
   const int strip = 256;  // few blocks per column: the bias-gradient atomics of all blocks hit the same 256 addresses
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, width,
                      dh, ld_dh, h, ld_h, dz, ld_dz, db, strip);

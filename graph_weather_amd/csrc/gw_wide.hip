@@ -35,10 +35,23 @@ int failw(int code, const char* msg) { return set_error(code, msg); }
 constexpr int kNtKC = 16;
 constexpr int kNtLd = 20;
 
+// Row tables added to the product before the activation: out[m] += table_i[b * rows_pb_i + idx_i[k]] with (b, k) = (m / rpb, m % rpb)
+// (idx NULL: k itself; rows_pb 0: one table shared by the batch).  This is how the layer-1 split of the fused kernels
+// (cat[x_s, x_d, e] . W1^T = x_s.Ws^T[src] + x_d.Wd^T[dst] + e.We^T) reaches the wide path: node products are made once per
+// node and gathered per edge here, in the epilogue of the edge-level product.
+struct Addends {
+  int n;                 // 0..3
+  int rows_per_batch;    // rpb
+  const float* table[3];
+  const int* idx[3];
+  int ld[3];
+  int rows_pb[3];
+};
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                       const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-                                                      int relu, float* __restrict__ C, int ldc) {
+                                                      int relu, float* __restrict__ C, int ldc, const Addends ga) {
   __shared__ __attribute__((aligned(16))) float As[2][128 * kNtLd];
   __shared__ __attribute__((aligned(16))) float Ws[2][128 * kNtLd];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,6 +119,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
     __syncthreads();
   }
   // D layout: column (n) = lane & 15, rows (m) = 4 * (lane >> 4) + r
+  if (ga.n > 0) {  // gathered row tables: 16 lanes read 64 contiguous bytes of a table row
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t mm = m0 + 64 * wm + 16 * tm + 4 * kq + r;
+        if (mm >= M) continue;
+        const int b = (int)(mm / ga.rows_per_batch), k = (int)(mm - (int64_t)b * ga.rows_per_batch);
+        for (int a = 0; a < ga.n; ++a) {
+          const int tr = ga.idx[a] != nullptr ? ldgi(ga.idx[a] + k) : k;
+          const float* row = ga.table[a] + ((size_t)b * ga.rows_pb[a] + tr) * ga.ld[a];
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + 64 * wn + 16 * tn + i;
+            if (n < N) acc[tm][tn][r] += ldg1(row + n);
+          }
+        }
+      }
+  }
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int n = n0 + 64 * wn + 16 * tn + i;
@@ -125,6 +157,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
   }
 }
 
+// out[m] = act(bias + sum_i table_i[row_i(m)]): layer 1 of an edge MLP whose every operand is a projected table (edge features
+// shared by the batch: first processor block, encoder, decoder) - no matrix work per edge at all.
+__global__ __launch_bounds__(256) void gather_sum_kernel(int64_t rows, int width, const float* __restrict__ bias, int relu,
+                                                         float* __restrict__ out, int ldo, const Addends ga) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= width) return;
+  const float bv = bias != nullptr ? ldg1(bias + c) : 0.f;
+  for (int64_t m = blockIdx.x; m < rows; m += gridDim.x) {
+    const int b = (int)(m / ga.rows_per_batch), k = (int)(m - (int64_t)b * ga.rows_per_batch);
+    float v = bv;
+    for (int a = 0; a < ga.n; ++a) {
+      const int tr = ga.idx[a] != nullptr ? ldgi(ga.idx[a] + k) : k;
+      v += ldg1(ga.table[a] + ((size_t)b * ga.rows_pb[a] + tr) * ga.ld[a] + c);
+    }
+    if (relu) v = fmaxf(v, 0.f);
+    stg1(out + (size_t)m * ldo + c, v);
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -135,11 +186,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NJ>
 __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(int64_t rows, int width, const float* __restrict__ y, int ld_y,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ res, int ld_res, float* __restrict__ out,
-                                                          int ld_out) {
+                                                          const float* __restrict__ res, int ld_res, int64_t res_period,
+                                                          float* __restrict__ out, int ld_out) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
+  const int64_t rr = res_period > 0 ? r % res_period : r;  // residual rows shared by the batch repeat with this period
   float v[NJ];
   float s = 0.f;
 #pragma unroll
@@ -162,7 +214,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(int64_t rows, int widt
     const int c = lane + 64 * j;
     if (c < width) {
       float o = (v[j] - mean) * rstd * ldg1(gamma + c) + ldg1(beta + c);
-      if (res != nullptr) o += ldg1(res + (size_t)r * ld_res + c);
+      if (res != nullptr) o += ldg1(res + (size_t)rr * ld_res + c);
       stg1(out + (size_t)r * ld_out + c, o);
     }
   }
@@ -233,14 +285,18 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(int64_t rows, int widt
 
 // ---- elementwise: dz = dh * (h > 0);  out = a + b -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relu_mask_wide_kernel(int64_t rows, int width, const float* __restrict__ dh, int ld_dh,
-                                                             const float* __restrict__ h, int ld_h, float* __restrict__ dz, int ld_dz) {
+                                                             const float* __restrict__ h, int ld_h, float* __restrict__ dz, int ld_dz,
+                                                             float* __restrict__ db) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= width) return;
+  float s = 0.f;
   for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
     float g = ldg1(dh + (size_t)r * ld_dh + c);
     if (h != nullptr && !(ldg1(h + (size_t)r * ld_h + c) > 0.f)) g = 0.f;
-    stg1(dz + (size_t)r * ld_dz + c, g);
+    if (dz != nullptr) stg1(dz + (size_t)r * ld_dz + c, g);
+    s += g;
   }
+  if (db != nullptr) __hip_atomic_fetch_add((GW_AS1 float*)(db + c), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void add_rows_kernel(int64_t rows, int width, const float* __restrict__ a, int lda,
@@ -320,9 +376,11 @@ int ln_bwd_wide_launch(int64_t rows, int32_t width, const float* dn, int32_t ld_
 }
 
 int relu_mask_wide_launch(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
-                          int32_t ld_dz, void* stream) {
-  hipLaunchKernelGGL(relu_mask_wide_kernel, dim3(row_blocks(rows), (unsigned)((width + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     rows, width, dh, ld_dh, h, ld_h, dz, ld_dz);
+                          int32_t ld_dz, float* db, void* stream) {
+  // with a bias gradient: few row blocks, so that the atomics of all blocks on the same `width` addresses stay cheap
+  const unsigned rb = db != nullptr ? (unsigned)(rows < 2048 ? (rows > 0 ? rows : 1) : 2048) : row_blocks(rows);
+  hipLaunchKernelGGL(relu_mask_wide_kernel, dim3(rb, (unsigned)((width + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     rows, width, dh, ld_dh, h, ld_h, dz, ld_dz, db);
   return check_launch("relu_mask_wide_kernel launch");
 }
 
@@ -330,32 +388,63 @@ int relu_mask_wide_launch(int64_t rows, int32_t width, const float* dh, int32_t 
 
 extern "C" {
 
+static int linear_launch(int64_t rows, int32_t k, int32_t n, const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias,
+                         int32_t relu, float* out, int32_t ldo, const Addends& ga, void* stream) {
+  if (rows >= ((int64_t)1 << 31)) return failw(GW_E_UNSUPPORTED, "gw_linear_forward: row count exceeds int32");
+  if (k == 0) {  // no matrix product: bias + gathered rows
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(row_blocks(rows), (unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n,
+                       bias, relu, out, ldo, ga);
+    return check_launch("gather_sum_kernel launch");
+  }
+  const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((n + 127) / 128));
+  const bool aligned = k % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0;
+  if (aligned)
+    hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (int)rows, n, k, x, ldx, w, ldw, bias, relu, out, ldo, ga);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (int)rows, n, k, x, ldx, w, ldw, bias, relu, out, ldo, ga);
+  return check_launch("gemm_nt_kernel launch");
+}
+
 int gw_linear_forward(int64_t rows, int32_t k, int32_t n, const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias,
                       int32_t relu, float* out, int32_t ldo, void* stream) {
   if (!x || !w || !out || rows < 0 || k <= 0 || n <= 0 || ldx < k || ldw < k || ldo < n)
     return failw(GW_E_BADARG, "gw_linear_forward: bad arguments");
   if (rows == 0) return GW_OK;
-  const int64_t mb = (rows + 127) / 128;
-  if (rows >= ((int64_t)1 << 31)) return failw(GW_E_UNSUPPORTED, "gw_linear_forward: row count exceeds int32");
-  const dim3 grid((unsigned)mb, (unsigned)((n + 127) / 128));
-  const bool aligned = k % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0;
-  if (aligned)
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (int)rows, n, k, x, ldx, w, ldw, bias, relu, out, ldo);
-  else
-    hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (int)rows, n, k, x, ldx, w, ldw, bias, relu, out, ldo);
-  return check_launch("gemm_nt_kernel launch");
+  Addends ga = {};
+  ga.rows_per_batch = 1;
+  return linear_launch(rows, k, n, x, ldx, w, ldw, bias, relu, out, ldo, ga, stream);
+}
+
+int gw_linear_gather_forward(int64_t rows, int32_t rows_per_batch, int32_t k, int32_t n, const float* x, int32_t ldx, const float* w,
+                             int32_t ldw, const float* bias, int32_t n_add, const float* const* add_table, const int32_t* const* add_idx,
+                             const int32_t* add_ld, const int32_t* add_rows_pb, int32_t relu, float* out, int32_t ldo, void* stream) {
+  if (!out || rows < 0 || k < 0 || n <= 0 || ldo < n || n_add < 0 || n_add > 3 || rows_per_batch <= 0 || (k == 0 && n_add == 0) ||
+      (k > 0 && (!x || !w || ldx < k || ldw < k)) || (n_add > 0 && (!add_table || !add_idx || !add_ld || !add_rows_pb)))
+    return failw(GW_E_BADARG, "gw_linear_gather_forward: bad arguments");
+  if (rows == 0) return GW_OK;
+  Addends ga = {};
+  ga.n = n_add;
+  ga.rows_per_batch = rows_per_batch;
+  for (int a = 0; a < n_add; ++a) {
+    if (!add_table[a] || add_ld[a] < n || add_rows_pb[a] < 0) return failw(GW_E_BADARG, "gw_linear_gather_forward: bad addend");
+    ga.table[a] = add_table[a];
+    ga.idx[a] = add_idx[a];
+    ga.ld[a] = add_ld[a];
+    ga.rows_pb[a] = add_rows_pb[a];
+  }
+  return linear_launch(rows, k, n, x, ldx, w, ldw, bias, relu, out, ldo, ga, stream);
 }
 
 int gw_layernorm_forward(int64_t rows, int32_t width, const float* y, int32_t ld_y, const float* gamma, const float* beta,
-                         const float* res, int32_t ld_res, float* out, int32_t ld_out, void* stream) {
-  if (!y || !gamma || !beta || !out || rows < 0 || width <= 0 || ld_y < width || ld_out < width || (res && ld_res < width))
+                         const float* res, int32_t ld_res, int64_t res_period, float* out, int32_t ld_out, void* stream) {
+  if (!y || !gamma || !beta || !out || rows < 0 || width <= 0 || ld_y < width || ld_out < width || (res && ld_res < width) || res_period < 0)
     return failw(GW_E_BADARG, "gw_layernorm_forward: bad arguments");
   if (width > 4096) return failw(GW_E_UNSUPPORTED, "gw_layernorm_forward: widths above 4096 are not implemented");
   if (rows == 0) return GW_OK;
   const dim3 grid((unsigned)((rows + 3) / 4));
   by_width(width, [&](auto nj) {
     hipLaunchKernelGGL(ln_fwd_wide_kernel<decltype(nj)::value>, grid, dim3(256), 0, (hipStream_t)stream, rows, width, y, ld_y, gamma, beta,
-                       res, ld_res, out, ld_out);
+                       res, ld_res, res_period, out, ld_out);
     return 0;
   });
   return check_launch("ln_fwd_wide_kernel launch");

@@ -3,16 +3,16 @@
 The fused HIP kernels (``csrc/gw_kernels.hip``, ``gw_edge.hip``, ``gw_edge16.hip``) are built around 256-float rows; the
 reference's own training script, however, constructs the forecaster with node / edge / hidden widths of 1024
 (``train/run.py:493-497``).  Such models run here: the same modules, the same ``state_dict`` keys, every ``nn.Linear`` one
-fp32-MFMA GEMM with bias and ReLU in its epilogue (``gw_linear_forward``), LayerNorm, the ``x[row]`` / ``x[col]`` gathers
-(MetaLayer, graph_net_block.py:221-228) and the ``scatter_sum`` (:188) one kernel each at any width (``csrc/gw_wide.hip``),
-forward and backward.  Nothing is fused across layers and the ``cat`` of graph_net_block.py:133 / :189 is materialised as in
-the reference: this is the coverage path, not the tuned one.
+fp32-MFMA GEMM with bias and ReLU in its epilogue (``gw_linear_forward``), LayerNorm (+ residual) and the ``scatter_sum``
+(graph_net_block.py:188) one kernel each at any width (``csrc/gw_wide.hip``), forward and backward.  Nothing is fused across
+layers: this is the coverage path, not the tuned one.
 
-What is kept from the native path: one shared destination-sorted graph plan for all batch elements (no replicated graph),
-batch-independent embeddings computed once, layer-1 weight columns of operands that are identically zero (the decoder's
-grid rows, assimilator_decoder.py:84,190-192) skipped, and segment sums that walk a CSR in one fixed order (bitwise
-reproducible, no atomics).  PyTorch moves data (``cat``, slices, views) and links the autograd nodes; no torch arithmetic
-op touches an activation.
+What is kept from the native design: one shared destination-sorted graph plan for all batch elements (no replicated graph),
+batch-independent embeddings computed once, the LAYER-1 SPLIT - the ``cat`` of graph_net_block.py:133 / :189 is never formed:
+``cat[x_s, x_d, e] . W1^T = (x_s . Ws^T)[src] + (x_d . Wd^T)[dst] + e . We^T``, node products made once per node and gathered in
+the epilogue of the edge-level GEMM (``gw_linear_gather_forward``), the decoder's zero grid rows dropped - and segment sums
+that walk a CSR in one fixed order (bitwise reproducible, no atomics).  PyTorch moves data (slices, views) and links the
+autograd nodes; no torch arithmetic op touches an activation.
 """
 from __future__ import annotations
 
@@ -70,7 +70,39 @@ def linear_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
-def layernorm_forward(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, res: Optional[torch.Tensor]) -> torch.Tensor:
+def linear_gather_forward(x: Optional[torch.Tensor], w: Optional[torch.Tensor], bias: Optional[torch.Tensor], relu: bool,
+                          adds: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], int]], rows: int, rows_per_batch: int) -> torch.Tensor:
+    """act(x @ w.T + bias + sum_i table_i[b * rows_pb_i + idx_i[k]]) for row m = (b, k) = divmod(m, rows_per_batch); ``adds`` =
+    [(table, idx or None, rows_pb)], at most three.  ``x`` / ``w`` None: no product (bias + gathered rows only)."""
+    import ctypes
+
+    n = int(adds[0][0].shape[1]) if w is None else int(w.shape[0])
+    k = 0
+    if w is not None:
+        x, w = _rows(x, "x"), _rows(w, "weight")
+        k = int(x.shape[1])
+        if int(w.shape[1]) != k or int(x.shape[0]) != rows:
+            raise RuntimeError("graph_weather_amd: Linear operand shapes do not match")
+    na = len(adds)
+    tabs = [_rows(t, "addend") for t, _, _ in adds]
+    dev = tabs[0].device if na else x.device
+    out = torch.empty((rows, n), dtype=torch.float32, device=dev)
+    tp = (ctypes.c_void_p * max(na, 1))(*[t.data_ptr() for t in tabs])
+    ip = (ctypes.c_void_p * max(na, 1))(*[None if i is None else i.data_ptr() for _, i, _ in adds])
+    lp = (ctypes.c_int32 * max(na, 1))(*[_ld(t) for t in tabs])
+    rp = (ctypes.c_int32 * max(na, 1))(*[int(r) for _, _, r in adds])
+    with on_device_of(out):
+        _lib.check(_L().gw_linear_gather_forward(rows, max(1, rows_per_batch), k, n, None if w is None else x.data_ptr(),
+                                                 0 if w is None else _ld(x), None if w is None else w.data_ptr(),
+                                                 0 if w is None else _ld(w), None if bias is None else bias.contiguous().data_ptr(), na,
+                                                 tp, ip, lp, rp, 1 if relu else 0, out.data_ptr(), n, _st(out)),
+                   "gw_linear_gather_forward")
+    return out
+
+
+def layernorm_forward(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, res: Optional[torch.Tensor],
+                      res_period: int = 0) -> torch.Tensor:
+    """``res_period`` > 0: the residual rows are shared by the batch (row m adds res[m % res_period])."""
     y = _rows(y, "y")
     rows, width = int(y.shape[0]), int(y.shape[1])
     if res is not None:
@@ -78,8 +110,8 @@ def layernorm_forward(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     out = torch.empty((rows, width), dtype=torch.float32, device=y.device)
     with on_device_of(out):
         _lib.check(_L().gw_layernorm_forward(rows, width, y.data_ptr(), _ld(y), gamma.contiguous().data_ptr(), beta.contiguous().data_ptr(),
-                                             None if res is None else res.data_ptr(), 0 if res is None else _ld(res), out.data_ptr(),
-                                             width, _st(out)), "gw_layernorm_forward")
+                                             None if res is None else res.data_ptr(), 0 if res is None else _ld(res), int(res_period),
+                                             out.data_ptr(), width, _st(out)), "gw_layernorm_forward")
     return out
 
 
@@ -117,12 +149,15 @@ def segment_sum_rows(rows: torch.Tensor, rows_pb_in: int, batch: int, batch_out:
     return out
 
 
-def _relu_mask(dh: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    dh, h = _rows(dh, "dh"), _rows(h, "h")
+def _relu_mask(dh: torch.Tensor, h: torch.Tensor, db: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dz = dh * (h > 0); ``db`` (zeroed by the caller) += column sums of dz."""
+    dh = _rows(dh, "dh")
+    h = None if h is None else _rows(h, "h")
     rows, width = int(dh.shape[0]), int(dh.shape[1])
     dz = torch.empty((rows, width), dtype=torch.float32, device=dh.device)
     with on_device_of(dz):
-        _lib.check(_L().gw_relu_backward(rows, width, dh.data_ptr(), _ld(dh), h.data_ptr(), _ld(h), dz.data_ptr(), width, None, _st(dz)),
+        _lib.check(_L().gw_relu_backward(rows, width, dh.data_ptr(), _ld(dh), None if h is None else h.data_ptr(),
+                                         0 if h is None else _ld(h), dz.data_ptr(), width, None if db is None else db.data_ptr(), _st(dz)),
                    "gw_relu_backward")
     return dz
 
@@ -158,11 +193,60 @@ class _Linear(Function):
         return dx, dw, db, None
 
 
-class _LayerNorm(Function):
+class _LinearGather(Function):
+    """Linear (+ ReLU) with gathered row tables added before the activation (``linear_gather_forward``): the layer-1 split
+    cat[x_s, x_d, e] . W1^T = (x_s . Ws^T)[src] + (x_d . Wd^T)[dst] + e . We^T of graph_net_block.py:131-134 / :189.
+    ``meta[i]`` = (idx, rows_pb, (perm, ptr)): how table i is read and the CSR that groups the reading rows by table row (for its
+    gradient, a segment sum of dz).  Backward of the product part as in ``_Linear``."""
+
     @staticmethod
-    def forward(ctx, y, gamma, beta, res):
-        out = layernorm_forward(y, gamma, beta, res)
-        ctx.has_res = res is not None
+    def forward(ctx, x, w, b, relu: bool, rows: int, rows_per_batch: int, meta, *tables):
+        adds = [(t, m[0], m[1]) for t, m in zip(tables, meta)]
+        out = linear_gather_forward(x, w, b, relu, adds, rows, rows_per_batch)
+        ctx.relu, ctx.rows, ctx.rpb, ctx.meta = relu, rows, rows_per_batch, meta
+        ctx.has_b = b is not None
+        ctx.save_for_backward(x, w, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .autograd import gemm_tn_acc
+
+        x, w, out = ctx.saved_tensors
+        n = int(dout.shape[1])
+        db = torch.zeros((n,), dtype=torch.float32, device=dout.device) if ctx.has_b else None
+        if w is None:  # no product: the bias gradient rides on the mask kernel
+            dz = _relu_mask(dout, out if ctx.relu else None, db) if (ctx.relu or db is not None) else _rows(dout, "dout")
+        else:
+            dz = _relu_mask(dout, out) if ctx.relu else _rows(dout, "dout")
+        dx = dw = None
+        if w is not None:
+            if ctx.needs_input_grad[0]:
+                dx = linear_forward(dz, w.detach().t().contiguous(), None, False)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                dw = torch.zeros_like(w)
+                with on_device_of(dw):
+                    gemm_tn_acc(dz, _rows(x, "x"), dw, colsum=db)
+        batch = ctx.rows // ctx.rpb
+        dts = []
+        for i, (idx, rows_pb, (perm, ptr)) in enumerate(ctx.meta):
+            if not ctx.needs_input_grad[7 + i]:
+                dts.append(None)
+                continue
+            if idx is None and rows_pb > 0:  # read row by row: the gradient is dz itself
+                dts.append(dz)
+            else:
+                dts.append(segment_sum_rows(dz, ctx.rpb, batch, batch if rows_pb > 0 else 1, int(ptr.numel()) - 1, ptr, perm))
+        return (dx, dw, db, None, None, None, None, *dts)
+
+
+class _LayerNorm(Function):
+    """LayerNorm (+ residual).  ``res_period`` > 0: residual rows shared by the batch - their gradient is summed over it."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, res, res_period: int = 0):
+        out = layernorm_forward(y, gamma, beta, res, res_period)
+        ctx.has_res, ctx.res_period = res is not None, int(res_period)
         ctx.save_for_backward(y, gamma)
         return out
 
@@ -175,7 +259,15 @@ class _LayerNorm(Function):
         dn = dout.contiguous()
         with on_device_of(dn):
             dy = layernorm_backward(dn, _rows(y, "y"), gamma.contiguous(), dgamma, dbeta)
-        return dy, dgamma, dbeta, (dout if ctx.has_res else None)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            if ctx.res_period > 0:
+                p = ctx.res_period
+                ident = torch.arange(p + 1, dtype=torch.int32, device=dn.device)
+                dres = segment_sum_rows(dn, p, int(dn.shape[0]) // p, 1, p, ident, None)
+            else:
+                dres = dout
+        return dy, dgamma, dbeta, dres, None
 
 
 class _Add(Function):
@@ -228,12 +320,6 @@ def _ident_ptr(plan: GraphPlan, n: int) -> torch.Tensor:
     return cache[n]
 
 
-def _broadcast(table: torch.Tensor, batch: int, plan: GraphPlan) -> torch.Tensor:
-    """A batch-shared table repeated for every batch element (its gradient is summed over the batch)."""
-    n = int(table.shape[0])
-    return _Gather.apply(table, None, batch, 0, n, (None, _ident_ptr(plan, n)))
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # MLP, block, encoder / processor / decoder
 # ---------------------------------------------------------------------------------------------------------------------
@@ -245,27 +331,41 @@ def is_wide(*mlps) -> bool:
     return False
 
 
-def mlp_rows(mlp, x2: torch.Tensor, residual: Optional[torch.Tensor] = None,
-             w1_cols: Optional[Sequence[Tuple[int, int]]] = None) -> torch.Tensor:
-    """graph_net_block.py:45-61,63-77 on rows: [rows, in] -> [rows, out_dim] (+ residual).  ``w1_cols``: the column ranges of the
-    first Linear that ``x2`` feeds, when an operand of the reference's ``cat`` is identically zero and is left out."""
+def _check_mlp(mlp) -> None:
     if mlp.compute_dtype != torch.float32:
         raise NotImplementedError("graph_weather_amd: bf16 matrix products exist for widths up to 256; wider models run in fp32")
-    lin, norm = mlp._linears(), mlp._norm()
+    norm = mlp._norm()
     if norm is not None and abs(norm.eps - 1e-5) > 0:
         raise RuntimeError("graph_weather_amd: LayerNorm eps must be 1e-5")
-    if not lin[0].weight.is_cuda:
+    if not mlp._linears()[0].weight.is_cuda:
         raise RuntimeError("graph_weather_amd: module parameters must be on a HIP device (no CPU path exists)")
 
+
+def _mlp_tail(mlp, h1: torch.Tensor, residual: Optional[torch.Tensor], res_period: int = 0) -> torch.Tensor:
+    """Everything of an MLP behind its first Linear + ReLU (``h1``): hidden layers, last Linear, [LayerNorm], + residual
+    (``res_period`` > 0: residual rows shared by the batch)."""
+    lin, norm = mlp._linears(), mlp._norm()
+    h = h1
+    for m in lin[1:-1]:
+        h = _Linear.apply(h, m.weight, m.bias, True)
+    y = _Linear.apply(h, lin[-1].weight, lin[-1].bias, False)
+    if norm is not None:
+        return _LayerNorm.apply(y, norm.weight, norm.bias, residual, res_period)
+    if residual is None:
+        return y
+    if res_period > 0:
+        ident = torch.arange(res_period + 1, dtype=torch.int32, device=y.device)
+        residual = _Gather.apply(residual, None, int(y.shape[0]) // res_period, 0, res_period, (None, ident))
+    return _Add.apply(y, residual)
+
+
+def mlp_rows(mlp, x2: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """graph_net_block.py:45-61,63-77 on rows: [rows, in] -> [rows, out_dim] (+ residual)."""
+    _check_mlp(mlp)
+    l0 = mlp._linears()[0]
+
     def run(x_, res_):
-        w0 = lin[0].weight if w1_cols is None else torch.cat([lin[0].weight[:, lo:hi] for lo, hi in w1_cols], dim=1)
-        h = _Linear.apply(x_, w0, lin[0].bias, True)
-        for m in lin[1:-1]:
-            h = _Linear.apply(h, m.weight, m.bias, True)
-        y = _Linear.apply(h, lin[-1].weight, lin[-1].bias, False)
-        if norm is not None:
-            return _LayerNorm.apply(y, norm.weight, norm.bias, res_)
-        return y if res_ is None else _Add.apply(y, res_)
+        return _mlp_tail(mlp, _Linear.apply(x_, l0.weight, l0.bias, True), res_)
 
     if mlp.use_checkpointing and torch.is_grad_enabled():  # graph_net_block.py:73-74
         from torch.utils.checkpoint import checkpoint
@@ -279,25 +379,45 @@ def block(blk, plan: GraphPlan, batch: int, x_src: torch.Tensor, src_rows_pb: in
     """One message-passing block (MetaLayer, graph_net_block.py:221-228) on the shared destination-sorted plan.
     ``x_src`` [batch * n_src, Dn] (``src_rows_pb`` = n_src) or one shared [n_src, Dn] (0); ``x_dst`` likewise, or None for
     destination rows that are all zero; ``e`` [batch * E, De] or shared [E, De] (``e_rows_pb`` 0).  Returns (x', e') for the
-    destination rows of every batch element."""
+    destination rows of every batch element.
+
+    The ``cat`` of :133 / :189 is never formed: layer 1 is split as in the fused kernels - cat[x_s, x_d, e] . W1^T =
+    (x_s . Ws^T)[src] + (x_d . Wd^T)[dst] + e . We^T - so the node products are made once per node (an edge-level product costs
+    ~7x as much) and gathered in the epilogue of the edge-level product (``_LinearGather``); with batch-shared edge features
+    that product is per edge of ONE sample too and layer 1 has no edge-level matrix work at all."""
     E, nd = plan.num_edges, plan.n_dst
     emlp, nmlp = blk.edge_model.edge_mlp, blk.node_model.node_mlp
+    _check_mlp(emlp)
+    _check_mlp(nmlp)
     dn, de = int(x_src.shape[1]), int(e.shape[1])
-    xs = _Gather.apply(x_src, plan.src, batch, src_rows_pb, E, plan.src_sorted())
-    parts, cols = [xs], [(0, dn)]
+    l0 = emlp._linears()[0]
+    w0, b0 = l0.weight, l0.bias
+    if int(w0.shape[1]) != 2 * dn + de:
+        raise RuntimeError("graph_weather_amd: edge MLP expects %d input features, got 2 x %d + %d" % (int(w0.shape[1]), dn, de))
+    tables = [_Linear.apply(x_src, w0[:, :dn], None, False)]
+    metas = [(plan.src, src_rows_pb, plan.src_sorted())]
     if x_dst is not None:
-        parts.append(_Gather.apply(x_dst, plan.dst, batch, dst_rows_pb, E, (None, plan.dst_ptr())))
-        cols.append((dn, 2 * dn))
-    e_b = e if e_rows_pb > 0 else _broadcast(e, batch, plan)
-    parts.append(e_b)
-    cols.append((2 * dn, 2 * dn + de))
-    e_new = mlp_rows(emlp, torch.cat(parts, dim=1), residual=e_b, w1_cols=None if x_dst is not None else cols)   # :131-137
-    agg = _SegmentSum.apply(e_new, plan, batch)                                                                   # :188
-    if x_dst is not None:
-        xd = x_dst if dst_rows_pb > 0 else _broadcast(x_dst, batch, plan)
-        x_new = mlp_rows(nmlp, torch.cat([xd, agg], dim=1), residual=xd)                                          # :189-191
+        tables.append(_Linear.apply(x_dst, w0[:, dn:2 * dn], None, False))
+        metas.append((plan.dst, dst_rows_pb, (None, plan.dst_ptr())))
+    we = w0[:, 2 * dn:]
+    if e_rows_pb == 0:
+        tables.append(_Linear.apply(e, we, None, False))
+        metas.append((None, 0, (None, _ident_ptr(plan, E))))
+        h1 = _LinearGather.apply(None, None, b0, True, batch * E, E, tuple(metas), *tables)
     else:
-        x_new = mlp_rows(nmlp, agg, w1_cols=[(dn, dn + de)])
+        h1 = _LinearGather.apply(e, we, b0, True, batch * E, E, tuple(metas), *tables)
+    e_new = _mlp_tail(emlp, h1, e, E if e_rows_pb == 0 else 0)                                     # :131-137
+    agg = _SegmentSum.apply(e_new, plan, batch)                                                   # :188
+    n0 = nmlp._linears()[0]
+    wn, bn = n0.weight, n0.bias
+    if int(wn.shape[1]) != dn + de:
+        raise RuntimeError("graph_weather_amd: node MLP expects %d input features, got %d + %d" % (int(wn.shape[1]), dn, de))
+    if x_dst is not None:                                                                         # :189-191
+        px = _Linear.apply(x_dst, wn[:, :dn], None, False)
+        h1n = _LinearGather.apply(agg, wn[:, dn:], bn, True, batch * nd, nd, ((None, dst_rows_pb, (None, _ident_ptr(plan, nd))),), px)
+        x_new = _mlp_tail(nmlp, h1n, x_dst, nd if dst_rows_pb == 0 else 0)
+    else:
+        x_new = _mlp_tail(nmlp, _Linear.apply(agg, wn[:, dn:], bn, True), None)
     return x_new, e_new
 
 

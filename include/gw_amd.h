@@ -212,8 +212,7 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
                 float* c, int32_t ldc, float* colsum_a /* TN only, may be NULL: colsum_a[m] += sum_k A[k][m] (bias gradient) */,
                 void* stream);
 /* nn.ReLU backward fused with the nn.Linear bias gradient: dz = dh * (h > 0) (h NULL: dz = dh), db[c] += sum_r dz[r][c].
- * dz may alias dh or be NULL (bias gradient only); db may be NULL.  width > 256 (wide models): dz required, db must be NULL
- * (their bias gradient is colsum_a of the weight-gradient GEMM). */
+ * dz may alias dh or be NULL (bias gradient only); db may be NULL.  Any width (above 256: wide models, csrc/gw_wide.hip). */
 int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh, const float* h, int32_t ld_h, float* dz,
                      int32_t ld_dz, float* db, void* stream);
 /* nn.LayerNorm(width, eps 1e-5) backward from the saved pre-norm rows y: dy; dgamma += , dbeta += (may be NULL).
@@ -261,9 +260,18 @@ int gw_nudging_backward(int64_t rows, int32_t feat, int32_t hidden, const float*
  * stride ldw); bias may be NULL; relu 0 / 1.  fp32 MFMA, fp32 accumulate. */
 int gw_linear_forward(int64_t rows, int32_t k, int32_t n, const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias,
                       int32_t relu, float* out, int32_t ldo, void* stream);
-/* nn.LayerNorm(width, eps 1e-5, affine) (+ res, the residual add of graph_net_block.py:135/:191); width <= 4096. */
+/* The same Linear with up to three row tables added before the activation:
+ *   out[m] = act(x[m] . w^T + bias + sum_i table_i[b * rows_pb_i + idx_i[k]]),  (b, k) = (m / rows_per_batch, m % rows_per_batch)
+ * (idx_i NULL: k itself; rows_pb_i 0: table shared by the batch).  This is the layer-1 split of the fused kernels for wide
+ * models - cat[x_s, x_d, e] . W1^T = (x_s . Ws^T)[src] + (x_d . Wd^T)[dst] + e . We^T: node products are made once per node and
+ * gathered per edge in the epilogue of the edge-level product.  k == 0 (x, w NULL): no product, only bias + gathered rows. */
+int gw_linear_gather_forward(int64_t rows, int32_t rows_per_batch, int32_t k, int32_t n, const float* x, int32_t ldx, const float* w,
+                             int32_t ldw, const float* bias, int32_t n_add, const float* const* add_table, const int32_t* const* add_idx,
+                             const int32_t* add_ld, const int32_t* add_rows_pb, int32_t relu, float* out, int32_t ldo, void* stream);
+/* nn.LayerNorm(width, eps 1e-5, affine) (+ res, the residual add of graph_net_block.py:135/:191; res_period > 0: residual rows
+ * shared by the batch, row m reads res[m % res_period]); width <= 4096. */
 int gw_layernorm_forward(int64_t rows, int32_t width, const float* y, int32_t ld_y, const float* gamma, const float* beta,
-                         const float* res, int32_t ld_res, float* out, int32_t ld_out, void* stream);
+                         const float* res, int32_t ld_res, int64_t res_period, float* out, int32_t ld_out, void* stream);
 /* out = a + b (residual add behind an MLP without norm). */
 int gw_add_rows(int64_t rows, int32_t width, const float* a, int32_t lda, const float* b, int32_t ldb, float* out, int32_t ldo,
                 void* stream);

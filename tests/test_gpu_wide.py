@@ -59,12 +59,54 @@ def test_layernorm_forward_and_backward_against_torch(rows, width, res):
     ref.backward(dout.double())
     yd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (y, g, b))
     rd = None if r is None else r.to(DEV).requires_grad_(True)
-    out = wide._LayerNorm.apply(yd, gd, bd, rd)
+    out = wide._LayerNorm.apply(yd, gd, bd, rd, 0)
     out.backward(dout.to(DEV))
     assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-5
     assert _rel(yd.grad, yr.grad) < 1e-4 and _rel(gd.grad, gr.grad) < 1e-4 and _rel(bd.grad, br.grad) < 1e-4
     if rd is not None:
         assert torch.equal(rd.grad.cpu(), dout)
+
+
+def test_layernorm_with_a_residual_shared_by_the_batch():
+    rs = np.random.RandomState(12)
+    B, E, W = 3, 50, 300
+    y, g, b, r, dout = _t(rs, B * E, W), 1 + _t(rs, W, scale=0.1), _t(rs, W, scale=0.1), _t(rs, E, W), _t(rs, B * E, W)
+    yr, rr = y.double().requires_grad_(True), r.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(yr, (W,), g.double(), b.double(), 1e-5) + rr.repeat(B, 1)
+    ref.backward(dout.double())
+    yd, rd = y.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    out = wide._LayerNorm.apply(yd, g.to(DEV), b.to(DEV), rd, E)
+    out.backward(dout.to(DEV))
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-5
+    assert _rel(yd.grad, yr.grad) < 1e-4 and _rel(rd.grad, rr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("with_product", [True, False])
+def test_linear_with_gathered_addends_forward_and_backward(with_product):
+    """relu(e . We^T + b + Ps[src] + Pd[dst] (+ Pe[k])): per-sample, batch-shared and identity-indexed tables; k = 0 form."""
+    rs = np.random.RandomState(21)
+    B, n_src, n_dst, E, K, N = 3, 40, 25, 333, 200, 300
+    plan = plan_from_coo(rs.randint(0, n_src, size=E), np.where(rs.rand(E) < 0.3, 7, rs.randint(0, n_dst, size=E)), n_src, n_dst).to(DEV)
+    s, d = plan.src.long().cpu(), plan.dst.long().cpu()
+    x, w, b = _t(rs, B * E, K), _t(rs, N, K, scale=1 / np.sqrt(K)), _t(rs, N)
+    ps, pd, pe, dout = _t(rs, B * n_src, N), _t(rs, n_dst, N), _t(rs, E, N), _t(rs, B * E, N)
+    refs = [t.double().requires_grad_(True) for t in (x, w, b, ps, pd, pe)]
+    xr, wr, br, psr, pdr, per = refs
+    z = br + psr.reshape(B, n_src, N)[:, s].reshape(B * E, N) + pdr[d].repeat(B, 1) + per.repeat(B, 1)
+    if with_product:
+        z = z + xr @ wr.t()
+    ref = torch.relu(z)
+    ref.backward(dout.double())
+    devs = [t.to(DEV).requires_grad_(True) for t in (x, w, b, ps, pd, pe)]
+    xd, wd, bd, psd, pdd, ped = devs
+    ident = torch.arange(E + 1, dtype=torch.int32, device=DEV)
+    meta = ((plan.src, n_src, plan.src_sorted()), (plan.dst, 0, (None, plan.dst_ptr())), (None, 0, (None, ident)))
+    out = wide._LinearGather.apply(xd if with_product else None, wd if with_product else None, bd, True, B * E, E, meta, psd, pdd, ped)
+    out.backward(dout.to(DEV))
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() / ref.abs().max().item() < 2e-6
+    pairs = [(bd, br), (psd, psr), (pdd, pdr), (ped, per)] + ([(xd, xr), (wd, wr)] if with_product else [])
+    for got, want in pairs:
+        assert _rel(got.grad, want.grad) < 1e-4
 
 
 def test_gather_and_segment_sum_at_any_width_and_their_gradients():
