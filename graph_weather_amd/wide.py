@@ -172,7 +172,7 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, relu: bool):
         out = linear_forward(x, w, b, relu)
-        ctx.relu = relu
+        ctx.relu, ctx.has_b = relu, b is not None
         ctx.save_for_backward(x, w, out if relu else None)
         return out
 
@@ -185,9 +185,9 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = linear_forward(dz, w.detach().t().contiguous(), None, False)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             dw = torch.zeros_like(w)
-            db = torch.zeros((int(w.shape[0]),), dtype=torch.float32, device=w.device)
+            db = torch.zeros((int(w.shape[0]),), dtype=torch.float32, device=w.device) if ctx.has_b else None
             with on_device_of(dw):
                 gemm_tn_acc(dz, _rows(x, "x"), dw, colsum=db)
         return dx, dw, db, None
