@@ -216,6 +216,7 @@ def run_extra(name, dev, steps, warmup):
     from graph_weather_amd.utils import seeded_features
 
     cfg = CONFIGS[name]
+    torch.cuda.init()
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     model, lat_lons = build_model(cfg, dev)
@@ -252,6 +253,7 @@ def run_wide(dev, steps=3, warmup=2):
     from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features
 
     W = 1024
+    torch.cuda.init()
     torch.cuda.reset_peak_memory_stats(dev)
     lat_lons = regular_lat_lons(1.0)
     model = gw.GraphWeatherForecaster(lat_lons, edge_dim=W, hidden_dim_processor_edge=W, node_dim=W, hidden_dim_processor_node=W,

@@ -374,8 +374,26 @@ def mlp_rows(mlp, x2: torch.Tensor, residual: Optional[torch.Tensor] = None) -> 
     return run(x2, residual)
 
 
+def _cached(owner, name: str, params, fn, of: Optional[torch.Tensor] = None):
+    """A batch-independent tensor of ``owner`` (an embedding, a layer-1 product of one): kept per parameter version while autograd
+    is off; under autograd it is part of the graph and recomputed every step (the reference recomputes it on every forward).
+    ``of``: an input tensor the value also depends on - part of the key, and held by the entry so that its address cannot be
+    reused by another tensor while the entry lives."""
+    params = list(params)
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or (of is not None and of.requires_grad)):
+        return fn()
+    from .layers import _ver, _version_key
+
+    cache = owner.__dict__.setdefault("_wide_cache", {})
+    key = _version_key(params) + (() if of is None else ((of.data_ptr(), _ver(of), tuple(of.shape)),))
+    hit = cache.get(name)
+    if hit is None or hit[0] != key or hit[2] is not of:
+        cache[name] = (key, fn(), of)
+    return cache[name][1]
+
+
 def block(blk, plan: GraphPlan, batch: int, x_src: torch.Tensor, src_rows_pb: int, x_dst: Optional[torch.Tensor], dst_rows_pb: int,
-          e: torch.Tensor, e_rows_pb: int):
+          e: torch.Tensor, e_rows_pb: int, static=None):
     """One message-passing block (MetaLayer, graph_net_block.py:221-228) on the shared destination-sorted plan.
     ``x_src`` [batch * n_src, Dn] (``src_rows_pb`` = n_src) or one shared [n_src, Dn] (0); ``x_dst`` likewise, or None for
     destination rows that are all zero; ``e`` [batch * E, De] or shared [E, De] (``e_rows_pb`` 0).  Returns (x', e') for the
@@ -384,7 +402,10 @@ def block(blk, plan: GraphPlan, batch: int, x_src: torch.Tensor, src_rows_pb: in
     The ``cat`` of :133 / :189 is never formed: layer 1 is split as in the fused kernels - cat[x_s, x_d, e] . W1^T =
     (x_s . Ws^T)[src] + (x_d . Wd^T)[dst] + e . We^T - so the node products are made once per node (an edge-level product costs
     ~7x as much) and gathered in the epilogue of the edge-level product (``_LinearGather``); with batch-shared edge features
-    that product is per edge of ONE sample too and layer 1 has no edge-level matrix work at all."""
+    that product is per edge of ONE sample too and layer 1 has no edge-level matrix work at all.  ``static(name, fn)``: the
+    caller's cache for products of batch-shared operands (they only change with the weights)."""
+    if static is None:
+        static = lambda name, fn: fn()  # noqa: E731
     E, nd = plan.num_edges, plan.n_dst
     emlp, nmlp = blk.edge_model.edge_mlp, blk.node_model.node_mlp
     _check_mlp(emlp)
@@ -397,11 +418,12 @@ def block(blk, plan: GraphPlan, batch: int, x_src: torch.Tensor, src_rows_pb: in
     tables = [_Linear.apply(x_src, w0[:, :dn], None, False)]
     metas = [(plan.src, src_rows_pb, plan.src_sorted())]
     if x_dst is not None:
-        tables.append(_Linear.apply(x_dst, w0[:, dn:2 * dn], None, False))
+        pd = lambda: _Linear.apply(x_dst, w0[:, dn:2 * dn], None, False)  # noqa: E731
+        tables.append(static("pd", pd) if dst_rows_pb == 0 else pd())
         metas.append((plan.dst, dst_rows_pb, (None, plan.dst_ptr())))
     we = w0[:, 2 * dn:]
     if e_rows_pb == 0:
-        tables.append(_Linear.apply(e, we, None, False))
+        tables.append(static("pe", lambda: _Linear.apply(e, we, None, False)))
         metas.append((None, 0, (None, _ident_ptr(plan, E))))
         h1 = _LinearGather.apply(None, None, b0, True, batch * E, E, tuple(metas), *tables)
     else:
@@ -413,7 +435,8 @@ def block(blk, plan: GraphPlan, batch: int, x_src: torch.Tensor, src_rows_pb: in
     if int(wn.shape[1]) != dn + de:
         raise RuntimeError("graph_weather_amd: node MLP expects %d input features, got %d + %d" % (int(wn.shape[1]), dn, de))
     if x_dst is not None:                                                                         # :189-191
-        px = _Linear.apply(x_dst, wn[:, :dn], None, False)
+        pxf = lambda: _Linear.apply(x_dst, wn[:, :dn], None, False)  # noqa: E731
+        px = static("px", pxf) if dst_rows_pb == 0 else pxf()
         h1n = _LinearGather.apply(agg, wn[:, dn:], bn, True, batch * nd, nd, ((None, dst_rows_pb, (None, _ident_ptr(plan, nd))),), px)
         x_new = _mlp_tail(nmlp, h1n, x_dst, nd if dst_rows_pb == 0 else 0)
     else:
@@ -436,7 +459,11 @@ def run_blocks(gp, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: 
 
     def span(lo, hi, x_, e_, shared):
         for i in range(lo, hi):
-            x_, e_ = block(gp.blocks[i], plan, batch, x_, n, x_, n, e_, 0 if shared else E)
+            blk = gp.blocks[i]
+            static = None
+            if shared:  # We . e of batch-shared edge features: per weight version (and per tensor e) in inference
+                static = lambda name, fn, blk=blk, e_in=e_, i=i: _cached(gp, "%s%d" % (name, i), blk.parameters(), fn, of=e_in)  # noqa: E731
+            x_, e_ = block(blk, plan, batch, x_, n, x_, n, e_, 0 if shared else E, static=static)
             shared = False
         return x_, e_
 
@@ -473,16 +500,19 @@ def encode(enc, features: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("features must be [B, %d, input_dim]" % enc.num_latlons)
     B, G, F = (int(s) for s in features.shape)
     enc_plan, _ = enc._plans(features.device)
+    ps = list(enc.parameters())
     xg = mlp_rows(enc.node_encoder, features.contiguous().reshape(B * G, F))
-    xm = mlp_rows(enc.node_encoder, enc.h3_nodes)            # batch independent (encoder.py:199-205 repeats it per sample)
-    e = mlp_rows(enc.edge_encoder, enc_plan.edge_attr)
-    x, _ = block(enc.graph_processor.blocks[0], enc_plan, B, xg, G, xm, 0, e, 0)
+    # batch independent (encoder.py:199-205 repeats them per sample): mesh-node and edge embeddings, their layer-1 products
+    xm = _cached(enc, "xm", ps, lambda: mlp_rows(enc.node_encoder, enc.h3_nodes))
+    e = _cached(enc, "e_enc", ps, lambda: mlp_rows(enc.edge_encoder, enc_plan.edge_attr))
+    x, _ = block(enc.graph_processor.blocks[0], enc_plan, B, xg, G, xm, 0, e, 0,
+                 static=lambda name, fn: _cached(enc, "enc_" + name, ps, fn))
     return x
 
 
 def latent_edges(enc, plan: GraphPlan) -> torch.Tensor:
     """latent_edge_encoder(attr) once, in destination-sorted order (encoder.py:235-241 repeats it B times)."""
-    return mlp_rows(enc.latent_edge_encoder, plan.edge_attr)
+    return _cached(enc, "e_lat", enc.latent_edge_encoder.parameters(), lambda: mlp_rows(enc.latent_edge_encoder, plan.edge_attr))
 
 
 def decode(dec, processor_features: torch.Tensor, batch_size: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -491,9 +521,11 @@ def decode(dec, processor_features: torch.Tensor, batch_size: int, residual: Opt
     if processor_features.shape[0] != B * M:
         raise RuntimeError("processor_features must have batch*num_h3 rows")
     plan = dec._plan(processor_features.device)
-    e = mlp_rows(dec.edge_encoder, plan.edge_attr)
+    ps = list(dec.edge_encoder.parameters()) + list(dec.graph_processor.parameters())
+    e = _cached(dec, "e_dec", ps, lambda: mlp_rows(dec.edge_encoder, plan.edge_attr))
     # grid rows are zeros (assimilator_decoder.py:84,190-192): no x_dst operand, node input [0 | agg], residual 0
-    xg, _ = block(dec.graph_processor.blocks[0], plan, B, processor_features.contiguous(), M, None, 0, e, 0)
+    xg, _ = block(dec.graph_processor.blocks[0], plan, B, processor_features.contiguous(), M, None, 0, e, 0,
+                  static=lambda name, fn: _cached(dec, "dec_" + name, ps, fn))
     res = None
     if residual is not None:
         if residual.dim() != 2 or residual.shape[0] != B * G or residual.shape[1] < dec.output_dim:

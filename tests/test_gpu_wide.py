@@ -234,6 +234,17 @@ def test_wide_forecaster_matches_oracle_forward_and_backward():
     assert torch.equal(y2, y)
     worst = {}
     _check_param_grads(model, ref, "", worst, bar=4e-3)
+    # inference caches of batch-independent embeddings / products follow the parameter versions
+    model.eval()
+    with torch.no_grad():
+        y_a = model(feats.to(DEV))
+        assert torch.equal(y_a, model(feats.to(DEV)))
+        for prm in (model.decoder.edge_encoder.model[0].weight, model.encoder.h3_nodes, model.processor.graph_processor.blocks[0].edge_model.edge_mlp.model[0].weight):
+            prm.add_(0.05)
+        y_b = model(feats.to(DEV))
+    assert (y_b - y_a).abs().max().item() > 1e-4
+    model.train()
+    _close(model(feats.to(DEV)).detach() - feats.to(DEV)[..., :20], y_b - feats.to(DEV)[..., :20], rel=1e-5, what="wide caches after a weight update")
     # no bf16 form of the wide path: loud
     with pytest.raises(NotImplementedError, match="bf16"):
         model.set_compute_dtype(torch.bfloat16)
