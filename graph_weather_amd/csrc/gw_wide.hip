@@ -31,7 +31,7 @@ int failw(int code, const char* msg) { return set_error(code, msg); }
 // Block = 4 waves, tile 128 (m) x 128 (n); wave (wm, wn) owns 64 x 64 = 4 x 4 MFMA tiles (v_mfma_f32_16x16x4_f32: fp32 in,
 // fp32 accumulate - an fmaf chain like the fused kernels).  Both operands are K-contiguous, so a 16-deep K chunk of each tile
 // (128 rows x 16 floats) is staged through LDS by coalesced 16-byte loads, double buffered through registers; the LDS row
-// stride of 20 floats puts the 16 rows x 4 k of one MFMA operand read on 64 distinct banks.
+// stride of 20 floats keeps the operand reads (one ds_read_b128 per 16-row tile and chunk) spread over the banks.
 constexpr int kNtKC = 16;
 constexpr int kNtLd = 20;
 
@@ -100,20 +100,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
   for (int c = 0; c < nch; ++c) {
     const int buf = c & 1;
     if (c + 1 < nch) load_chunk((c + 1) * kNtKC);
-    const float* as = &As[buf][(64 * wm + i) * kNtLd + kq];
-    const float* ws = &Ws[buf][(64 * wn + i) * kNtLd + kq];
+    // The k a lane feeds into K-step ks is 4 kq + ks (any assignment of the chunk's 16 k to (K-step, lane group) pairs is a
+    // valid order of the sum as long as both operands agree): its four K-steps are 16 contiguous bytes, one ds_read_b128.
+    const float* as = &As[buf][(64 * wm + i) * kNtLd + 4 * kq];
+    const float* ws = &Ws[buf][(64 * wn + i) * kNtLd + 4 * kq];
+    f32x4 a4[4], b4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a4[t] = *(const f32x4*)(as + 16 * t * kNtLd);
+      b4[t] = *(const f32x4*)(ws + 16 * t * kNtLd);
+    }
 #pragma unroll
     for (int ks = 0; ks < kNtKC / 4; ++ks) {
-      float a[4], b[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = as[16 * t * kNtLd + 4 * ks];
-        b[t] = ws[16 * t * kNtLd + 4 * ks];
-      }
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tm][ks], b4[tn][ks], acc[tm][tn], 0, 0, 0);
     }
     if (c + 1 < nch) store_chunk(buf ^ 1);  // last read in iteration c - 1, before its barrier
     __syncthreads();

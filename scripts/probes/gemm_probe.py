@@ -24,7 +24,16 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n
 
 
-for rows in (11764, 82324, 129600, 907200):
+# the wide path's edge-level product: 453 600 decoder edges, 1024 -> 1024
+for rows, k, n in ((453600, 1024, 1024), (41162, 1024, 1024), (64800, 102, 1024)):
+    x = torch.randn(rows, k, device=dev)
+    w = torch.randn(n, k, device=dev) / 32
+    t = timeit(lambda: wide.linear_forward(x, w, None, True), n=5)
+    ref = torch.relu(x[:256].double() @ w.double().t())
+    err = (wide.linear_forward(x, w, None, True)[:256].double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"gemm_nt {rows} x {k} -> {n}: {t*1e3:8.1f} us ({2.0*rows*k*n/t/1e9:6.1f} TF/s), rel err {err:.1e}")
+
+for rows in (82324, 907200):
     d = torch.randn(rows, 256, device=dev)
     h = torch.randn(rows, 256, device=dev)
     W = torch.randn(256, 256, device=dev) / 16
