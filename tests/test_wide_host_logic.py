@@ -1,0 +1,169 @@
+"""Host logic of the wide path (graph_weather_amd/wide.py) without a GPU: the kernel wrappers are replaced by torch statements
+of what each kernel computes (the GPU tests check the kernels against exactly these statements), so that the orchestration -
+layer-1 split with gathered node products, weight column ranges, shared / per-sample tables, residuals shared by the batch,
+segment sums on the destination-sorted plan, the autograd nodes and the inference caches - runs on the CPU against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import graph_weather_amd as gw
+from graph_weather_amd import autograd as ag
+from graph_weather_amd import wide
+from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons
+from oracle import reference_math as om
+
+
+def _linear_gather(x, w, bias, relu, adds, rows, rpb):
+    n = int(adds[0][0].shape[1]) if w is None else int(w.shape[0])
+    z = torch.zeros(rows, n, dtype=torch.float64) if w is None else x.double() @ w.double().t()
+    if bias is not None:
+        z = z + bias.double()
+    batch = rows // rpb
+    bidx = torch.arange(batch).repeat_interleave(rpb)
+    for t, idx, rows_pb in adds:
+        k = (torch.arange(rpb) if idx is None else idx.long()).repeat(batch)
+        z = z + t.double()[bidx * rows_pb + k]
+    return (torch.relu(z) if relu else z).float()
+
+
+def _segment_sum(rows, rows_pb_in, batch, batch_out, n_seg, ptr, perm):
+    p = ptr.long()
+    counts = p[1:] - p[:-1]
+    seg = torch.arange(n_seg).repeat_interleave(counts)          # segment of each CSR position
+    pos = torch.arange(int(p[-1])) if perm is None else perm.long()[: int(p[-1])]
+    out = torch.zeros(batch_out * n_seg, rows.shape[1], dtype=torch.float64)
+    for b in range(batch):
+        bo = b if batch_out == batch else 0
+        out.index_add_(0, bo * n_seg + seg, rows.double()[b * rows_pb_in + pos])
+    return out.float()
+
+
+def _gather(table, rows_pb, idx, batch, n_idx):
+    k = torch.arange(n_idx) if idx is None else idx.long()
+    return torch.cat([table[b * rows_pb + k] for b in range(batch)]).clone()
+
+
+def _ln(y, g, b, res, res_period=0):
+    o = torch.nn.functional.layer_norm(y.double(), (y.shape[1],), g.double(), b.double(), 1e-5)
+    if res is not None:
+        r = res.double()
+        o = o + (r.repeat(y.shape[0] // res_period, 1) if res_period else r)
+    return o.float()
+
+
+def _ln_bwd(dn, y, gamma, dgamma, dbeta, width=0):
+    with torch.enable_grad():  # (called from inside a Function.backward, where grad mode is off)
+        yr = y.detach().double().requires_grad_(True)
+        gr = gamma.detach().double().requires_grad_(True)
+        br = torch.zeros_like(gr).requires_grad_(True)
+        torch.nn.functional.layer_norm(yr, (y.shape[1],), gr, br, 1e-5).backward(dn.double())
+    dgamma += gr.grad.float()
+    dbeta += br.grad.float()
+    return yr.grad.float()
+
+
+def _tn(a, b, c, c_col0=0, colsum=None):
+    c[:a.shape[1], c_col0:c_col0 + b.shape[1]] += (a.double().t() @ b.double()).float()
+    if colsum is not None:
+        colsum[:a.shape[1]] += a.double().sum(0).float()
+
+
+def _mask(dh, h, db=None):
+    dz = dh if h is None else dh * (h > 0)
+    if db is not None:
+        db += dz.double().sum(0).float()
+    return dz.contiguous()
+
+
+@pytest.fixture
+def torch_kernels(monkeypatch):
+    monkeypatch.setattr(wide, "_rows", lambda t, name: t)
+    monkeypatch.setattr(wide, "linear_forward", lambda x, w, b, relu: _linear_gather(x, w, b, relu, [], int(x.shape[0]), max(1, int(x.shape[0]))))
+    monkeypatch.setattr(wide, "linear_gather_forward", _linear_gather)
+    monkeypatch.setattr(wide, "layernorm_forward", _ln)
+    monkeypatch.setattr(wide, "add_rows", lambda a, b: a + b)
+    monkeypatch.setattr(wide, "gather_rows", _gather)
+    monkeypatch.setattr(wide, "segment_sum_rows", _segment_sum)
+    monkeypatch.setattr(wide, "_relu_mask", _mask)
+    monkeypatch.setattr(wide, "_check_mlp", lambda mlp: None)
+    monkeypatch.setattr(ag, "gemm_tn_acc", _tn)
+    monkeypatch.setattr(ag, "layernorm_backward", _ln_bwd)
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+
+
+def _forward(model, feats):
+    """GraphWeatherForecaster.forward behind its device check (the product refuses CPU tensors; the kernels are patched here)."""
+    from graph_weather_amd.layers import fused_forward
+
+    f = feats.contiguous()
+    return fused_forward(model.encoder, model.processor, model.decoder, f, f.reshape(f.shape[0] * f.shape[1], f.shape[2]))
+
+
+def test_wide_forecaster_orchestration_against_the_oracle(torch_kernels):
+    lat_lons = regular_lat_lons(30.0)
+    model = gw.GraphWeatherForecaster(lat_lons, resolution=0, feature_dim=6, aux_dim=2, node_dim=260, edge_dim=258, num_blocks=2,
+                                      hidden_dim_processor_node=264, hidden_dim_processor_edge=257, hidden_dim_decoder=259)
+    deterministic_fill_(model, seed=3)
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    g64 = om.graphs_to_dtype(model.encoder.graphs.as_oracle_dict(), torch.float64)
+    rs = np.random.RandomState(0)
+    feats = torch.from_numpy(rs.standard_normal((2, len(lat_lons), 8)).astype(np.float32))
+    dy = torch.from_numpy(rs.standard_normal((2, len(lat_lons), 6)).astype(np.float32))
+    y_ref = om.forecaster_forward(ref, g64, feats.double(), feature_dim=6)
+    (y_ref * dy.double()).sum().backward()
+    with torch.no_grad():
+        y = _forward(model, feats)
+        assert _rel(y, y_ref.detach()) < 1e-5
+        assert torch.equal(_forward(model, feats), y)  # second call: served from the inference caches
+    model.train()
+    y = _forward(model, feats)
+    assert _rel(y.detach(), y_ref.detach()) < 1e-5
+    (y * dy).sum().backward()
+    worst = max(_rel(p.grad, ref[k].grad) for k, p in model.named_parameters())
+    assert worst < 1e-4, worst
+    # compositional API on the replicated graph the reference returns (tests/test_model.py:106-119)
+    with torch.no_grad():
+        x, ei, ea = model.encoder(feats)
+        assert x.shape == (2 * model.encoder.num_h3, 260) and ea.shape[1] == 258
+        out = model.decoder(model.processor(x, ei, ea), feats[..., :6])
+    assert _rel(out, y_ref.detach()) < 1e-5
+    # caches follow the parameter versions
+    model.eval()
+    with torch.no_grad():
+        y_a = _forward(model, feats)
+        model.decoder.edge_encoder.model[0].weight.add_(0.05)
+        y_b = _forward(model, feats)
+    assert (y_a - y_b).abs().max().item() > 1e-5
+    model.train()
+    assert _rel(_forward(model, feats).detach(), y_b) < 1e-5
+
+
+def test_wide_graph_processor_shared_edges_and_checkpoint_segments(torch_kernels):
+    """Processor with efficient_batching (one edge set shared by the batch, processor.py:106-118) and recompute segments."""
+    proc = gw.Processor(input_dim=260, edge_dim=258, num_blocks=3, hidden_dim_processor_node=257, hidden_dim_processor_edge=262)
+    deterministic_fill_(proc, seed=5)
+    ref = {"p." + k: v.detach().double().requires_grad_(True) for k, v in proc.state_dict().items()}
+    rs = np.random.RandomState(2)
+    B, n, e = 2, 30, 120
+    x = torch.from_numpy(rs.standard_normal((B * n, 260)).astype(np.float32))
+    ea = torch.from_numpy(rs.standard_normal((e, 258)).astype(np.float32))
+    ei = torch.from_numpy(np.stack([rs.randint(0, n, size=e), rs.randint(0, n, size=e)]).astype(np.int64))
+    gx = torch.from_numpy(rs.standard_normal((B * n, 260)).astype(np.float32))
+    xr, er = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    outs = [om.graph_processor({k.replace("p.graph_processor.", "gp."): v for k, v in ref.items()}, "gp", xr[b * n:(b + 1) * n], ei, er)[0]
+            for b in range(B)]
+    y_ref = torch.cat(outs)
+    (y_ref * gx.double()).sum().backward()
+    for seg in (0, -1, 2):
+        proc.set_checkpoint_segments(seg)
+        proc.zero_grad()
+        xd, ed = x.clone().requires_grad_(True), ea.clone().requires_grad_(True)
+        y = proc(xd, ei, ed, batch_size=B, efficient_batching=True)
+        assert _rel(y.detach(), y_ref.detach()) < 1e-5
+        (y * gx).sum().backward()
+        assert _rel(xd.grad, xr.grad) < 1e-4 and _rel(ed.grad, er.grad) < 1e-4
+        worst = max(_rel(p.grad, ref["p." + k].grad) for k, p in proc.named_parameters())
+        assert worst < 1e-4, (seg, worst)
