@@ -107,3 +107,33 @@ def test_edge16_kernels_keep_their_weights_in_accumulation_registers(tmp_path):
     body = text[text.index(l1 + ":"):]
     body = body[:body.index(".end_amdhsa_kernel")]
     assert len(re.findall(r"^\s*v_mfma_f32_16x16x32_bf16", body, re.M)) == 128
+
+
+@pytest.mark.timeout(600)
+def test_wide_kernels_have_no_scratch_and_the_gemm_keeps_three_waves_per_simd(tmp_path):
+    """csrc/gw_wide.hip: the LayerNorm kernels hold a whole row per wave in registers (up to 64 columns per lane, three such arrays
+    in the backward) - a spill would turn them into scratch-memory kernels; the GEMM's 128 x 128 tile must leave room for three
+    workgroups per CU (LDS 40 KiB each, <= 168 registers per wave)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graph_weather_amd", "csrc", "gw_wide.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "w.o", "-save-temps"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+    text = (tmp_path / "gw_wide-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    seen = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        name, meta = m.group(1), m.group(2)
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", meta).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch"
+        assert vgpr <= 512, f"{name}: {vgpr} registers"
+        seen[name] = (vgpr, lds)
+    gemms = {k: v for k, v in seen.items() if "gemm_nt_kernel" in k}
+    assert len(gemms) == 2, list(seen)
+    for k, (vgpr, lds) in gemms.items():
+        assert vgpr <= 168 and lds <= 40 * 1024 + 512, f"{k}: {vgpr} registers, {lds} bytes of LDS"
+    for family, count in (("ln_fwd_wide_kernel", 4), ("ln_bwd_wide_kernel", 4), ("gather_sum_kernel", 1), ("segment_sum_wide_kernel", 1),
+                          ("gather_wide_kernel", 1), ("relu_mask_wide_kernel", 1), ("add_rows_kernel", 1)):
+        assert sum(family in k for k in seen) == count, (family, list(seen))
