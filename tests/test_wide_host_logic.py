@@ -118,6 +118,8 @@ def test_wide_forecaster_orchestration_against_the_oracle(torch_kernels):
         y = _forward(model, feats)
         assert _rel(y, y_ref.detach()) < 1e-5
         assert torch.equal(_forward(model, feats), y)  # second call: served from the inference caches
+    with torch.inference_mode():  # inference tensors have no version counter: the caches must not need one
+        assert _rel(_forward(model, feats.clone()), y_ref.detach()) < 1e-5
     model.train()
     y = _forward(model, feats)
     assert _rel(y.detach(), y_ref.detach()) < 1e-5
