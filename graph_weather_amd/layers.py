@@ -348,9 +348,11 @@ def build_graph_processor_block(in_dim_node=128, in_dim_edge=128, hidden_dim_nod
 def _check_native_dims(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge, norm_type):
     if max(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge) > 256 or norm_type not in ("LayerNorm", None):
         raise NotImplementedError(
-            "graph_weather_amd: the HIP message-passing kernels handle node / edge / hidden widths up to 256 (narrower "
+            "graph_weather_amd: the fused HIP message-passing kernels handle node / edge / hidden widths up to 256 (narrower "
             "models run zero-padded to 256) with LayerNorm or no norm (the only norm_type values torch.nn resolves, "
-            "graph_net_block.py:50-59); wider models are not implemented")
+            "graph_net_block.py:50-59).  Wider GraphWeatherForecaster / GraphCast / Encoder / Processor / Decoder / "
+            "GraphProcessor / MLP models run on the generic kernels of graph_weather_amd/wide.py; RegionalForecaster and "
+            "GraphWeatherAssimilator are not routed there yet")
 
 
 def _pad256(t: torch.Tensor) -> torch.Tensor:
