@@ -253,30 +253,33 @@ def test_wide_forecaster_matches_oracle_forward_and_backward():
 
 
 def test_reference_training_script_widths_one_step():
-    """The constructor call of the reference's train/run.py:486-501 (1024-wide nodes, edges, hidden layers and decoder) on a
-    10 degree grid: forward against the oracle, then loss.backward() + optimizer step like train/run.py:509-521."""
-    lat_lons = regular_lat_lons(10.0)
-    model = gw.GraphWeatherForecaster(lat_lons, feature_dim=20, aux_dim=4, edge_dim=1024, hidden_dim_processor_edge=1024, node_dim=1024,
-                                      hidden_dim_processor_node=1024, hidden_dim_decoder=1024, num_blocks=2)
+    """The constructor call of the reference's train/run.py:479-501 as written - lat_lons as an [N, 2] numpy array, 605 + 40
+    input channels, 605 outputs, nodes / edges / hidden layers / decoder 1024 wide, 6 blocks - on a 10 degree grid: forward
+    against the oracle, then its loop body (:509-521: zero_grad, forward, NormalizedMSELoss, backward, torch.optim.AdamW.step)."""
+    lat_lons = np.array(np.meshgrid(np.arange(-90.0, 90.0, 10.0), np.arange(0.0, 360.0, 10.0))).T.reshape(-1, 2)
+    model = gw.GraphWeatherForecaster(lat_lons, edge_dim=1024, hidden_dim_processor_edge=1024, node_dim=1024,
+                                      hidden_dim_processor_node=1024, hidden_dim_decoder=1024, feature_dim=605, aux_dim=40, num_blocks=6)
     deterministic_fill_(model, seed=2)
     ref = {k: v.detach().clone() for k, v in model.state_dict().items()}
     g = model.encoder.graphs.as_oracle_dict()
     rs = np.random.RandomState(2)
-    feats, target = _t(rs, 2, len(lat_lons), 24), _t(rs, 2, len(lat_lons), 20)
-    y_ref = om.forecaster_forward(ref, g, feats, feature_dim=20)
+    n = len(lat_lons)
+    inputs, labels = _t(rs, 1, n, 645), _t(rs, 1, n, 605)
+    y_ref = om.forecaster_forward(ref, g, inputs, feature_dim=605)
     model = model.to(DEV)
     with torch.no_grad():
-        y = model(feats.to(DEV))
-    res = feats[..., :20]
-    _close(y.cpu() - res, y_ref.float() - res, what="1024-wide forecaster")
-    criterion = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=torch.ones(20), device=DEV).to(DEV)
-    opt = gw.AdamW(model.parameters(), lr=2e-5)
+        y = model(inputs.to(DEV))
+    res = inputs[..., :605]
+    _close(y.cpu() - res, y_ref.float() - res, what="train/run.py forecaster (1024 wide, 645 -> 605)")
+    criterion = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=[0.0] * 605, device=DEV).to(DEV)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=2e-5)
     model.train()
     losses = []
     for _ in range(4):
-        opt.zero_grad()
-        loss = criterion(model(feats.to(DEV)), target.to(DEV))
+        optimizer.zero_grad()
+        outputs = model(inputs.to(DEV))
+        loss = criterion(outputs, labels.to(DEV))
         loss.backward()
-        opt.step()
-        losses.append(float(loss.detach()))
+        optimizer.step()
+        losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -169,3 +169,33 @@ def test_wide_graph_processor_shared_edges_and_checkpoint_segments(torch_kernels
         assert _rel(xd.grad, xr.grad) < 1e-4 and _rel(ed.grad, er.grad) < 1e-4
         worst = max(_rel(p.grad, ref["p." + k].grad) for k, p in proc.named_parameters())
         assert worst < 1e-4, (seg, worst)
+
+
+def test_reference_training_script_constructor_call_shapes(torch_kernels):
+    """train/run.py:479-501 as written - lat_lons as an [N, 2] numpy array, 605 + 40 input channels, 605 outputs, 1024-wide nodes,
+    edges, hidden layers and decoder, 6 blocks, torch.optim.AdamW - on a coarse mesh (resolution 0 keeps the CPU stand-ins quick)."""
+    lat_lons = np.array(np.meshgrid(np.arange(-60.0, 61.0, 30.0), np.arange(0.0, 360.0, 60.0))).T.reshape(-1, 2)
+    model = gw.GraphWeatherForecaster(lat_lons, resolution=0, edge_dim=1024, hidden_dim_processor_edge=1024, node_dim=1024,
+                                      hidden_dim_processor_node=1024, hidden_dim_decoder=1024, feature_dim=605, aux_dim=40, num_blocks=6)
+    deterministic_fill_(model, seed=1)
+    criterion = gw.NormalizedMSELoss(lat_lons=lat_lons, feature_variance=[0.0] * 605, device="cpu")
+    ref = {k: v.detach().double() for k, v in model.state_dict().items()}
+    g64 = om.graphs_to_dtype(model.encoder.graphs.as_oracle_dict(), torch.float64)
+    rs = np.random.RandomState(4)
+    n = len(lat_lons)
+    inputs = torch.from_numpy(rs.standard_normal((1, n, 645)).astype(np.float32))
+    labels = torch.from_numpy(rs.standard_normal((1, n, 605)).astype(np.float32))
+    y_ref = om.forecaster_forward(ref, g64, inputs.double(), feature_dim=605)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=0.001)
+    optimizer.zero_grad()
+    outputs = _forward(model, inputs)
+    assert outputs.shape == (1, n, 605) and _rel(outputs.detach(), y_ref) < 1e-5
+    assert criterion.weights.shape == (5,)  # the constructor took the numpy coordinates
+    # the loss kernel itself needs a GPU: its oracle statement gives the value and the backward seed here
+    od = outputs.detach().double().requires_grad_(True)
+    loss_ref = om.normalized_mse_loss(od, labels.double(), [tuple(ll) for ll in lat_lons.tolist()])
+    loss_ref.backward()
+    outputs.backward(od.grad.float())
+    optimizer.step()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    assert np.isfinite(float(loss_ref))
