@@ -332,6 +332,29 @@ class RegionalForecaster(nn.Module):
             self._cache[name] = (key, fn())
         return self._cache[name][1]
 
+    def _is_wide(self) -> bool:
+        from . import wide
+
+        e, d = self.encoder_gnn.blocks[0], self.decoder_gnn.blocks[0]
+        return (wide.is_wide(self.node_encoder, self.edge_encoder, self.latent_edge_encoder, self.decoder_edge_encoder, self.node_decoder,
+                             e.edge_model.edge_mlp, e.node_model.node_mlp, d.edge_model.edge_mlp, d.node_model.node_mlp)
+                or wide.processor_is_wide(self.processor.graph_processor))
+
+    def _forward_wide(self, feats, B, N, enc_plan, lat_plan, dec_plan, rows):
+        """The same forward for widths above 256, on the generic kernels of wide.py (regional_forecast.py:258-284)."""
+        from . import wide
+
+        C = enc_plan.n_dst
+        xo = wide.mlp_rows(self.node_encoder, feats)
+        xm = wide.mlp_rows(self.node_encoder, self.h3_embeddings[rows])
+        e_enc = wide.mlp_rows(self.edge_encoder, enc_plan.edge_attr)
+        x, _ = wide.block(self.encoder_gnn.blocks[0], enc_plan, B, xo, N, xm, 0, e_enc, 0)
+        e_lat = wide.mlp_rows(self.latent_edge_encoder, lat_plan.edge_attr)
+        x, _ = wide.run_blocks(self.processor.graph_processor, x, lat_plan, e_lat, True, B, False)
+        e_dec = wide.mlp_rows(self.decoder_edge_encoder, dec_plan.edge_attr)
+        xg, _ = wide.block(self.decoder_gnn.blocks[0], dec_plan, B, x.contiguous(), C, None, 0, e_dec, 0)
+        return wide.mlp_rows(self.node_decoder, xg, residual=feats[:, :self.output_dim])
+
     def forward(self, features: torch.Tensor, lat_lons: list, global_context: Optional[torch.Tensor] = None) -> torch.Tensor:
         """regional_forecast.py:234-298."""
         if not features.is_cuda:
@@ -350,9 +373,14 @@ class RegionalForecaster(nn.Module):
         if F < self.output_dim:
             raise RuntimeError("graph_weather_amd: features need at least output_dim = %d channels for the residual "
                                "(regional_forecast.py:283-284)" % self.output_dim)
+        feats = features.reshape(B * N, F)
+        if self._is_wide():
+            out = self._forward_wide(feats, B, N, enc_plan, lat_plan, dec_plan, rows).reshape(B, N, self.output_dim)
+            if self.nudging is not None and global_context is not None:
+                out = self.nudging(out, global_context, lat_lons)
+            return out
         _check_native_dims(*self.encoder_gnn._dims)
         _check_native_dims(*self.decoder_gnn._dims)
-        feats = features.reshape(B * N, F)
 
         # ---- encode: coordinates + regional cells through the bipartite block (:258, :266-269) ----
         xo = self.node_encoder.run(feats, B * N, N)

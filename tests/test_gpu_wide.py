@@ -283,3 +283,29 @@ def test_reference_training_script_widths_one_step():
         optimizer.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_wide_regional_forecaster_forward_and_backward():
+    """RegionalForecaster (regional_forecast.py:234-298) at widths above 256: forward and every parameter gradient against the oracle."""
+    rs = np.random.RandomState(17)
+    n = 230
+    lat_lons = [(float(a), float(b)) for a, b in zip(rs.uniform(35, 65, n), rs.uniform(-15, 30, n))]
+    model = gw.RegionalForecasterConfig(feature_dim=20, aux_dim=5, node_dim=320, edge_dim=288, num_blocks=2, hidden_dim_processor_node=384,
+                                        hidden_dim_processor_edge=300, hidden_dim_decoder=272, enable_nudging=True).build()
+    deterministic_fill_(model, seed=12)
+    feats, ctx, dy = _t(rs, 2, n, 25), _t(rs, 2, n, 20), _t(rs, 2, n, 20)
+    enc, _, lat, h3_idx = model.graph_builder(lat_lons)
+    g = {"enc_edge_index": enc.edge_index, "enc_edge_attr": enc.edge_attr, "lat_edge_index": lat.edge_index,
+         "lat_edge_attr": lat.edge_attr, "h3_indices": h3_idx}
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    y_ref = om.regional_forward(ref, om.graphs_to_dtype(g, torch.float64), feats.double(), 20, global_context=ctx.double(), lat_lons=lat_lons)
+    (y_ref * dy.double()).sum().backward()
+    model = model.to(DEV)
+    with torch.no_grad():
+        _close(model(feats.to(DEV), lat_lons, global_context=ctx.to(DEV)), y_ref, what="wide regional (inference)")
+    model.train()
+    y = model(feats.to(DEV), lat_lons, global_context=ctx.to(DEV))
+    _close(y, y_ref, what="wide regional (training forward)")
+    (y * dy.to(DEV)).sum().backward()
+    worst = {}
+    _check_param_grads(model, ref, "", worst, bar=4e-3)

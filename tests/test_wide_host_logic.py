@@ -199,3 +199,28 @@ def test_reference_training_script_constructor_call_shapes(torch_kernels):
     optimizer.step()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert np.isfinite(float(loss_ref))
+
+
+def test_wide_regional_forecaster_against_the_oracle(torch_kernels):
+    """RegionalForecaster (regional_forecast.py:234-298) with widths above 256 takes the same generic route."""
+    rs = np.random.RandomState(17)
+    n = 60
+    lat_lons = [(float(a), float(b)) for a, b in zip(rs.uniform(45, 55, n), rs.uniform(-5, 10, n))]
+    model = gw.RegionalForecasterConfig(feature_dim=6, aux_dim=2, node_dim=260, edge_dim=258, num_blocks=2, hidden_dim_processor_node=264,
+                                        hidden_dim_processor_edge=257, hidden_dim_decoder=259).build()
+    deterministic_fill_(model, seed=12)
+    assert model._is_wide()
+    feats = torch.from_numpy(rs.standard_normal((2, n, 8)).astype(np.float32))
+    dy = torch.from_numpy(rs.standard_normal((2, n, 6)).astype(np.float32))
+    enc, _, lat, h3_idx = model.graph_builder(lat_lons)
+    g = {"enc_edge_index": enc.edge_index, "enc_edge_attr": enc.edge_attr, "lat_edge_index": lat.edge_index,
+         "lat_edge_attr": lat.edge_attr, "h3_indices": h3_idx}
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    y_ref = om.regional_forward(ref, om.graphs_to_dtype(g, torch.float64), feats.double(), 6)
+    (y_ref * dy.double()).sum().backward()
+    enc_plan, lat_plan, dec_plan, rows = model.graph_builder.native_plans(lat_lons, torch.device("cpu"))
+    y = model._forward_wide(feats.reshape(2 * n, 8), 2, n, enc_plan, lat_plan, dec_plan, rows).reshape(2, n, 6)
+    assert _rel(y.detach(), y_ref.detach()) < 1e-5
+    (y * dy).sum().backward()
+    worst = max(_rel(p.grad, ref[k].grad) for k, p in model.named_parameters() if ref[k].grad is not None)
+    assert worst < 1e-4, worst
