@@ -82,8 +82,15 @@ class AssimilatorEncoder(nn.Module):
     def latent_edge_embedding(self, plan) -> torch.Tensor:
         return self._cached("lat_e", list(self.latent_edge_encoder.parameters()), lambda: self.latent_edge_encoder.table(plan.edge_attr))
 
-    def encode(self, features: torch.Tensor, lat_lon_heights: torch.Tensor) -> torch.Tensor:
-        """assimilator_encoder.py:137-157 -> mesh node features [(B*M), D] (reversed-rank order)."""
+    def _is_wide(self) -> bool:
+        from . import wide as wd
+
+        b = self.graph_processor.blocks[0]
+        return wd.is_wide(self.node_encoder, self.edge_encoder, self.latent_edge_encoder, b.edge_model.edge_mlp, b.node_model.node_mlp)
+
+    def encode(self, features: torch.Tensor, lat_lon_heights: torch.Tensor, wide: bool = False) -> torch.Tensor:
+        """assimilator_encoder.py:137-157 -> mesh node features [(B*M), D] (reversed-rank order).  ``wide``: take the generic
+        kernels even if this encoder alone would fit the fused ones (another part of the model is wider than 256)."""
         if not features.is_cuda:
             raise RuntimeError("graph_weather_amd: features must be on a HIP device - there is no CPU path")
         B, N, F = (int(s) for s in features.shape)
@@ -91,10 +98,18 @@ class AssimilatorEncoder(nn.Module):
         plan = self._observation_plan(lat_lon_heights, dev)
         if plan.n_src != N:
             raise RuntimeError("features and lat_lon_heights disagree on the number of observations")
-        _check_native_dims(*self.graph_processor._dims)
         feats = features.contiguous().reshape(B * N, F)
-        xo = self.node_encoder.table(feats)  # observation rows
         zeros_in = self.h3_nodes.to(dev)
+        if wide or self._is_wide():  # widths above 256: the generic kernels of wide.py
+            from . import wide as wd
+
+            xo = wd.mlp_rows(self.node_encoder, feats)
+            xm = wd.mlp_rows(self.node_encoder, zeros_in)
+            e = wd.mlp_rows(self.edge_encoder, plan.edge_attr)
+            x, _ = wd.block(self.graph_processor.blocks[0], plan, B, xo, N, xm, 0, e, 0)
+            return x
+        _check_native_dims(*self.graph_processor._dims)
+        xo = self.node_encoder.table(feats)  # observation rows
         xm = self._cached("mesh", list(self.node_encoder.parameters()), lambda: self.node_encoder.table(zeros_in))
         e = self.edge_encoder.table(plan.edge_attr)  # depends on the observation positions: not cached across graphs
         blk = self.graph_processor.blocks[0]
@@ -188,9 +203,16 @@ class GraphWeatherAssimilator(nn.Module, PyTorchModelHubMixin):
 
     def forward(self, features: torch.Tensor, obs_lat_lon_heights: torch.Tensor) -> torch.Tensor:
         """analysis.py:136-150; fused native path (shared graphs, data stays in the native layouts between the stages)."""
+        from . import wide as wd
+
         B = int(features.shape[0])
-        x = self.encoder.encode(features, obs_lat_lon_heights)
         plan = self.encoder._latent_plan(features.device)
+        if self.encoder._is_wide() or wd.processor_is_wide(self.processor.graph_processor) or wd.decoder_is_wide(self.decoder):
+            x = self.encoder.encode(features, obs_lat_lon_heights, wide=True)
+            e_lat = wd.mlp_rows(self.encoder.latent_edge_encoder, plan.edge_attr)
+            x, _ = wd.run_blocks(self.processor.graph_processor, x, plan, e_lat, True, B, False)
+            return wd.decode(self.decoder, x, B)
+        x = self.encoder.encode(features, obs_lat_lon_heights)
         e_lat = self.encoder.latent_edge_embedding(plan)
         x, _ = self.processor.graph_processor.run_plan(x, plan, e_lat, True, B, False)
         return self.decoder.decode(x, B)

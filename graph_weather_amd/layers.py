@@ -350,9 +350,8 @@ def _check_native_dims(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edg
         raise NotImplementedError(
             "graph_weather_amd: the fused HIP message-passing kernels handle node / edge / hidden widths up to 256 (narrower "
             "models run zero-padded to 256) with LayerNorm or no norm (the only norm_type values torch.nn resolves, "
-            "graph_net_block.py:50-59).  Wider GraphWeatherForecaster / GraphCast / RegionalForecaster / Encoder / Processor / "
-            "Decoder / GraphProcessor / MLP models run on the generic kernels of graph_weather_amd/wide.py; "
-            "GraphWeatherAssimilator is not routed there yet")
+            "graph_net_block.py:50-59).  Wider models run on the generic kernels of graph_weather_amd/wide.py - this call was "
+            "reached with a table the fused kernels cannot take")
 
 
 def _pad256(t: torch.Tensor) -> torch.Tensor:

@@ -309,3 +309,26 @@ def test_wide_regional_forecaster_forward_and_backward():
     (y * dy.to(DEV)).sum().backward()
     worst = {}
     _check_param_grads(model, ref, "", worst, bar=4e-3)
+
+
+def test_wide_assimilator_forward_and_backward():
+    """GraphWeatherAssimilator (analysis.py:52-150) at widths above 256, on the observations of the golden case."""
+    from .test_oracle import _assimilator_setup
+
+    out_lat_lons, llh, feats, g = _assimilator_setup()
+    model = gw.GraphWeatherAssimilator(output_lat_lons=out_lat_lons, analysis_dim=24, node_dim=320, edge_dim=288, num_blocks=2,
+                                       hidden_dim_processor_node=384, hidden_dim_processor_edge=300, hidden_dim_decoder=272)
+    deterministic_fill_(model, seed=6)
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    rs = np.random.RandomState(3)
+    dy = _t(rs, 1, 648, 24)
+    y_ref = om.assimilator_forward(ref, om.graphs_to_dtype(g, torch.float64), feats.double(), 24)
+    (y_ref * dy.double()).sum().backward()
+    model = model.to(DEV)
+    with torch.no_grad():
+        _close(model(feats.to(DEV), llh.to(DEV)), y_ref, what="wide assimilator (inference)")
+    model.train()
+    y = model(feats.to(DEV), llh.to(DEV))
+    (y * dy.to(DEV)).sum().backward()
+    worst = {}
+    _check_param_grads(model, ref, "", worst, bar=4e-3)
