@@ -220,7 +220,7 @@ def test_two_step_rollout_gradients_include_the_residual_path():
     """Step t+1 consumes step t's output: d(out)/d(features) has the identity term of decoder.py:93.  Two chained steps,
     gradients of every parameter and of the input against the oracle's fp64 autograd."""
     lat_lons = regular_lat_lons(10.0)
-    model = gw.GraphWeatherForecaster(lat_lons)
+    model = gw.GraphWeatherForecaster(lat_lons, num_blocks=3)  # (two chained oracle forwards + an fp64 backward on the host)
     deterministic_fill_(model, seed=3)
     ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
     g64 = om.graphs_to_dtype(model.encoder.graphs.as_oracle_dict(), torch.float64)
@@ -245,7 +245,7 @@ def test_two_step_rollout_gradients_include_the_residual_path():
 def test_frozen_processor_still_passes_gradients_to_the_encoder():
     """a frozen block downstream of a trainable one must run the differentiable path."""
     lat_lons = regular_lat_lons(10.0)
-    model = gw.GraphWeatherForecaster(lat_lons)
+    model = gw.GraphWeatherForecaster(lat_lons, num_blocks=3)
     deterministic_fill_(model, seed=9)
     ref = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
     g64 = om.graphs_to_dtype(model.encoder.graphs.as_oracle_dict(), torch.float64)
