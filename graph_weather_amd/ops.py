@@ -18,6 +18,7 @@ class KernelTimer:
     def __init__(self, tags):
         self.tags = set(tags)
         self.events = {t: [] for t in self.tags}
+        self.units = {t: [] for t in self.tags}  # batch elements each timed launch processed (per-sample streams: 1)
 
     def start(self, tag):
         if tag not in self.tags:
@@ -26,10 +27,15 @@ class KernelTimer:
         ev[0].record()
         return ev
 
-    def stop(self, tag, ev):
+    def stop(self, tag, ev, units: int = 1):
         if ev is not None:
             ev[1].record()
             self.events[tag].append(ev)
+            self.units[tag].append(int(units))
+
+    def mean_units(self, tag) -> float:
+        u = self.units[tag]
+        return sum(u) / max(1, len(u))
 
     def mean_ms(self, tag) -> float:
         evs = self.events[tag]
@@ -289,7 +295,7 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
                                                      None if ws is None else ws.data_ptr(), ws_bytes, flags, _stream(agg)),
                    "gw_edge_update_forward")
     if ev is not None:
-        TIMER.stop(tag, ev)
+        TIMER.stop(tag, ev, batch)
 
 
 def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, x_res: Operand, agg: Operand,

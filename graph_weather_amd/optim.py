@@ -11,7 +11,18 @@ def _bump_versions(params) -> None:
     """The kernel updates parameters through raw pointers; the packed-weight / embedding caches of the modules key on
     ``Tensor._version``, so it is advanced here - without launching anything."""
     ps = tuple(params)
-    torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
+    if not ps:
+        return
+    try:
+        torch._C._autograd._unsafe_set_version_counter(ps, tuple(p._version + 1 for p in ps))
+    except (TypeError, AttributeError):
+        # older torch: (Tensor, int) signature, or no such hook at all - fall back to an in-place no-op per tensor
+        for p in ps:
+            try:
+                torch._C._autograd._unsafe_set_version_counter(p, p._version + 1)
+            except (TypeError, AttributeError):
+                with torch.no_grad():
+                    p.add_(0)
 
 
 class AdamW(torch.optim.Optimizer):
@@ -28,6 +39,30 @@ class AdamW(torch.optim.Optimizer):
             if len(self.param_groups) != 1 or mine != {id(p) for p in flat.params}:
                 raise ValueError("graph_weather_amd.AdamW: flat must cover exactly the parameters of the single parameter group")
             self._flat_state = {"step": 0, "exp_avg": torch.zeros_like(flat.param), "exp_avg_sq": torch.zeros_like(flat.param)}
+
+    # The flat moments and the bias-correction step live outside torch.optim.Optimizer.state (they are not per parameter):
+    # carry them through state_dict() / load_state_dict() so that a resumed run does not silently restart them from zero.
+    def state_dict(self):
+        sd = super().state_dict()
+        if self.flat is not None:
+            st = self._flat_state
+            sd["gw_flat_state"] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fs = state_dict.pop("gw_flat_state", None)
+        super().load_state_dict(state_dict)
+        if self.flat is not None:
+            if fs is None:
+                raise ValueError("graph_weather_amd.AdamW: state_dict has no 'gw_flat_state' (saved from an optimizer without flat=...)")
+            st = self._flat_state
+            if fs["exp_avg"].numel() != st["exp_avg"].numel():
+                raise ValueError("graph_weather_amd.AdamW: flat optimizer state has %d elements, this model needs %d"
+                                 % (fs["exp_avg"].numel(), st["exp_avg"].numel()))
+            st["step"] = int(fs["step"])
+            st["exp_avg"].copy_(fs["exp_avg"])
+            st["exp_avg_sq"].copy_(fs["exp_avg_sq"])
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -163,17 +163,47 @@ class FlatGradients:
         self._pending = [b[2] for b in self.buckets]
         self._handles = [None] * len(self.buckets)
         self._ctx: Optional[ShardContext] = None
+        self._sync = True  # False inside no_sync(): gradients accumulate locally, no collective is launched
         self.collectives = 0
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    def _rearm(self) -> None:
+        self._pending = [b[2] for b in self.buckets]
+        self._handles = [None] * len(self.buckets)
+
     def _make_hook(self, i: int):
         def hook(param):
+            if not self._sync:  # accumulation step (no_sync): the gradient stays local
+                return
             b = self._bucket_of[i]
             self._pending[b] -= 1
-            if self._pending[b] == 0 and self._ctx is not None and self._ctx.world > 1:
+            if self._pending[b] < 0:
+                # a second backward() into an armed step would add local gradients onto buckets whose all-reduce is already
+                # in flight (or done): the ranks would diverge silently
+                raise RuntimeError("graph_weather_amd.FlatGradients: a parameter received a second gradient in one step - run "
+                                   "every backward() but the last under flat.no_sync() (gradient accumulation), and call "
+                                   "flat.allreduce() / flat.zero_() between steps")
+            if self._pending[b] == 0 and self._handles[b] is None and self._ctx is not None and self._ctx.world > 1:
                 self._launch(b)
         return hook
+
+    def no_sync(self):
+        """Context for gradient accumulation (torch DDP's ``no_sync``): backward passes inside it only accumulate into the flat
+        buffer; the first backward outside it launches the bucket all-reduces as usual."""
+        flat = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                flat._sync = False
+                return flat
+
+            def __exit__(self_inner, *exc):
+                flat._sync = True
+                flat._rearm()  # the next backward sees full buckets again
+                return False
+
+        return _NoSync()
 
     def _launch(self, b: int) -> None:
         import torch.distributed as dist
@@ -199,8 +229,7 @@ class FlatGradients:
     def zero_(self) -> None:
         """One fill for every gradient; re-arms the bucket counters for the next backward."""
         self.grad.zero_()
-        self._pending = [b[2] for b in self.buckets]
-        self._handles = [None] * len(self.buckets)
+        self._rearm()
 
     def allreduce(self, ctx: ShardContext) -> int:
         """Average the gradients over the ranks: launch the buckets the backward has not already launched, wait for all of
@@ -216,6 +245,9 @@ class FlatGradients:
         for h in self._handles:
             h.wait()
         self.grad.div_(ctx.world)
+        # the step's collectives are done: stale (completed) handles must not make the next allreduce() skip its launches when
+        # the caller zeroes gradients some other way (optimizer.zero_grad(set_to_none=False)) instead of zero_()
+        self._rearm()
         return n
 
 

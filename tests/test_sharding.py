@@ -162,6 +162,61 @@ def test_bench_main_world_two_gloo(tmp_path, config, per_rank, scaling):
     assert abs(d["value"] - sum(per_rank) * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
 
 
+_TRAINED = {}
+
+
+def _train_worker(rank: int, world: int, port: int, out_dir: str):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import contextlib
+    import io
+
+    import bench
+
+    holder = {}
+
+    def factory(cfg, dev):
+        model, lat_lons = _stub_factory(cfg, dev)
+        holder["model"] = model
+        return model, lat_lons
+
+    def loss_factory(lat_lons):
+        return lambda pred, target: (pred - target).square().mean()
+
+    def opt_factory(params, flat):
+        holder["flat"] = flat
+        return torch.optim.SGD(list(params), lr=0.5)  # stands for the one-launch AdamW kernel (updates the flat views in place)
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--mode", "train", "--config", "c2"],
+                   backend="gloo", device="cpu", model_factory=factory, train_factories=(loss_factory, opt_factory))
+    flat = holder["flat"]
+    assert flat.views_intact() and flat.collectives == 4 * len(flat.buckets)  # every step reduced every bucket once
+    torch.save(holder["model"].w.detach().clone(), os.path.join(out_dir, f"w{rank}.pt"))
+    with open(os.path.join(out_dir, f"train{rank}.txt"), "w") as fh:
+        fh.write(buf.getvalue())
+
+
+@pytest.mark.timeout(240)
+def test_bench_train_loop_world_two_gloo(tmp_path):
+    """bench.py --mode train itself on two gloo ranks: flat buffer -> hooks -> bucketed all-reduce -> optimizer step.  Ranks see
+    different data, so equal parameters afterwards mean the averaged gradient reached both; rank 0 alone prints one line."""
+    import json
+
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    w0, w1 = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    assert torch.equal(w0, w1) and not torch.allclose(w0, torch.full_like(w0, 0.5))  # trained, and in lock-step
+    out0 = (tmp_path / "train0.txt").read_text().strip().splitlines()
+    assert (tmp_path / "train1.txt").read_text().strip() == "" and len(out0) == 1
+    d = json.loads(out0[0])
+    assert d["n_gpus"] == 2 and d["unit"] == "samples/s" and d["config"]["global_batch"] == 4 and d["collectives_per_step"] >= 1
+
+
 def _flat_worker(rank: int, world: int, port: int, out_dir: str):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
@@ -195,6 +250,45 @@ def _flat_worker(rank: int, world: int, port: int, out_dir: str):
     with torch.no_grad():
         for p2, r in zip(model2.parameters(), ref):
             p2.copy_(r)
+    (model2(x) - y).square().mean().backward()
+    for p, p2 in zip(model.parameters(), model2.parameters()):
+        g = p2.grad.clone()
+        dist.all_reduce(g)
+        assert torch.allclose(p.grad, g / world, atol=1e-6)
+    # --- gradient accumulation: two micro-batches, the first under no_sync(); equals the gradient of the summed loss ----------
+    x2, y2 = torch.randn(16, 6), torch.randn(16, 3)
+    flat.zero_()
+    before = flat.collectives
+    with flat.no_sync():
+        (model(x) - y).square().mean().backward()
+    assert flat.collectives == before  # nothing launched while accumulating
+    (model(x2) - y2).square().mean().backward()
+    assert flat.allreduce(ctx) == len(flat.buckets)
+    for p2 in model2.parameters():
+        p2.grad = None
+    ((model2(x) - y).square().mean() + (model2(x2) - y2).square().mean()).backward()
+    for p, p2 in zip(model.parameters(), model2.parameters()):
+        g = p2.grad.clone()
+        dist.all_reduce(g)
+        assert torch.allclose(p.grad, g / world, atol=1e-6)
+    # --- a second backward into an armed step (no no_sync) must not be silently mixed into in-flight buckets -------------------
+    flat.zero_()
+    (model(x) - y).square().mean().backward()
+    try:
+        (model(x2) - y2).square().mean().backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    assert raised
+    flat.allreduce(ctx)
+    # --- gradients zeroed some other way (optimizer.zero_grad(set_to_none=False) keeps the views): the next step still reduces --
+    for p in model.parameters():
+        p.grad.zero_()
+    before = flat.collectives
+    (model(x) - y).square().mean().backward()
+    assert flat.allreduce(ctx) == len(flat.buckets) and flat.collectives == before + len(flat.buckets)
+    for p2 in model2.parameters():
+        p2.grad = None
     (model2(x) - y).square().mean().backward()
     for p, p2 in zip(model.parameters(), model2.parameters()):
         g = p2.grad.clone()
