@@ -40,173 +40,13 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "gw_device.hpp"
-#include "gw_internal.hpp"
+#include "gw_edge16.hpp"
 
 using namespace gw;
+using namespace gw16;
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kTileCols = 64;                       // columns (edges) per tile: 4 groups of 16
-constexpr int kGroups = 4;
-constexpr int kHBytes = kGroups * 8 * 1024;         // one tile in the B-operand layout: 4 groups x 8 K-steps x 1 KiB
-constexpr int kStageLd = 260;                       // staging row stride in floats (256 + 4: conflict-free column walks)
-constexpr int kOffH1 = 0;                           // two layer-1 buffers (DMA prefetch of the next tile)
-constexpr int kOffH2 = 2 * kHBytes;                 // layer-2 activations; the staging area reuses it (dead by then)
-constexpr int kOffStage = kOffH2;
-constexpr int kOffGd = kOffStage + kTileCols * kStageLd * 4;
-constexpr int kOffLn = kOffGd + kTileCols * 4;
-constexpr int kOffPar = kOffLn + 8 * kTileCols * 8;    // after [wave <= 8][column] (sum, sum of squares): b_mid, b_out, gamma, beta
-constexpr int kLdsTotal = kOffPar + 5 * 256 * 4;       // ... and b1 (GATHER form)
-static_assert(kTileCols * kStageLd * 4 >= kHBytes, "staging area covers Hbuf2");
-static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
-
-struct Edge16Args {
-  int batch, n_edges, n_dst;
-  int neb;  // edge blocks of 64
-  const int* src;
-  const int* dst;
-  int n_proj;
-  const float* p_ptr[3];
-  int p_rows_pb[3];
-  int p_ld[3];
-  int p_kind[3];  // 0: row = src[k], 1: dst[k], 2: k
-  const float* b1;
-  const char* w_raw;  // packed W_e (layer-1 slice of the raw edge operand), edge16_l1_kernel only
-  const char* w_mid;
-  const float* b_mid;
-  const char* w_out;
-  const float* b_out;
-  const float* gamma;
-  const float* beta;
-  // residual e: fp32 rows (res_ptr) or bf16 edge tiles (res_tiles); exactly one is set
-  const float* res_ptr;
-  int res_rows_pb;
-  int res_ld;
-  const char* res_tiles;
-  int res_tiles_shared;  // the residual tiles are one set shared by the batch (cached edge embeddings of encoder / decoder / block 0)
-  const char* e_tiles;   // raw edge operand of edge16_l1_kernel (== res_tiles in the forecaster)
-  int e_tiles_shared;
-  float* e_out;         // fp32 rows [batch * n_edges, 256] or null
-  char* e_out_tiles;    // bf16 edge tiles or null
-  float* agg;
-  float* carry;  // deterministic segment sums: per-tile carry records (gw_internal.hpp), NULL = atomics; 4-wave kernel only
-  char* h1g;  // workspace: layer-1 activations, [batch * neb tiles][4 groups][8 K-steps][64 lanes][8 bf16]
-  int skip;                 // tuning builds only (GW_EDGE16_SKIP): 1 = no aggregate writes
-  unsigned long long* dbg;  // gw_debug_timestamps(kind 3): phase clocks of each workgroup's third tile
-  int dbg_cap;
-};
-
-__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
-
-__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
-  bf16x4 r;
-  r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
-  return r;
-}
-__device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
-  bf16x8 r;
-  r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
-  r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
-  return r;
-}
-__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
-
-// x + (x of lane ^ 16) + (x of lane ^ 32) + (x of lane ^ 48): the sum over the four 16-lane rows, i.e. over the q index of
-// the accumulator layout, on the gfx950 lane-swap instructions (v_permlane16_swap swaps the odd rows of its first operand
-// with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second): two
-// VALU operations per step instead of a ds_bpermute round trip through the LDS pipeline.
-__device__ __forceinline__ float sum_rows(float x) {
-  const unsigned u = __float_as_uint(x);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  const unsigned v = __float_as_uint(t);
-  const auto r2 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
-}
-
-// B fragments of one 16-column group: 8 K-steps x 16 bytes per lane, all reads issued back to back
-__device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* __restrict__ hbuf_g, int lane) {
-#pragma unroll
-  for (int s = 0; s < 8; ++s) bf[s] = *(const bf16x8*)(hbuf_g + s * 1024 + lane * 16);
-}
-// One resident layer on one 16-column group: acc[t] (RT row tiles of this wave) += W[tile t][K-step s] . B[s].
-// The MFMAs are written as asm with the weight fragment constrained to an accumulation register ("a"): the weight
-// registers then live in the AGPR half of the file for the whole kernel and feed the matrix cores from there.  Left to
-// itself the allocator treats AGPRs as spill space and copies every fragment back to a VGPR before use (~700 copies per
-// tile, measured).  Inline asm is opaque to the hazard recogniser, so the wait states it would insert are explicit:
-// before the first MFMA (accumulator written by a VALU move) and after the last one (accumulator read by VALU code).
-// An accumulator is touched by every 4th MFMA at most (RT = 2: even and odd K-steps accumulate separately and are added
-// at the end), as in the round-1 kernel.
-__device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
-}
-__device__ __forceinline__ void layer_group(f32x4 (&acc)[4], const bf16x8 (&w)[4][8], const bf16x8 (&bf)[8]) {
-  asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) mfma_a(acc[t], w[t][s], bf[s]);
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-}
-__device__ __forceinline__ void layer_group(f32x4 (&acc)[2], const bf16x8 (&w)[2][8], const bf16x8 (&bf)[8]) {
-  f32x4 odd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]));
-#pragma unroll
-  for (int s = 0; s < 8; s += 2) {
-    mfma_a(acc[0], w[0][s], bf[s]);
-    mfma_a(acc[1], w[1][s], bf[s]);
-    mfma_a(odd[0], w[0][s + 1], bf[s + 1]);
-    mfma_a(odd[1], w[1][s + 1], bf[s + 1]);
-  }
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]));
-  acc[0] += odd[0];
-  acc[1] += odd[1];
-}
-// The same layer with the B fragments read from LDS in two halves of 4 K-steps (16 fragment registers instead of 32: the
-// 8-wave kernel has 128 VGPRs beside its 128 weight registers); the partner wave on the SIMD covers the second LDS latency.
-__device__ __forceinline__ void layer_group_lds(f32x4 (&acc)[2], const bf16x8 (&w)[2][8], const char* __restrict__ hbuf_g, int lane) {
-  f32x4 odd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  bf16x8 bf[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bf[s] = *(const bf16x8*)(hbuf_g + (4 * h + s) * 1024 + lane * 16);
-    asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
-#pragma unroll
-    for (int s = 0; s < 4; s += 2) {
-      mfma_a(acc[0], w[0][4 * h + s], bf[s]);
-      mfma_a(acc[1], w[1][4 * h + s], bf[s]);
-      mfma_a(odd[0], w[0][4 * h + s + 1], bf[s + 1]);
-      mfma_a(odd[1], w[1][4 * h + s + 1], bf[s + 1]);
-    }
-    // the fragment registers are rewritten by the next half's LDS reads: keep those behind the MFMAs that read them
-    asm volatile("s_nop 7" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
-  }
-  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(odd[0]), "+v"(odd[1]));
-  acc[0] += odd[0];
-  acc[1] += odd[1];
-}
-__device__ __forceinline__ void layer_group_lds(f32x4 (&acc)[4], const bf16x8 (&w)[4][8], const char* __restrict__ hbuf_g, int lane) {
-  bf16x8 bf[8];
-  load_frags(bf, hbuf_g, lane);
-  layer_group(acc, w, bf);
-}
-
-// unit u of XCD x -> (edge block, batch element); workgroups / loop iterations with u >= n_units have nothing to do
-struct TileWalk {
-  int eb_start, n_units;
-};
-__device__ __forceinline__ TileWalk tile_walk(int xcd, int neb, int batch) {
-  const int eb_base = neb / 8, eb_rem = neb % 8;
-  TileWalk w;
-  w.eb_start = xcd * eb_base + (xcd < eb_rem ? xcd : eb_rem);
-  w.n_units = (eb_base + (xcd < eb_rem ? 1 : 0)) * batch;
-  return w;
-}
 
 // Launch 1a: one workgroup per EDGE BLOCK (wave = 16-column group), all batch elements in turn.  Eight lanes read one
 // 128-byte line of a row (features 32 s .. 32 s + 31), so an instruction touches 8 full cache lines; lane piece p = lane & 7
@@ -924,6 +764,24 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     else rc = rt ? launch_resident(edge16_kernel<4, true, false>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, false>, 256, n_wg, a, stream);
     if (rc != GW_OK || !deterministic) return rc;
     return segment_fixup_launch((int64_t)batch * a.neb, a.carry, agg, stream);
+  }
+  // team-pipelined form (gw_edge16t.hip): residual as bf16 tiles, atomics mode; the gather form needs one or two per-sample tables
+  static const int team = GW_TUNE("GW_EDGE16_TEAM", 1);
+  if (team != 0 && rt) {
+    int n_dyn = 0, n_shared = 0;
+    for (int p = 0; p < a.n_proj; ++p) (a.p_rows_pb[p] != 0 ? n_dyn : n_shared) += 1;
+    if (!ga || n_dyn == 1 || n_dyn == 2) {
+      // chunk = batch elements of one edge block a workgroup walks in a row: as many as leave every workgroup >= 16 units
+      int bc = 1;
+      if (ga && n_shared > 0)
+        for (int d = 1; d <= batch; ++d)
+          if (batch % d == 0 && (long long)a.neb * (batch / d) >= 16ll * n_wg) bc = d;
+      static const int bc_force = GW_TUNE("GW_EDGE16_BC", 0);
+      if (bc_force > 0 && batch % bc_force == 0) bc = bc_force;
+      a.bc = bc;
+      a.nchunk = batch / bc;
+      return edge16t_launch(&a, ga, n_wg, stream);
+    }
   }
   if (ga) return rt ? launch_resident(edge16_kernel<8, true, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, true>, 512, n_wg, a, stream);
   return rt ? launch_resident(edge16_kernel<8, true, false>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, false>, 512, n_wg, a, stream);

@@ -1,0 +1,497 @@
+// gw_edge16t.hip - team-pipelined form of the bf16 edge update with on-chip weights (BASELINE.json configs[2]).
+//
+//   e'[c] = LayerNorm(W_out . relu(W_mid . relu(z1[c]) + b_mid) + b_out) + e[c],   agg[dst(c)] += e'[c]
+//   (graph_net_block.py:131-137 + the scatter_sum of :188; z1 = layer-1 pre-activations, see gw_edge16.hip)
+//
+// The lock-step kernel of gw_edge16.hip walks every 64-edge tile through gather | middle layer | output layer | LayerNorm |
+// segment sums with all 8 waves in the same phase: its phase clocks (profiles/r02_edge16_timeline_*.log) show ~4 k of the
+// 16-21 k cycles of a tile on the matrix cores - while the waves run LayerNorm or walk segments the MFMA pipe idles, and while
+// they issue MFMAs the vector ALU / LDS / memory pipes idle.  Here the workgroup's 8 waves form two TEAMS with one matrix each:
+//
+//     team A = waves 0-3 (one per SIMD): W_mid resident in AGPRs (rows 64 w ..), produces Hbuf2 from Hbuf1, and prepares
+//              Hbuf1 of the tile after (GATHER: relu(b1 + sum of projected rows); else LDS-DMA of the layer-1 tiles a
+//              previous launch left in the workspace);
+//     team B = waves 4-7 (the other wave of each SIMD): W_out resident, output layer, LayerNorm, residual, e' tile store,
+//              staging for the segment sums.
+//
+// A step of the pipeline is two half-steps separated by workgroup barriers; in each half one team is on the matrix pipe and the
+// other on the vector / LDS / memory pipes of the same SIMDs:
+//
+//     half 1 (s):   A: middle layer of tile s   (Hbuf1 -> Hbuf2)         B: LayerNorm + residual + staging of tile s - 1
+//     half 2 (s):   A: segment sums of tile s - 1 (columns 0..31),        B: segment sums of tile s - 1 (columns 32..63),
+//                      then Hbuf1 of tile s + 1                              then output layer of tile s (Hbuf2 -> registers)
+//
+// so three tiles are in flight per workgroup.  Every buffer has ONE producer half-step and ONE consumer half-step with a
+// barrier between them (Hbuf1: A.h2 -> A.h1; Hbuf2: A.h1 -> B.h2; LayerNorm partial sums: B.h2 -> B.h1; staged tile: B.h1 ->
+// both .h2), so none is double buffered.  Tiles are walked XCD-aware as in gw_edge16.hip, and batch-innermost PER WORKGROUP in
+// chunks of `bc` batch elements of one edge block: what an edge block shares across the batch (row indices, the cached
+// per-edge products We.e + b1 of encoder / decoder / first processor block) is fetched once per chunk and kept in registers
+// (as fp16 pairs: 11 significant bits in front of a bf16 rounding).
+// The residual e comes from bf16 edge tiles; segment sums meet in fp32 atomics where a run crosses a tile or the middle of
+// one (the deterministic mode stays on the lock-step 4-wave kernel).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "gw_edge16.hpp"
+
+using namespace gw;
+using namespace gw16;
+
+namespace {
+
+constexpr int kT_H1 = 0;
+constexpr int kT_H2 = kHBytes;
+constexpr int kT_Stage = 2 * kHBytes;
+constexpr int kT_Gd = kT_Stage + kTileCols * kStageLd * 4;  // destination rows of 4 tiles in flight (ring)
+constexpr int kT_Ln = kT_Gd + 4 * kTileCols * 4;            // [team-B wave][column] (sum, sum of squares)
+constexpr int kT_Par = kT_Ln + 4 * kTileCols * 8;           // b_mid, b_out, gamma, beta, b1
+constexpr int kT_Total = kT_Par + 5 * 256 * 4;
+static_assert(kT_Total <= 160 * 1024, "LDS budget of one CU");
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// LDS traffic of this wave is complete, then the workgroup barrier.  Not __syncthreads(): its release fence also drains the
+// vector-memory counter, i.e. the residual / index loads and the LDS-DMA that are meant to stay in flight across the barrier.
+__device__ __forceinline__ void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct TileId {
+  int eb, b;
+};
+
+// NDYN (GATHER form): projected tables with one row set per batch element (1: decoder - P_s; 2: first processor block - P_s, P_d);
+// the other projected tables are shared by the batch and cached per chunk.
+template <bool GATHER, int NDYN>
+__global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool team_b = wave >= 4;
+  const int tw = wave & 3;              // wave within its team
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const int f0 = 64 * tw + 4 * q;       // this lane's features of its team's layer: f0 + 16 t + r, t < 4
+  const int s0 = 2 * tw;                // K-steps of the B layout the wave's 4 row tiles fill: s0, s0 + 1
+
+  // ---- resident weights: rows 64 tw .. of the team's matrix, all 8 K-steps (packed stream: [s][16 tiles][lane][8]) ----
+  bf16x8 wr[4][8];
+  {
+    const char* wsrc = team_b ? a.w_out : a.w_mid;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wr[t][s] = *(const bf16x8*)(wsrc + ((size_t)(s * 16 + 4 * tw + t) * 64 + lane) * 16);
+  }
+  if (threadIdx.x < 256) {
+    float* par_w = (float*)(lds + kT_Par);
+    const int i = threadIdx.x;
+    par_w[i] = a.b_mid[i];
+    par_w[256 + i] = a.b_out[i];
+    par_w[512 + i] = a.gamma[i];
+    par_w[768 + i] = a.beta[i];
+    par_w[1024 + i] = a.b1[i];
+  }
+  const float* const par_l = (const float*)(lds + kT_Par) + f0;  // this lane's slice: + 256 * which + 16 * t
+  char* const h1 = lds + kT_H1;
+  char* const h2 = lds + kT_H2;
+  float* const stage = (float*)(lds + kT_Stage);
+  int* const gdl = (int*)(lds + kT_Gd);
+  float* const lnp = (float*)(lds + kT_Ln);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+  // ---- tile list of this workgroup: XCD x = workgroup & 7 owns a contiguous range of edge blocks; unit = (edge block, chunk
+  // of bc batch elements); the workgroups of an XCD take units round-robin and walk the bc samples of a unit in a row ----
+  const int slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const TileWalk twk = tile_walk(blockIdx.x & 7, a.neb, a.nchunk);
+  const int n_my_units = twk.n_units > slot ? (twk.n_units - slot + nslot - 1) / nslot : 0;
+  const int n = n_my_units * a.bc;
+  auto tile_at = [&](int i) -> TileId {
+    const int k = i / a.bc, bi = i - k * a.bc;
+    const int u = slot + k * nslot;
+    const int ebl = u / a.nchunk, c = u - ebl * a.nchunk;
+    return TileId{twk.eb_start + ebl, c * a.bc + bi};
+  };
+
+  // =========================================== team A: Hbuf1 of a tile ===============================================
+  // GATHER: thread -> (column c of 32, 16-byte piece) and two column passes; 8 lanes read one 128-byte line of a projected row.
+  const int gpiece = threadIdx.x & 7;
+  const int gcol = (threadIdx.x >> 3) & 31;
+  int gidx[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  half2_t zc[2][8][2];  // per pass and K-step: b1 + rows of the batch-shared tables (fp16 pairs), valid for `cached_eb`
+#pragma unroll
+  for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) zc[cp][s][0] = zc[cp][s][1] = half2_t{(_Float16)0.f, (_Float16)0.f};
+  int cached_eb = -1;
+
+  auto prep_chunk = [&](int eb) {  // new edge block: row indices + the batch-shared part of layer 1
+    int gp4 = 4 * gpiece;
+    asm volatile("" : "+v"(gp4));
+    const float* b1l = (const float*)(lds + kT_Par) + 1024 + gp4;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      const int kr = eb * kTileCols + 32 * cp + gcol;
+      const int k = kr < a.n_edges ? kr : a.n_edges - 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        gidx[cp][p] = p < a.n_proj ? (a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k)) : 0;
+    }
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      f32x4 z[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) z[s] = *(const f32x4*)(b1l + 32 * s);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (p < a.n_proj && a.p_rows_pb[p] == 0) {
+          const float* row = a.p_ptr[p] + (size_t)gidx[cp][p] * (size_t)a.p_ld[p] + gp4;
+          f32x4 v[8];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) z[s] += v[s];
+        }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        zc[cp][s][0] = half2_t{(_Float16)z[s].x, (_Float16)z[s].y};
+        zc[cp][s][1] = half2_t{(_Float16)z[s].z, (_Float16)z[s].w};
+      }
+    }
+    cached_eb = eb;
+  };
+  auto gather_store = [&](const f32x4 (&z)[8], int cp, bool cvalid) {
+    const int col = 32 * cp + gcol;
+    char* out = h1 + (col >> 4) * 8192 + (16 * (gpiece & 3) + (col & 15)) * 16 + (gpiece >> 2) * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      bf16x4 o4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
+      *(bf16x4*)(out + s * 1024) = o4;
+    }
+  };
+  auto cache_add = [&](f32x4 (&z)[8], int cp) {  // z += the cached batch-shared part of this column pass
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      z[s] += f32x4{(float)zc[cp][s][0][0], (float)zc[cp][s][0][1], (float)zc[cp][s][1][0], (float)zc[cp][s][1][1]};
+  };
+  // The gather of a tile is split so that its first load round trip passes under other work: gather_issue0 requests the rows
+  // of column pass 0 (first per-sample table) at the END of half 1 - in flight across the barrier and the segment sums of half
+  // 2 - gather_finish completes pass 0 and runs pass 1.
+  int dyn[2] = {0, 0};  // per-sample tables of this launch (rows_pb != 0): exactly NDYN of them (the host checks)
+  if (GATHER) {
+    int nd = 0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      if (p < a.n_proj && a.p_rows_pb[p] != 0 && nd < NDYN) dyn[nd++] = p;
+  }
+  auto row_of = [&](TileId t, int p, int cp) -> const float* {
+    int gp4 = 4 * gpiece;
+    asm volatile("" : "+v"(gp4));
+    return a.p_ptr[p] + ((size_t)t.b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
+  };
+  auto load_rows = [&](f32x4 (&x)[8], const float* row) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = ldg4(row + 32 * s);
+  };
+  auto gather_issue0 = [&](TileId t, f32x4 (&x0)[8]) {
+    if (t.eb != cached_eb) prep_chunk(t.eb);
+    load_rows(x0, row_of(t, dyn[0], 0));
+  };
+  auto gather_finish = [&](TileId t, f32x4 (&x0)[8]) {
+    const bool v0 = t.eb * kTileCols + gcol < a.n_edges, v1 = t.eb * kTileCols + 32 + gcol < a.n_edges;
+    f32x4 x1[8];
+    if constexpr (NDYN == 2) {
+      load_rows(x1, row_of(t, dyn[1], 0));
+#pragma unroll
+      for (int s = 0; s < 8; ++s) x0[s] += x1[s];
+    }
+    cache_add(x0, 0);
+    gather_store(x0, 0, v0);
+    load_rows(x0, row_of(t, dyn[0], 1));
+    if constexpr (NDYN == 2) {
+      load_rows(x1, row_of(t, dyn[1], 1));
+#pragma unroll
+      for (int s = 0; s < 8; ++s) x0[s] += x1[s];
+    }
+    cache_add(x0, 1);
+    gather_store(x0, 1, v1);
+  };
+  auto tile_row = [&](TileId t) -> size_t { return (size_t)(t.b * a.neb + t.eb); };
+  auto prep_dma_issue = [&](TileId t) {  // 32 KiB of layer-1 activations -> Hbuf1: 8 LDS-DMA pieces of 1 KiB per team-A wave
+    const char* src = a.h1g + tile_row(t) * kHBytes;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int piece = 8 * tw + i;
+      glds16_asm_s((const float*)(src + piece * 1024), (unsigned)lane * 16u,
+                   __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kT_H1 + piece * 1024)));
+    }
+  };
+  auto publish_dst = [&](TileId t, int ring) {  // (wave 0) destination rows of the tile's 64 columns, for its segment sums
+    const int kr = t.eb * kTileCols + lane;
+    gdl[ring * kTileCols + lane] = kr < a.n_edges ? t.b * a.n_dst + ldgi(a.dst + kr) : -1;
+  };
+
+  // ===================================== both teams: segment sums of a staged tile ====================================
+  // Thread (f, h) owns feature f = thread & 255 for the columns 32 h .. 32 h + 31 (h = team).  Segment ends are the same for
+  // every thread: lane i compares column i's destination with column i + 1's, the ballot is a 64-bit scalar mask, the walk
+  // tests one bit per column.  A segment wholly inside the thread's columns is complete: plain store.  The first and the last
+  // one may continue elsewhere (neighbouring tiles, or across the middle of this one) and are added with atomics.
+  auto segment_sums = [&](TileId t, int ring) {
+    constexpr int COLS = 32;
+    int f = threadIdx.x & 255;
+    asm volatile("" : "+v"(f));
+    const int hh = team_b ? 1 : 0;
+    const int c0 = hh * COLS;
+    float vv[COLS];
+#pragma unroll
+    for (int i = 0; i < COLS; ++i) vv[i] = stage[(c0 + i) * kStageLd + f];
+    const int gdv = gdl[ring * kTileCols + lane];
+    const int gdn = gdl[ring * kTileCols + (lane < kTileCols - 1 ? lane + 1 : lane)];
+    const unsigned long long ends = __ballot(lane == kTileCols - 1 || gdn != gdv);
+    const bool mid_open = ((ends >> (COLS - 1)) & 1ull) == 0;  // a segment straddles columns 31 | 32
+    const unsigned long long mine = (ends >> c0) | (1ull << (COLS - 1));
+    float run = 0.f;
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < COLS; ++i) {
+      run += vv[i];
+      if (__builtin_expect((mine >> i) & 1ull, 0)) {
+        const int cur = __builtin_amdgcn_readlane(gdv, c0 + i);
+        if (cur >= 0 && GW_SKIP(a) != 1) {
+          float* dstp = a.agg + (size_t)cur * 256 + f;
+          const bool open_lo = first && (hh == 0 || mid_open);
+          const bool open_hi = i == COLS - 1 && (hh == 1 || mid_open);
+          if (open_lo || open_hi) __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else stg1(dstp, run);
+        }
+        first = false;
+        run = 0.f;
+      }
+    }
+    if (a.e_out_tiles != nullptr) {
+      // e' as bf16 edge tiles from the staged tile: wave w packs K-step w of all 4 groups - lane (j, q) holds features
+      // 32 w + 16 (i >> 2) + 4 q + (i & 3) of column 16 g + j - one coalesced 1 KiB store per wave and group
+      const size_t tile = tile_row(t);
+      int so = 32 * wave + 4 * q;
+      asm volatile("" : "+v"(so));
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        const int col = 16 * g + j;
+        const f32x4 lo = *(const f32x4*)(stage + col * kStageLd + so);
+        const f32x4 hi = *(const f32x4*)(stage + col * kStageLd + so + 16);
+        bf16x8 pk = to_bf16x8(lo, hi);
+        if (t.eb * kTileCols + col >= a.n_edges) pk = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *(GW_AS1 bf16x8*)(a.e_out_tiles + (tile * kGroups + g) * 8192 + (size_t)wave * 1024 + (size_t)lane * 16) = pk;
+      }
+    }
+    if (a.e_out != nullptr) {  // e' as fp32 rows from the staged tile (callers that want rows back): 8 rows per wave
+      int l4 = 4 * lane;
+      asm volatile("" : "+v"(l4));
+      const int k0 = t.eb * kTileCols;
+#pragma unroll 4
+      for (int i = 0; i < 8; ++i) {
+        const int col = 8 * wave + i;
+        if (k0 + col < a.n_edges) {
+          const f32x4 v = *(const f32x4*)(stage + col * kStageLd + l4);
+          stg4(a.e_out + ((size_t)t.b * a.n_edges + k0 + col) * 256 + l4, v);
+        }
+      }
+    }
+  };
+
+  if (n == 0) return;  // (uniform for the workgroup: no barrier is skipped by part of it)
+
+  if (!team_b) {
+    // ================================================ team A ========================================================
+    TileId t_next = tile_at(0);
+    f32x4 gx[8];  // GATHER: rows of column pass 0 of the next tile, in flight from the end of half 1
+    if (GATHER) {
+      __syncthreads();  // the parameter block (b1) is visible  [team B meets this barrier below]
+      gather_issue0(t_next, gx);
+      gather_finish(t_next, gx);
+    } else {
+      __syncthreads();
+      prep_dma_issue(t_next);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (tw == 0) publish_dst(t_next, 0);
+    TileId t_cur = t_next, t_prev = t_next;
+#pragma unroll 1
+    for (int s = 0; s <= n; ++s) {
+      t_prev = t_cur;
+      t_cur = t_next;
+      if (s + 1 < n) t_next = tile_at(s + 1);
+      const bool stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;  // gw_debug_timestamps(kind 3): phase clocks
+      unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+      if (stamp) ts[0] = gw_clock();
+      team_barrier();  // (alpha) Hbuf1 of tile s complete; staged tile s - 2 free
+      if (stamp) ts[1] = gw_clock();
+      if (s < n) {
+        // ---- middle layer of tile s: Hbuf1 -> Hbuf2 ----
+        bf16x8 bfr[8];
+        load_frags(bfr, h1, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+          f32x4 acc[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = *(const f32x4*)(par_l + 16 * t);  // b_mid (LDS: no registers held across groups)
+          layer_group(acc, wr, bfr);
+          if (g + 1 < kGroups) load_frags(bfr, h1 + (g + 1) * 8 * 1024, lane);
+          *(bf16x8*)(h2 + ((g * 8 + s0) * 64 + lane) * 16) = to_bf16x8(relu4(acc[0]), relu4(acc[1]));
+          *(bf16x8*)(h2 + ((g * 8 + s0 + 1) * 64 + lane) * 16) = to_bf16x8(relu4(acc[2]), relu4(acc[3]));
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      const bool has_next = s + 1 < n;
+      if (GATHER && has_next) gather_issue0(t_next, gx);  // (registers only: Hbuf1 is still being read by the other waves)
+      if (stamp) ts[2] = gw_clock();
+      team_barrier();  // (beta) Hbuf2 of tile s and the staged tile s - 1 complete; Hbuf1 free
+      if (stamp) ts[3] = gw_clock();
+      if (!GATHER && has_next) prep_dma_issue(t_next);  // in flight under the segment sums
+      if (s >= 1) segment_sums(t_prev, (s - 1) & 3);
+      if (stamp) ts[4] = gw_clock();
+      if (has_next) {
+        if (GATHER) gather_finish(t_next, gx);
+        if (tw == 0) publish_dst(t_next, (s + 1) & 3);
+        if (!GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (stamp) {
+        ts[5] = gw_clock();
+        if (threadIdx.x == 0)
+          for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = ts[i];
+      }
+    }
+  } else {
+    // ================================================ team B ========================================================
+    __syncthreads();  // (pairs with team A's barrier before its first gather / DMA)
+    f32x4 o[kGroups][4];
+    bf16x8 rest0[kGroups];  // residual, K-step s0 (feature tiles 0, 1 of this wave); K-step s0 + 1 is requested in half 1
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      rest0[g] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    TileId t_next = tile_at(0), t_cur = t_next, t_prev = t_next;
+#pragma unroll 1
+    for (int s = 0; s <= n; ++s) {
+      t_prev = t_cur;
+      t_cur = t_next;
+      if (s + 1 < n) t_next = tile_at(s + 1);
+      const bool stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;
+      unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+      if (stamp) ts[0] = gw_clock();
+      team_barrier();  // (alpha) LayerNorm partial sums of tile s - 1 visible; staged tile s - 2 free
+      if (stamp) ts[1] = gw_clock();
+      if (s >= 1) {
+        // ---- LayerNorm (eps 1e-5, biased variance), residual, staging of tile s - 1 ----
+        // v = (o - mean) rstd gamma + beta + e = o (rstd gamma) + ((-mean rstd) gamma + (beta + e)), one feature tile (16 rows)
+        // at a time for all 4 groups: the accumulators of a tile die as it is staged, and the second half of the residual is
+        // requested after the first tile - its registers take the place of the dead accumulators.
+        const int k0 = t_prev.eb * kTileCols;
+        float ga[kGroups], gb[kGroups];
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+          const float2 pr = *(const float2*)(lnp + (q * kTileCols + 16 * g + j) * 2);  // row q reads team-B wave q's partial sums
+          const float s1 = sum_rows(pr.x);
+          const float s2 = sum_rows(pr.y);
+          const float mean = s1 * (1.0f / 256.0f);
+          const float var = fmaxf(s2 * (1.0f / 256.0f) - mean * mean, 0.f);
+          ga[g] = 1.0f / sqrtf(var + 1e-5f);
+          gb[g] = -mean * ga[g];
+        }
+        bf16x8 rest1[kGroups];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t == 1) {
+            const size_t rtile = a.res_tiles_shared ? (size_t)t_prev.eb : tile_row(t_prev);
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+              rest1[g] = *(const GW_AS1 bf16x8*)(a.res_tiles + (rtile * kGroups + g) * 8192 + (size_t)(s0 + 1) * 1024 + (size_t)lane * 16);
+          }
+          const f32x4 gm = *(const f32x4*)(par_l + 512 + 16 * t);
+          const f32x4 bt = *(const f32x4*)(par_l + 768 + 16 * t);
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g) {
+            const bf16x8 rr = t < 2 ? rest0[g] : rest1[g];
+            const f32x4 rv = (t & 1) ? f32x4{(float)rr[4], (float)rr[5], (float)rr[6], (float)rr[7]}
+                                     : f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(o[g][t][r], ga[g] * gm[r], fmaf(gb[g], gm[r], bt[r] + rv[r]));
+            *(f32x4*)(stage + (16 * g + j) * kStageLd + f0 + 16 * t) = v;
+          }
+        }
+        (void)k0;
+      }
+      if (stamp) ts[2] = gw_clock();
+      team_barrier();  // (beta) Hbuf2 of tile s and the staged tile s - 1 complete
+      if (stamp) ts[3] = gw_clock();
+      if (s >= 1) segment_sums(t_prev, (s - 1) & 3);
+      if (stamp) ts[4] = gw_clock();
+      if (s < n) {
+        // ---- output layer of tile s: Hbuf2 -> registers, LayerNorm partial sums ----
+        bf16x8 bfr[8];
+        load_frags(bfr, h2, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) o[g][t] = *(const f32x4*)(par_l + 256 + 16 * t);  // b_out
+          layer_group(o[g], wr, bfr);
+          if (g + 1 < kGroups) load_frags(bfr, h2 + (g + 1) * 8 * 1024, lane);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s1 += o[g][t][r];
+              s2 = fmaf(o[g][t][r], o[g][t][r], s2);
+            }
+          s1 = sum_rows(s1);
+          s2 = sum_rows(s2);
+          if (q == 0) *(float2*)(lnp + (tw * kTileCols + 16 * g + j) * 2) = float2{s1, s2};
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ---- residual of tile s (bf16 edge tiles: the lane's own 16-byte slot of K-step s0): requested here, used after the
+        // next barrier - in flight across it ----
+        const size_t rtile = a.res_tiles_shared ? (size_t)t_cur.eb : tile_row(t_cur);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g)
+          rest0[g] = *(const GW_AS1 bf16x8*)(a.res_tiles + (rtile * kGroups + g) * 8192 + (size_t)s0 * 1024 + (size_t)lane * 16);
+      }
+      if (stamp) {
+        ts[5] = gw_clock();
+        if (threadIdx.x == 256)
+          for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 16 + 8 + i] = ts[i];
+      }
+    }
+  }
+}
+
+template <typename K>
+int launch_team(K kernel, int n_wg, const Edge16Args& a, void* stream) {
+  static DeviceOnce once;  // per template instantiation and device
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kT_Total);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)n_wg), dim3(512), kT_Total, (hipStream_t)stream, a);
+  return check_launch("edge16t_kernel launch");
+}
+
+}  // namespace
+
+namespace gw {
+
+int edge16t_launch(const void* edge16_args, bool gather, int n_wg, void* stream) {
+  const Edge16Args& a = *(const Edge16Args*)edge16_args;
+  if (!gather) return launch_team(edge16t_kernel<false, 1>, n_wg, a, stream);
+  int n_dyn = 0;
+  for (int p = 0; p < a.n_proj; ++p) n_dyn += a.p_rows_pb[p] != 0 ? 1 : 0;
+  if (n_dyn == 1) return launch_team(edge16t_kernel<true, 1>, n_wg, a, stream);
+  if (n_dyn == 2) return launch_team(edge16t_kernel<true, 2>, n_wg, a, stream);
+  return set_error(GW_E_UNSUPPORTED, "edge16t: the gather form takes one or two per-sample projected tables");
+}
+
+}  // namespace gw

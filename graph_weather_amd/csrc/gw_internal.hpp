@@ -131,6 +131,9 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
                   float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, bool deterministic, void* stream);
 size_t edge16_workspace_needed(int32_t batch, int32_t n_edges, const gw_operand* e_in, bool deterministic);  // layer-1 tiles (if a
                                                                                   // separate launch makes them) + carry records
+// team-pipelined form of the resident kernel (gw_edge16t.hip): residual as bf16 tiles, atomics mode; gather = layer 1 is a
+// gather-add done inside the kernel (every operand projected), else the layer-1 tiles come from the workspace
+int edge16t_launch(const void* edge16_args /* gw16::Edge16Args */, bool gather, int n_wg, void* stream);
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                          void* stream);
 
