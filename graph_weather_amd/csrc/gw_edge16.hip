@@ -718,7 +718,10 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   a.b_out = w->b_out;
   a.gamma = w->ln_gamma;
   a.beta = w->ln_beta;
-  if (e_res->layout == GW_LAYOUT_EDGE_TILES_BF16) {
+  const bool no_res = e_res->k == 0 || !e_res->ptr;  // no residual: the caller pre-added the segment sums of e (team kernel only)
+  if (no_res) {
+    if (e_out || e_out_tiles) return set_error(GW_E_UNSUPPORTED, "edge16: e' was requested without its residual operand");
+  } else if (e_res->layout == GW_LAYOUT_EDGE_TILES_BF16) {
     a.res_tiles = (const char*)e_res->ptr;
     a.res_tiles_shared = e_res->rows_per_batch == 0;
   } else {
@@ -736,6 +739,8 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   {
     static const int skip = GW_TUNE("GW_EDGE16_SKIP", 0);
     a.skip = skip;
+    static const int tune = GW_TUNE("GW_EDGE16_TUNE", 0);
+    a.tune = tune;
   }
 #endif
   if (g_dbg != nullptr && g_dbg_kind == 3) {
@@ -758,19 +763,21 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   static const int nw = GW_TUNE("GW_EDGE16_NW", 8);
   const bool rt = a.res_tiles != nullptr;
   const bool ga = !raw_e && fuse_gather;  // layer 1 gathered inside the resident kernel
+  static const int team = GW_TUNE("GW_EDGE16_TEAM", 1);
   int rc;
+  if (no_res && (nw == 4 || deterministic || team == 0))
+    return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual runs on the team-pipelined kernel only (atomics mode)");
   if (nw == 4 || deterministic) {  // the deterministic walk is a whole-tile walk per thread: the 4-wave form
     if (ga) rc = rt ? launch_resident(edge16_kernel<4, true, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, true>, 256, n_wg, a, stream);
     else rc = rt ? launch_resident(edge16_kernel<4, true, false>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, false>, 256, n_wg, a, stream);
     if (rc != GW_OK || !deterministic) return rc;
     return segment_fixup_launch((int64_t)batch * a.neb, a.carry, agg, stream);
   }
-  // team-pipelined form (gw_edge16t.hip): residual as bf16 tiles, atomics mode; the gather form needs one or two per-sample tables
-  static const int team = GW_TUNE("GW_EDGE16_TEAM", 1);
-  if (team != 0 && rt) {
+  // team-pipelined form (gw_edge16t.hip): residual as bf16 tiles or none, atomics mode; the gather form needs one or two per-sample tables
+  if (team != 0 && (rt || no_res) && nw != 4 && !deterministic) {
     int n_dyn = 0, n_shared = 0;
     for (int p = 0; p < a.n_proj; ++p) (a.p_rows_pb[p] != 0 ? n_dyn : n_shared) += 1;
-    if (!ga || n_dyn == 1 || n_dyn == 2) {
+    if (!ga || n_dyn == 1) {  // (two per-sample tables: the lock-step kernel below is the faster one, see gw_edge16t.hip)
       // chunk = batch elements of one edge block a workgroup walks in a row: as many as leave every workgroup >= 16 units
       int bc = 1;
       if (ga && n_shared > 0)
@@ -783,6 +790,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
       return edge16t_launch(&a, ga, n_wg, stream);
     }
   }
+  if (no_res) return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual needs exactly one per-sample projected table");
   if (ga) return rt ? launch_resident(edge16_kernel<8, true, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, true>, 512, n_wg, a, stream);
   return rt ? launch_resident(edge16_kernel<8, true, false>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, false>, 512, n_wg, a, stream);
 }

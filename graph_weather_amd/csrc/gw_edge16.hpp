@@ -62,6 +62,7 @@ struct Edge16Args {
   char* h1g;  // workspace: layer-1 activations, [batch * neb tiles][4 groups][8 K-steps][64 lanes][8 bf16]
   int bc, nchunk;           // team kernel (gw_edge16t.hip): batch elements of one edge block a workgroup handles in a row (divides
                             // batch) and chunks per edge block (batch / bc): per-edge data shared by the batch is fetched once per chunk
+  int tune;                 // tuning builds only (GW_EDGE16_TUNE): A/B switches of the team kernel
   int skip;                 // tuning builds only (GW_EDGE16_SKIP): 1 = no aggregate writes
   unsigned long long* dbg;  // gw_debug_timestamps(kind 3): phase clocks of each workgroup's third tile
   int dbg_cap;

@@ -47,7 +47,8 @@ constexpr int kT_Stage = 2 * kHBytes;
 constexpr int kT_Gd = kT_Stage + kTileCols * kStageLd * 4;  // destination rows of 4 tiles in flight (ring)
 constexpr int kT_Ln = kT_Gd + 4 * kTileCols * 4;            // [team-B wave][column] (sum, sum of squares)
 constexpr int kT_Par = kT_Ln + 4 * kTileCols * 8;           // b_mid, b_out, gamma, beta, b1
-constexpr int kT_Total = kT_Par + 5 * 256 * 4;
+constexpr int kT_Zc = kT_Par + 5 * 256 * 4;                 // GATHER: cached batch-shared layer-1 part of column pass 1 (fp16), thread private
+constexpr int kT_Total = kT_Zc + 8 * 256 * 8;
 static_assert(kT_Total <= 160 * 1024, "LDS budget of one CU");
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -56,13 +57,74 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 // vector-memory counter, i.e. the residual / index loads and the LDS-DMA that are meant to stay in flight across the barrier.
 __device__ __forceinline__ void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// The value recomputed from here on: keeps cheap lane-derived offsets (lane * 16, ...) from being shared kernel-wide as one
+// long-lived (and then spilled) register - a scratch reload queues behind the wave's stores like any other load.
+__device__ __forceinline__ int fresh(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (fmaxf adds a canonicalising v_max in front)
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// One resident layer of a team wave on the 4 groups of a tile (4 row tiles x 8 K-steps x 4 groups = 128 MFMAs), software
+// pipelined inside the wave.  The team has ONE wave per SIMD, and a wave issues in order: whatever it does between two MFMAs
+// beyond the ~2 issue slots the 16-cycle matrix instruction covers is time the matrix pipe idles (measured: 128 MFMAs with their
+// ~370 other instructions in blocks took 4.3 k cycles, = not overlapped at all).  So every MFMA is followed by at most one
+// small filler:
+//  * slots 0..3 of each half-group (16 MFMAs): one B fragment (ds_read_b128) of the NEXT half-group into the other buffer;
+//  * slots 2..29 of group g: piece m = slot - 2 of the epilogue of group g - 1 (what the caller does with its accumulators:
+//    relu + bf16 pack + LDS store, or LayerNorm partial sums), one or two instructions each;
+//  * slots 28..31: the bias of group g + 1 into its accumulator set (LDS reads straight into the accumulators).
+// Two accumulator sets alternate (a caller that keeps all groups passes 4).  The pieces of the last group run at the end.
+// bias(dst, t): accumulator of row tile t <- bias;  piece(g, m, acc): m = 0 .. 27.
+template <int NSETS, class Bias, class Piece>
+__device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 (&w)[4][8], const char* __restrict__ hin, int lane,
+                                           Bias bias, Piece piece) {
+  bf16x8 fr[2][4];
+  const char* const p0 = hin + fresh(lane) * 16;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fr[0][s] = *(const bf16x8*)(p0 + s * 1024);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) bias(acc[0][t], t);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const int g = h >> 1, hh = h & 1;
+    f32x4 (&ac)[4] = acc[g % NSETS];
+#pragma unroll
+    for (int m16 = 0; m16 < 16; ++m16) {
+      const int ks = m16 >> 2, t = m16 & 3, slot = 16 * hh + m16;
+      mfma_a(ac[t], w[t][4 * hh + ks], fr[h & 1][ks]);
+      if (m16 < 4 && h + 1 < 8)
+        fr[(h + 1) & 1][m16] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + m16 * 1024);
+      if (g > 0 && slot >= 2 && slot < 30) piece(g - 1, slot - 2, acc[(g - 1) % NSETS]);
+      if (slot >= 28 && g + 1 < 4) bias(acc[(g + 1) % NSETS][slot - 28], slot - 28);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  {
+    f32x4 (&ac)[4] = acc[3 % NSETS];
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]));  // MFMA results -> VALU readers
+#pragma unroll
+    for (int m = 0; m < 28; ++m) piece(3, m, ac);
+  }
+}
+
 struct TileId {
   int eb, b;
 };
 
 // NDYN (GATHER form): projected tables with one row set per batch element (1: decoder - P_s; 2: first processor block - P_s, P_d);
 // the other projected tables are shared by the batch and cached per chunk.
-template <bool GATHER, int NDYN>
+// RES: the residual e of graph_net_block.py:135 is added from bf16 edge tiles (true), or not at all (false: callers that only
+// want the aggregate - the decoder - add the segment sums of their batch-shared e into the aggregate buffer beforehand:
+// sum(LN(.) + e) = sum(LN(.)) + sum(e), and sum(e) per destination is the same for every batch element).
+template <bool GATHER, int NDYN, bool RES>
 __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
@@ -92,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     par_w[768 + i] = a.beta[i];
     par_w[1024 + i] = a.b1[i];
   }
-  const float* const par_l = (const float*)(lds + kT_Par) + f0;  // this lane's slice: + 256 * which + 16 * t
+#define par_l ((const float*)(lds + kT_Par) + fresh(f0))  /* this lane's slice: + 256 * which + 16 * t (recomputed per use) */
   char* const h1 = lds + kT_H1;
   char* const h2 = lds + kT_H2;
   float* const stage = (float*)(lds + kT_Stage);
@@ -113,16 +175,33 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     return TileId{twk.eb_start + ebl, c * a.bc + bi};
   };
 
+  // gw_debug_timestamps(kind 3): phase clocks of each workgroup's 4th pipeline step (32 x u64 per workgroup: team A [0, 16),
+  // team B [16, 32)); tuning builds: a.tune bit 0 = no s_setprio around the MFMA phases, bit 1 = no residual loads (zeros)
+  bool stamp = false;
+  const int ts_thread = team_b ? 256 : 0, ts_base = (int)blockIdx.x * 32 + (team_b ? 16 : 0);
+#define GW_TS(i)                                                      \
+  if (stamp) {                                                        \
+    const unsigned long long c_ = gw_clock();                         \
+    if ((int)threadIdx.x == ts_thread) a.dbg[ts_base + (i)] = c_;     \
+  }
+  const bool use_prio = (GW_TUNE_ARG(a) & 1) == 0;
+  const bool use_res = (GW_TUNE_ARG(a) & 2) == 0;
+  const bool t_skip_ln = (GW_TUNE_ARG(a) & 4) != 0;     // (wrong results: timing experiments) team B skips LayerNorm / staging
+  const bool t_skip_a2 = (GW_TUNE_ARG(a) & 8) != 0;     // team A skips its half-2 work (segment sums, gather finish)
+  const bool t_skip_bseg = (GW_TUNE_ARG(a) & 16) != 0;  // team B skips its segment sums
+
   // =========================================== team A: Hbuf1 of a tile ===============================================
   // GATHER: thread -> (column c of 32, 16-byte piece) and two column passes; 8 lanes read one 128-byte line of a projected row.
   const int gpiece = threadIdx.x & 7;
   const int gcol = (threadIdx.x >> 3) & 31;
   int gidx[2][3] = {{0, 0, 0}, {0, 0, 0}};
-  half2_t zc[2][8][2];  // per pass and K-step: b1 + rows of the batch-shared tables (fp16 pairs), valid for `cached_eb`
+  // per column pass and K-step: b1 + rows of the batch-shared tables as fp16 pairs, valid for `cached_eb`; pass 0 in registers,
+  // pass 1 in a thread-private LDS slot (16 + 16 registers would not fit beside the gathered rows)
+  half2_t zc[8][2];
 #pragma unroll
-  for (int cp = 0; cp < 2; ++cp)
-#pragma unroll
-    for (int s = 0; s < 8; ++s) zc[cp][s][0] = zc[cp][s][1] = half2_t{(_Float16)0.f, (_Float16)0.f};
+  for (int s = 0; s < 8; ++s) zc[s][0] = zc[s][1] = half2_t{(_Float16)0.f, (_Float16)0.f};
+  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+  half4_t* const zc1 = (half4_t*)(lds + kT_Zc) + (threadIdx.x & 255);  // [s][thread]: + 256 s
   int cached_eb = -1;
 
   auto prep_chunk = [&](int eb) {  // new edge block: row indices + the batch-shared part of layer 1
@@ -154,8 +233,12 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        zc[cp][s][0] = half2_t{(_Float16)z[s].x, (_Float16)z[s].y};
-        zc[cp][s][1] = half2_t{(_Float16)z[s].z, (_Float16)z[s].w};
+        if (cp == 0) {
+          zc[s][0] = half2_t{(_Float16)z[s].x, (_Float16)z[s].y};
+          zc[s][1] = half2_t{(_Float16)z[s].z, (_Float16)z[s].w};
+        } else {
+          zc1[256 * s] = half4_t{(_Float16)z[s].x, (_Float16)z[s].y, (_Float16)z[s].z, (_Float16)z[s].w};
+        }
       }
     }
     cached_eb = eb;
@@ -173,8 +256,14 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   };
   auto cache_add = [&](f32x4 (&z)[8], int cp) {  // z += the cached batch-shared part of this column pass
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      z[s] += f32x4{(float)zc[cp][s][0][0], (float)zc[cp][s][0][1], (float)zc[cp][s][1][0], (float)zc[cp][s][1][1]};
+    for (int s = 0; s < 8; ++s) {
+      if (cp == 0) {
+        z[s] += f32x4{(float)zc[s][0][0], (float)zc[s][0][1], (float)zc[s][1][0], (float)zc[s][1][1]};
+      } else {
+        const half4_t c = zc1[256 * s];
+        z[s] += f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
+      }
+    }
   };
   // The gather of a tile is split so that its first load round trip passes under other work: gather_issue0 requests the rows
   // of column pass 0 (first per-sample table) at the END of half 1 - in flight across the barrier and the segment sums of half
@@ -199,10 +288,13 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     if (t.eb != cached_eb) prep_chunk(t.eb);
     load_rows(x0, row_of(t, dyn[0], 0));
   };
-  auto gather_finish = [&](TileId t, f32x4 (&x0)[8]) {
-    const bool v0 = t.eb * kTileCols + gcol < a.n_edges, v1 = t.eb * kTileCols + 32 + gcol < a.n_edges;
-    f32x4 x1[8];
+  // part 1 (before the segment sums of half 2): pass 0 -> Hbuf1, and the rows of pass 1 requested - a wave's loads queue behind
+  // its own earlier stores, so every load of the half is issued before the aggregate stores; part 2 (after them): pass 1.
+  // (Both passes in flight from half 1 would need 64 registers across the barrier: measured in the build - it spills.)
+  auto gather_part1 = [&](TileId t, f32x4 (&x0)[8]) {
+    const bool v0 = t.eb * kTileCols + gcol < a.n_edges;
     if constexpr (NDYN == 2) {
+      f32x4 x1[8];
       load_rows(x1, row_of(t, dyn[1], 0));
 #pragma unroll
       for (int s = 0; s < 8; ++s) x0[s] += x1[s];
@@ -210,7 +302,11 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     cache_add(x0, 0);
     gather_store(x0, 0, v0);
     load_rows(x0, row_of(t, dyn[0], 1));
+  };
+  auto gather_part2 = [&](TileId t, f32x4 (&x0)[8]) {
+    const bool v1 = t.eb * kTileCols + 32 + gcol < a.n_edges;
     if constexpr (NDYN == 2) {
+      f32x4 x1[8];
       load_rows(x1, row_of(t, dyn[1], 1));
 #pragma unroll
       for (int s = 0; s < 8; ++s) x0[s] += x1[s];
@@ -244,9 +340,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     asm volatile("" : "+v"(f));
     const int hh = team_b ? 1 : 0;
     const int c0 = hh * COLS;
-    float vv[COLS];
+    constexpr int VH = 16;  // staged values read at a time (registers: team A holds gathered rows and its cache across the walk)
+    float vv[VH];
 #pragma unroll
-    for (int i = 0; i < COLS; ++i) vv[i] = stage[(c0 + i) * kStageLd + f];
+    for (int i = 0; i < VH; ++i) vv[i] = stage[(c0 + i) * kStageLd + f];
     const int gdv = gdl[ring * kTileCols + lane];
     const int gdn = gdl[ring * kTileCols + (lane < kTileCols - 1 ? lane + 1 : lane)];
     const unsigned long long ends = __ballot(lane == kTileCols - 1 || gdn != gdv);
@@ -256,7 +353,11 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     bool first = true;
 #pragma unroll
     for (int i = 0; i < COLS; ++i) {
-      run += vv[i];
+      if (i > 0 && i % VH == 0) {  // next batch of staged values
+#pragma unroll
+        for (int i2 = 0; i2 < VH; ++i2) vv[i2] = stage[(c0 + i + i2) * kStageLd + f];
+      }
+      run += vv[i % VH];
       if (__builtin_expect((mine >> i) & 1ull, 0)) {
         const int cur = __builtin_amdgcn_readlane(gdv, c0 + i);
         if (cur >= 0 && GW_SKIP(a) != 1) {
@@ -283,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         const f32x4 hi = *(const f32x4*)(stage + col * kStageLd + so + 16);
         bf16x8 pk = to_bf16x8(lo, hi);
         if (t.eb * kTileCols + col >= a.n_edges) pk = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        *(GW_AS1 bf16x8*)(a.e_out_tiles + (tile * kGroups + g) * 8192 + (size_t)wave * 1024 + (size_t)lane * 16) = pk;
+        *(GW_AS1 bf16x8*)(a.e_out_tiles + (tile * kGroups + g) * 8192 + (size_t)wave * 1024 + (size_t)(fresh(lane) * 16)) = pk;
       }
     }
     if (a.e_out != nullptr) {  // e' as fp32 rows from the staged tile (callers that want rows back): 8 rows per wave
@@ -306,11 +407,13 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   if (!team_b) {
     // ================================================ team A ========================================================
     TileId t_next = tile_at(0);
-    f32x4 gx[8];  // GATHER: rows of column pass 0 of the next tile, in flight from the end of half 1
+    int res_warm = 0;
     if (GATHER) {
       __syncthreads();  // the parameter block (b1) is visible  [team B meets this barrier below]
-      gather_issue0(t_next, gx);
-      gather_finish(t_next, gx);
+      f32x4 gx0[8];
+      gather_issue0(t_next, gx0);
+      gather_part1(t_next, gx0);
+      gather_part2(t_next, gx0);
     } else {
       __syncthreads();
       prep_dma_issue(t_next);
@@ -323,151 +426,178 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       t_prev = t_cur;
       t_cur = t_next;
       if (s + 1 < n) t_next = tile_at(s + 1);
-      const bool stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;  // gw_debug_timestamps(kind 3): phase clocks
-      unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-      if (stamp) ts[0] = gw_clock();
+      stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;
+      f32x4 gx[8];  // GATHER: rows of column pass 0 of the next tile, in flight from the end of half 1 into half 2 (declared per
+                    // step: as a loop-carried variable it would hold 32 registers through the MFMA phase as well)
+      GW_TS(0)
       team_barrier();  // (alpha) Hbuf1 of tile s complete; staged tile s - 2 free
-      if (stamp) ts[1] = gw_clock();
+      GW_TS(1)
       if (s < n) {
         // ---- middle layer of tile s: Hbuf1 -> Hbuf2 ----
-        bf16x8 bfr[8];
-        load_frags(bfr, h1, lane);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-          f32x4 acc[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = *(const f32x4*)(par_l + 16 * t);  // b_mid (LDS: no registers held across groups)
-          layer_group(acc, wr, bfr);
-          if (g + 1 < kGroups) load_frags(bfr, h1 + (g + 1) * 8 * 1024, lane);
-          *(bf16x8*)(h2 + ((g * 8 + s0) * 64 + lane) * 16) = to_bf16x8(relu4(acc[0]), relu4(acc[1]));
-          *(bf16x8*)(h2 + ((g * 8 + s0 + 1) * 64 + lane) * 16) = to_bf16x8(relu4(acc[2]), relu4(acc[3]));
-        }
+        f32x4 acc[2][4];
+        unsigned pk[8];  // bf16 pairs of the group being packed: row tile t -> pk[2 t], pk[2 t + 1]
+        if (use_prio) __builtin_amdgcn_s_setprio(1);
+        team_layer<2>(
+            acc, wr, h1, lane,
+            [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + 16 * t); },  // b_mid
+            [&](int g, int m, f32x4 (&ac)[4]) {
+              // m = 0..15: relu of one accumulator value; 16..23: bf16 pack of a pair; 24 / 25: the 16-byte store of K-step s0 / s0 + 1
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              if (m < 16) {
+                ac[m >> 2][m & 3] = relu1(ac[m >> 2][m & 3]);
+              } else if (m < 24) {
+                const int pi = m - 16;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[pi]) : "v"(ac[pi >> 1][2 * (pi & 1)]), "v"(ac[pi >> 1][2 * (pi & 1) + 1]));
+              } else if (m == 24) {
+                *(u32x4*)(h2 + ((g * 8 + s0) * 64 + fresh(lane)) * 16) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+              } else if (m == 25) {
+                *(u32x4*)(h2 + ((g * 8 + s0 + 1) * 64 + fresh(lane)) * 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+              }
+            });
         __builtin_amdgcn_s_setprio(0);
+        GW_TS(2)
       }
       const bool has_next = s + 1 < n;
       if (GATHER && has_next) gather_issue0(t_next, gx);  // (registers only: Hbuf1 is still being read by the other waves)
-      if (stamp) ts[2] = gw_clock();
+      GW_TS(6)
       team_barrier();  // (beta) Hbuf2 of tile s and the staged tile s - 1 complete; Hbuf1 free
-      if (stamp) ts[3] = gw_clock();
+      GW_TS(7)
       if (!GATHER && has_next) prep_dma_issue(t_next);  // in flight under the segment sums
-      if (s >= 1) segment_sums(t_prev, (s - 1) & 3);
-      if (stamp) ts[4] = gw_clock();
+      if (RES && s < n && !a.res_tiles_shared) {
+        // the residual of tile s (per-sample bf16 edge tiles, 256 lines of 128 bytes) -> this XCD's L2: team B reads it in its
+        // next half-step just in time, 8 bytes at a time - a round trip to HBM there would be exposed
+        res_warm ^= ldgi((const int*)(a.res_tiles + tile_row(t_cur) * kHBytes + (size_t)(threadIdx.x & 255) * 128));
+      }
+      if (GATHER && has_next && !t_skip_a2) gather_part1(t_next, gx);
+      GW_TS(9)
+      if (s >= 1 && !t_skip_a2) segment_sums(t_prev, (s - 1) & 3);
+      GW_TS(8)
       if (has_next) {
-        if (GATHER) gather_finish(t_next, gx);
+        if (GATHER && !t_skip_a2) gather_part2(t_next, gx);
+        GW_TS(10)
         if (tw == 0) publish_dst(t_next, (s + 1) & 3);
         if (!GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (stamp) {
-        ts[5] = gw_clock();
-        if (threadIdx.x == 0)
-          for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 16 + i] = ts[i];
-      }
+      GW_TS(11)
     }
+    asm volatile("" ::"v"(res_warm));
   } else {
     // ================================================ team B ========================================================
     __syncthreads();  // (pairs with team A's barrier before its first gather / DMA)
     f32x4 o[kGroups][4];
-    bf16x8 rest0[kGroups];  // residual, K-step s0 (feature tiles 0, 1 of this wave); K-step s0 + 1 is requested in half 1
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
+    for (int g = 0; g < kGroups; ++g)
 #pragma unroll
       for (int t = 0; t < 4; ++t) o[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      rest0[g] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
     TileId t_next = tile_at(0), t_cur = t_next, t_prev = t_next;
 #pragma unroll 1
     for (int s = 0; s <= n; ++s) {
       t_prev = t_cur;
       t_cur = t_next;
       if (s + 1 < n) t_next = tile_at(s + 1);
-      const bool stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;
-      unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-      if (stamp) ts[0] = gw_clock();
+      stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;
+      GW_TS(0)
       team_barrier();  // (alpha) LayerNorm partial sums of tile s - 1 visible; staged tile s - 2 free
-      if (stamp) ts[1] = gw_clock();
-      if (s >= 1) {
+      GW_TS(1)
+      if (s >= 1 && !t_skip_ln) {
         // ---- LayerNorm (eps 1e-5, biased variance), residual, staging of tile s - 1 ----
         // v = (o - mean) rstd gamma + beta + e = o (rstd gamma) + ((-mean rstd) gamma + (beta + e)), one feature tile (16 rows)
         // at a time for all 4 groups: the accumulators of a tile die as it is staged, and the second half of the residual is
         // requested after the first tile - its registers take the place of the dead accumulators.
-        const int k0 = t_prev.eb * kTileCols;
+        // The residual (bf16 edge tiles: feature tile t of this wave = 8 bytes of the lane's 16-byte slot of K-step
+        // s0 + (t >> 1)) is read just in time, two feature tiles ahead: team A warmed its lines into L2 half a step ago, this
+        // half-step issues no stores, and the stores of the previous one have had its output layer to drain.
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        bf16x4_t rb[2][kGroups];
+        const char* rbase = nullptr;
+        if constexpr (RES) {
+          const size_t rtile = a.res_tiles_shared ? (size_t)t_prev.eb : tile_row(t_prev);
+          rbase = a.res_tiles + rtile * kHBytes + (size_t)s0 * 1024 + (size_t)(fresh(lane) * 16);
+        }
+        auto res_load = [&](bf16x4_t (&r)[kGroups], int t) {
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g)
+            r[g] = use_res ? *(const GW_AS1 bf16x4_t*)(rbase + (size_t)g * 8192 + (t >> 1) * 1024 + (t & 1) * 8) : bf16x4_t{0, 0, 0, 0};
+        };
+        if constexpr (RES) res_load(rb[0], 0);
         float ga[kGroups], gb[kGroups];
+        const float* const lnr = lnp + fresh(q * kTileCols + j) * 2;
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
-          const float2 pr = *(const float2*)(lnp + (q * kTileCols + 16 * g + j) * 2);  // row q reads team-B wave q's partial sums
+          const float2 pr = *(const float2*)(lnr + 32 * g);  // row q reads team-B wave q's partial sums
           const float s1 = sum_rows(pr.x);
           const float s2 = sum_rows(pr.y);
           const float mean = s1 * (1.0f / 256.0f);
           const float var = fmaxf(s2 * (1.0f / 256.0f) - mean * mean, 0.f);
-          ga[g] = 1.0f / sqrtf(var + 1e-5f);
+          ga[g] = __builtin_amdgcn_rsqf(var + 1e-5f);  // v_rsq_f32 (1 ulp): in front of bf16 matrix products
           gb[g] = -mean * ga[g];
         }
-        bf16x8 rest1[kGroups];
+        GW_TS(2)
+        float* const srow = stage + fresh(j) * kStageLd + fresh(f0);  // + 16 g rows, + 16 t floats: immediates
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          if (t == 1) {
-            const size_t rtile = a.res_tiles_shared ? (size_t)t_prev.eb : tile_row(t_prev);
-#pragma unroll
-            for (int g = 0; g < kGroups; ++g)
-              rest1[g] = *(const GW_AS1 bf16x8*)(a.res_tiles + (rtile * kGroups + g) * 8192 + (size_t)(s0 + 1) * 1024 + (size_t)lane * 16);
-          }
+          __builtin_amdgcn_sched_barrier(0);  // (one feature tile at a time: hoisted parameter reads would hold registers)
           const f32x4 gm = *(const f32x4*)(par_l + 512 + 16 * t);
           const f32x4 bt = *(const f32x4*)(par_l + 768 + 16 * t);
 #pragma unroll
           for (int g = 0; g < kGroups; ++g) {
-            const bf16x8 rr = t < 2 ? rest0[g] : rest1[g];
-            const f32x4 rv = (t & 1) ? f32x4{(float)rr[4], (float)rr[5], (float)rr[6], (float)rr[7]}
-                                     : f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+            f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (RES) {
+              const bf16x4_t rr = rb[t & 1][g];
+              rv = f32x4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]};
+            }
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaf(o[g][t][r], ga[g] * gm[r], fmaf(gb[g], gm[r], bt[r] + rv[r]));
-            *(f32x4*)(stage + (16 * g + j) * kStageLd + f0 + 16 * t) = v;
-          }
-        }
-        (void)k0;
-      }
-      if (stamp) ts[2] = gw_clock();
-      team_barrier();  // (beta) Hbuf2 of tile s and the staged tile s - 1 complete
-      if (stamp) ts[3] = gw_clock();
-      if (s >= 1) segment_sums(t_prev, (s - 1) & 3);
-      if (stamp) ts[4] = gw_clock();
-      if (s < n) {
-        // ---- output layer of tile s: Hbuf2 -> registers, LayerNorm partial sums ----
-        bf16x8 bfr[8];
-        load_frags(bfr, h2, lane);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) o[g][t] = *(const f32x4*)(par_l + 256 + 16 * t);  // b_out
-          layer_group(o[g], wr, bfr);
-          if (g + 1 < kGroups) load_frags(bfr, h2 + (g + 1) * 8 * 1024, lane);
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s1 += o[g][t][r];
-              s2 = fmaf(o[g][t][r], o[g][t][r], s2);
+            *(f32x4*)(srow + 16 * g * kStageLd + 16 * t) = v;
+            if constexpr (RES) {
+              // the next feature tile's residual: requested half a tile ahead (two groups of accumulators have died by now)
+              if (g == 1 && t + 1 < 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                res_load(rb[(t + 1) & 1], t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
-          s1 = sum_rows(s1);
-          s2 = sum_rows(s2);
-          if (q == 0) *(float2*)(lnp + (tw * kTileCols + 16 * g + j) * 2) = float2{s1, s2};
+          }
+          GW_TS(3 + t)
         }
+      }
+      team_barrier();  // (beta) Hbuf2 of tile s and the staged tile s - 1 complete
+      GW_TS(7)
+      if (s >= 1 && !t_skip_bseg) segment_sums(t_prev, (s - 1) & 3);
+      GW_TS(8)
+      if (s < n) {
+        // ---- output layer of tile s: Hbuf2 -> registers, LayerNorm partial sums (per group, in the shadow of the next group) ----
+        float s1 = 0.f, s2 = 0.f;
+        if (use_prio) __builtin_amdgcn_s_setprio(1);
+        team_layer<4>(
+            o, wr, h2, lane,
+            [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + 256 + 16 * t); },  // b_out
+            [&](int g, int m, f32x4 (&ac)[4]) {
+              // m = 0..15: one accumulator value into the column's sum and sum of squares; 16..19: the sums over the four
+              // 16-lane rows (q) in two lane-swap steps each; 20: the wave's partial sums of the group's 16 columns -> LDS
+              if (m < 16) {
+                const float x = ac[m >> 2][m & 3];
+                s1 = m == 0 ? x : s1 + x;
+                s2 = m == 0 ? x * x : fmaf(x, x, s2);
+              } else if (m == 16 || m == 18) {
+                float& v = m == 16 ? s1 : s2;
+                const unsigned u = __float_as_uint(v);
+                const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+              } else if (m == 17 || m == 19) {
+                float& v = m == 17 ? s1 : s2;
+                const unsigned u = __float_as_uint(v);
+                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+              } else if (m == 20) {
+                if (q == 0) *(float2*)(lnp + (tw * kTileCols + 16 * g + fresh(j)) * 2) = float2{s1, s2};
+              }
+            });
         __builtin_amdgcn_s_setprio(0);
-        // ---- residual of tile s (bf16 edge tiles: the lane's own 16-byte slot of K-step s0): requested here, used after the
-        // next barrier - in flight across it ----
-        const size_t rtile = a.res_tiles_shared ? (size_t)t_cur.eb : tile_row(t_cur);
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g)
-          rest0[g] = *(const GW_AS1 bf16x8*)(a.res_tiles + (rtile * kGroups + g) * 8192 + (size_t)s0 * 1024 + (size_t)lane * 16);
+        GW_TS(9)
       }
-      if (stamp) {
-        ts[5] = gw_clock();
-        if (threadIdx.x == 256)
-          for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 16 + 8 + i] = ts[i];
-      }
+      GW_TS(13)
     }
   }
 }
@@ -486,12 +616,14 @@ namespace gw {
 
 int edge16t_launch(const void* edge16_args, bool gather, int n_wg, void* stream) {
   const Edge16Args& a = *(const Edge16Args*)edge16_args;
-  if (!gather) return launch_team(edge16t_kernel<false, 1>, n_wg, a, stream);
+  const bool res = a.res_tiles != nullptr;
+  if (!gather) return res ? launch_team(edge16t_kernel<false, 1, true>, n_wg, a, stream) : launch_team(edge16t_kernel<false, 1, false>, n_wg, a, stream);
   int n_dyn = 0;
   for (int p = 0; p < a.n_proj; ++p) n_dyn += a.p_rows_pb[p] != 0 ? 1 : 0;
-  if (n_dyn == 1) return launch_team(edge16t_kernel<true, 1>, n_wg, a, stream);
-  if (n_dyn == 2) return launch_team(edge16t_kernel<true, 2>, n_wg, a, stream);
-  return set_error(GW_E_UNSUPPORTED, "edge16t: the gather form takes one or two per-sample projected tables");
+  if (n_dyn == 1) return res ? launch_team(edge16t_kernel<true, 1, true>, n_wg, a, stream) : launch_team(edge16t_kernel<true, 1, false>, n_wg, a, stream);
+  // (two per-sample tables - the first processor block - stay on the lock-step kernel: measured 0.43 ms there against 0.49 ms
+  //  here, its gather needs both tables of a column pass in flight and does not fit the team's register budget)
+  return set_error(GW_E_UNSUPPORTED, "edge16t: the gather form takes exactly one per-sample projected table");
 }
 
 }  // namespace gw

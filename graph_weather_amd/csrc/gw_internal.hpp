@@ -83,9 +83,11 @@ extern int g_dbg_kind;
 int env_int(const char* name, int fallback);
 #define GW_TUNE(name, fallback) gw::env_int(name, fallback)
 #define GW_SKIP(a) ((a).skip)
+#define GW_TUNE_ARG(a) ((a).tune)
 #else
 #define GW_TUNE(name, fallback) (fallback)
 #define GW_SKIP(a) 0
+#define GW_TUNE_ARG(a) 0
 #endif
 
 // hipFuncSetAttribute is per device: one flag per (kernel instantiation, device) instead of one per process, so a second

@@ -836,7 +836,13 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
     if (bad256(ops[i]) || (!ops[i]->projected && !w->w1[i]))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
-  if (bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
+  // e_res->k == 0: no residual - for callers that want only the aggregate and have added the segment sums of their (batch-
+  // shared) e into agg beforehand: sum(LN(.) + e) = sum(LN(.)) + sum(e).  bf16 path with resident weights only (edge16_launch).
+  const bool no_res = e_res->k == 0;
+  if (no_res && (e_out_any != nullptr || save || !gw::edge16_eligible(x_src, x_dst, e_in, w) || (flags & GW_EDGE_DETERMINISTIC)))
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: an edge update without residual (e_res.k == 0) is implemented for the bf16 "
+                                  "path with resident weights, without e_out, activation saving or deterministic sums");
+  if (!no_res && bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
   // edge tiles (bf16) are a format of the bf16 path with resident weights only
   const bool tiles_in = (e_in->k > 0 && e_in->layout == GW_LAYOUT_EDGE_TILES_BF16) || e_res->layout == GW_LAYOUT_EDGE_TILES_BF16;
   const bool tiles_out = e_out_any != nullptr && e_out_layout == GW_LAYOUT_EDGE_TILES_BF16;
@@ -848,7 +854,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
   const size_t ws16 = gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");
-  if (tiles_in || tiles_out) {
+  if (tiles_in || tiles_out || no_res) {
     if (save || (ws16 > 0 && (!workspace || workspace_bytes < ws16)) || !gw::edge16_eligible(x_src, x_dst, e_in, w))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
                                     "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");

@@ -13,8 +13,9 @@ from __future__ import annotations
 import torch
 
 from . import autograd as ag
+from . import wide
 from .graphs import build_forecast_graphs
-from .layers import Decoder, Encoder, Processor
+from .layers import Decoder, Encoder, Processor, fused_forward
 
 
 class GraphCast(torch.nn.Module):
@@ -64,23 +65,41 @@ class GraphCast(torch.nn.Module):
     def set_checkpoint_decoder(self, checkpoint_flag: bool):
         self._checkpoint_decoder = checkpoint_flag
 
+    def _any_wide(self) -> bool:
+        """Wide (layer-by-layer, unpadded rows) versus fused (256-float tables) is decided ONCE for the whole model, as
+        ``layers.fused_forward`` does: the two paths hand different table layouts from stage to stage."""
+        return (wide.encoder_is_wide(self.encoder) or wide.processor_is_wide(self.processor.graph_processor)
+                or wide.decoder_is_wide(self.decoder))
+
     def _encode(self, features: torch.Tensor) -> torch.Tensor:
+        if self._any_wide():
+            return wide.encode(self.encoder, features)
         return self.encoder.encode(features)
 
     def _process(self, x: torch.Tensor, B: int, dev) -> torch.Tensor:
         _, lat_plan = self.encoder._plans(dev)
+        if self._any_wide():
+            return wide.run_blocks(self.processor.graph_processor, x, lat_plan, wide.latent_edges(self.encoder, lat_plan), True, B, False)[0]
         e_lat = self.encoder.latent_edge_embedding(lat_plan)
         return self.processor.graph_processor.run_plan(x, lat_plan, e_lat, True, B, False)[0]
 
     def _decode(self, x: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
         B, G = int(features.shape[0]), self.encoder.num_latlons
-        return self.decoder.decode(x, B, residual=features.reshape(B * G, features.shape[2]))
+        res = features.reshape(B * G, features.shape[2])
+        if self._any_wide():
+            return wide.decode(self.decoder, x, B, residual=res)
+        return self.decoder.decode(x, B, residual=res)
 
     def _custom_forward(self, features: torch.Tensor) -> torch.Tensor:
         """graphcast/model.py:212-262 (hierarchical checkpointing: encoder / processor / decoder segments; the processor's
         -1 / N segments are handled inside ``GraphProcessor.run_plan``)."""
         B, dev = int(features.shape[0]), features.device
         grad = torch.is_grad_enabled()
+        if not (grad and (self._checkpoint_encoder or self._checkpoint_decoder)):
+            # no encoder / decoder segment to recompute: the forecaster's fused forward (inference: projection-free blocks, one
+            # launch chain in native layouts; wide models through wide.forward; processor segments inside run_plan)
+            G = self.encoder.num_latlons
+            return fused_forward(self.encoder, self.processor, self.decoder, features, features.reshape(B * G, features.shape[2]))
         if grad and self._checkpoint_encoder:
             x = ag.recompute(lambda f: (self._encode(f),), (features,), self.encoder)[0]
         else:

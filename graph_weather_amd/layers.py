@@ -319,7 +319,7 @@ class GraphNetBlock(nn.Module):
             e_out = torch.empty(ops.edge_tiles_bytes(batch, n_edges), dtype=torch.uint8, device=device)
         else:
             e_out = torch.empty((batch * n_edges, 256), dtype=torch.float32, device=device) if want_edges else None
-        res_op = Operand(e_res, e_res_rows_pb, 256, tiles=(e_res.dtype == torch.uint8))
+        res_op = ops.ZERO if e_res is None else Operand(e_res, e_res_rows_pb, 256, tiles=(e_res.dtype == torch.uint8))
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
                                 e_in.operand(), res_op, n_dst, agg, e_out, tag=tag, deterministic=self.deterministic)
         res_x = ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256)
@@ -813,14 +813,34 @@ class AssimilatorDecoder(nn.Module):
             if hit is None or hit[0] != key:
                 self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
             pe = self._cache["dec_pe"][1]
+            x_node = FEED_ZERO
             if mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and n_e > 0:
-                # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
-                hit = self._cache.get("dec_e_tiles")
-                if hit is None or hit[0] != key:
-                    self._cache["dec_e_tiles"] = (key, ops.edge_rows_to_tiles(e, 1, n_e, n_e))
-                e = self._cache["dec_e_tiles"][1]
-        xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
-                        tag="decoder_edge")
+                pm_n = blk.node_model.node_mlp.packed()
+                if blk.deterministic or pm_n.weight_dtype != pm_e.weight_dtype:
+                    # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
+                    hit = self._cache.get("dec_e_tiles")
+                    if hit is None or hit[0] != key:
+                        self._cache["dec_e_tiles"] = (key, ops.edge_rows_to_tiles(e, 1, n_e, n_e))
+                    e = self._cache["dec_e_tiles"][1]
+                else:
+                    # e' itself is dropped (assimilator_decoder.py:195) and e is the same for every sample, so
+                    #   agg = sum(LN(.) + e) = sum(LN(.)) + S,  S[dst] = sum of e over the destination's edges (batch independent),
+                    # and layer 1 of the node update (graph_net_block.py:189, x == 0) is Wa.agg = Wa.sum(LN(.)) + Wa.S: the edge
+                    # kernel adds no residual at all, and Wa.S enters the node update as a cached, batch-shared PROJECTED operand
+                    # in the slot of the all-zero x rows.
+                    hit = self._cache.get("dec_e_sum")
+                    if hit is None or hit[0] != key:
+                        e_sum = ag.segment_sum_rows(e, n_e, 1, 1, plan.n_dst, plan.dst_ptr(), None)
+                        self._cache["dec_e_sum"] = (key, ops.project_forward([pm_n.w1[1]], Operand(e_sum, plan.n_dst, 256),
+                                                                             plan.n_dst, plan.n_dst)[0])
+                    x_node = Feed(self._cache["dec_e_sum"][1], 0, "proj")
+                    e = None
+        if not train and x_node is not FEED_ZERO:
+            xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), None, 0, x_node, None, 0, False, dev,
+                            tag="decoder_edge")
+        else:
+            xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
+                            tag="decoder_edge")
         res = None
         if residual is not None:
             if residual.dim() != 2 or residual.shape[0] != B * G or residual.shape[1] < self.output_dim:

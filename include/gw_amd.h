@@ -144,8 +144,10 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
  *   e_new = LN(MLP(cat[x_src[b, src[e]], x_dst[b, dst[e]], e_in[b, e]])) + e_res[b, e]
  *   agg[b, dst[e], :] += e_new                         (agg must be zero-filled by the caller)
  * and, if e_out != NULL, e_out[b, e, :] = e_new.  Feature width is 256.  Each of x_src / x_dst / e_in may be
- * raw rows, pre-projected rows (operand.projected) or zeros (k == 0); e_res is always the raw edge feature row
- * (the residual of graph_net_block.py:135). */
+ * raw rows, pre-projected rows (operand.projected) or zeros (k == 0); e_res is the raw edge feature row (the residual of
+ * graph_net_block.py:135) - or k == 0 for "none": a caller that wants only the aggregate of batch-shared edge features (the
+ * decoder, assimilator_decoder.py:195 drops e') may add their per-destination sums into agg beforehand instead,
+ * sum(LN(.) + e) = sum(LN(.)) + sum(e)  (bf16 weights with resident kernels, e_out == NULL, no save, atomics mode). */
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w,

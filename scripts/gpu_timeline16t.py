@@ -1,6 +1,6 @@
 """Phase clocks of the team-pipelined bf16 edge kernel (gw_edge16t.hip) on the 1-degree decoder / processor, batch 16.
-Per workgroup and team (A = waves 0-3: middle layer + Hbuf1 of the next tile; B = waves 4-7: output layer + LayerNorm):
-wait at alpha | half 1 | wait at beta | segment sums | rest of half 2, stamped on each workgroup's 4th pipeline step."""
+Per workgroup and team (A = waves 0-3: middle layer + Hbuf1 of the next tile; B = waves 4-7: output layer + LayerNorm),
+stamped on each workgroup's 4th pipeline step (gw_debug_timestamps kind 3; 32 x u64 per workgroup)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,7 +15,7 @@ ll = regular_lat_lons(1.0)
 m = gw.GraphWeatherForecaster(ll); deterministic_fill_(m, 0); m = m.to(dev).eval(); m.set_compute_dtype(torch.bfloat16)
 x = seeded_features(B, len(ll)).to(dev)
 cap = 256
-buf = torch.zeros(cap * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(cap * 32, dtype=torch.int64, device=dev)
 L = _lib.lib()
 with torch.no_grad():
     y = m(x)
@@ -34,15 +34,19 @@ with torch.no_grad():
         yd = m.decoder.decode(xp, B, residual=x.reshape(B * len(ll), 102))
         torch.cuda.synchronize()
         L.gw_debug_timestamps(None, 0, -1)
-rec = buf.cpu().numpy().reshape(cap, 16)
+rec = buf.cpu().numpy().reshape(cap, 32)
 rec = rec[rec[:, 0] != 0]
-names = ["wait at alpha", "half 1", "wait at beta", "segment sums", "rest of half 2"]
-print(WHICH, "batch", B, "workgroups", rec.shape[0], "(s_memtime ticks = shader cycles)")
-for team, off, what in (("A", 0, "half 1 = middle layer (+ issue of gather pass 0); rest of half 2 = gather / DMA wait of the next tile"),
-                        ("B", 8, "half 1 = LayerNorm + residual + staging; rest of half 2 = output layer + residual request")):
-    r = rec[:, off:off + 6]
+NA = ["wait at alpha", "mid group 0", "mid group 1", "mid group 2", "mid group 3", "issue gather pass 0", "wait at beta", "segment sums",
+      "gather: pass 0 done", "gather: pass 1 done", "dst ids / DMA wait"]
+NB = ["wait at alpha", "LN: mean / rstd", "LN: tile 0 (needs residual)", "LN: tile 1 (+ residual request)", "LN: tile 2", "LN: tile 3",
+      "wait at beta", "segment sums", "out group 0", "out group 1", "out group 2", "out group 3", "residual request"]
+print(WHICH, "batch", B, "workgroups", rec.shape[0], "env", {k: v for k, v in os.environ.items() if k.startswith("GW_")}, "(ticks = shader cycles)")
+for team, off, names in (("A", 0, NA), ("B", 16, NB)):
+    r = rec[:, off:off + len(names) + 1].astype(np.int64)
+    if WHICH == "processor" and team == "A":  # (DMA form: no gather stamps 9 - their slots stay 0)
+        r = r.copy(); r[:, 9] = r[:, 8]
     d = np.diff(r, axis=1)
-    print("team", team, "-", what)
+    print("team", team)
     for i, n in enumerate(names):
-        print(f"  {n:18s} median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
-    print(f"  step total         median {np.median(r[:, 5] - r[:, 0]):8.0f}")
+        print(f"  {n:32s} median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+    print(f"  step total                       median {np.median(r[:, len(names)] - r[:, 0]):8.0f}")

@@ -110,6 +110,44 @@ def test_edge16_kernels_keep_their_weights_in_accumulation_registers(tmp_path):
 
 
 @pytest.mark.timeout(600)
+def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path):
+    """csrc/gw_edge16t.hip (team-pipelined bf16 edge update): every instantiation keeps its matrix in the AGPR half (all 256
+    MFMAs - 128 per team - read their A operand from an AGPR, no AGPR <-> VGPR copies after the prologue), fits two waves per SIMD
+    (<= 256 registers) and stays near the register budget (the allocator parks a few loop-invariant dwords in scratch: bounded
+    here - none of them is the destination of a load the kernel issues from asm, which are LDS-DMA only).  Inside the MFMA phases
+    the stream is 'one filler per MFMA': no run of more than 12 non-MFMA instructions between two MFMAs of a group."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graph_weather_amd", "csrc", "gw_edge16t.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "e.o", "-save-temps"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+    text = (tmp_path / "gw_edge16t-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    names = re.findall(r"^(_Z\w*edge16t_kernelILb[01]ELi[12]ELb[01]E\w*):", text, re.M)
+    assert len(names) == 4, names  # (layer-1 tiles by DMA | gathered in the kernel) x (residual tiles | none)
+    for name in names:
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        assert vgpr <= 256, (name, vgpr)
+        assert scratch <= 256, (name, scratch)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        mfma = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma_f32_16x16x32_bf16")]
+        assert len(mfma) == 256, (name, len(mfma))
+        for i in mfma:
+            ops = [o.strip() for o in lines[i].split(None, 1)[1].split(",")]
+            assert ops[1].startswith("a["), f"weight operand not in an AGPR: {lines[i]}"
+        first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
+        assert not any(ln.startswith(("v_accvgpr_read", "v_accvgpr_write")) for ln in lines[first_barrier:]), name
+        for phase in (mfma[:128], mfma[128:]):
+            gaps = [b_ - a_ - 1 for a_, b_ in zip(phase, phase[1:])]
+            assert max(gaps) <= 12, (name, max(gaps))
+
+
+@pytest.mark.timeout(600)
 def test_wide_kernels_have_no_scratch_and_the_gemm_keeps_three_waves_per_simd(tmp_path):
     """csrc/gw_wide.hip: the LayerNorm kernels hold a whole row per wave in registers (up to 64 columns per lane, three such arrays
     in the backward) - a spill would turn them into scratch-memory kernels; the GEMM's 128 x 128 tile must leave room for three
