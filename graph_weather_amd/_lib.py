@@ -15,15 +15,15 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 DTYPE_F32, DTYPE_BF16 = 0, 1
-LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16 = 0, 1
+LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16 = 0, 1, 2
 EDGE_DETERMINISTIC = 1
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
     "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector",
-    "gw_mlp_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
+    "gw_mlp_forward", "gw_mlp_post_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
     "gw_edge_rows_to_tiles", "gw_node_update_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
     "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step", "gw_nudging_forward", "gw_nudging_backward",
@@ -107,6 +107,9 @@ def lib():
     L.gw_mlp_forward.restype = c_int
     L.gw_mlp_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwMlpWeights), POINTER(GwOperand),
                                  c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]
+    L.gw_mlp_post_forward.restype = c_int
+    L.gw_mlp_post_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_int32, c_int32,
+                                      POINTER(c_void_p), POINTER(c_void_p), c_int32, c_void_p]
     L.gw_edge_update_forward.restype = c_int
     L.gw_edge_update_forward.argtypes = [c_int32, c_int32, c_void_p, c_void_p, POINTER(GwOperand), POINTER(GwOperand),
                                          POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights), c_void_p, c_int32, c_void_p,
@@ -121,10 +124,10 @@ def lib():
     L.gw_node_update_forward.restype = c_int
     L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
                                          POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_int32,
-                                         POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]
+                                         POINTER(c_void_p), POINTER(c_void_p), c_int32, c_void_p, c_void_p]
     L.gw_project_forward.restype = c_int
     L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
-                                     c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+                                     c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     L.gw_normalized_mse_forward.restype = c_int
     L.gw_normalized_mse_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                             c_void_p, c_void_p]

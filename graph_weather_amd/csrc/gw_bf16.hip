@@ -61,6 +61,15 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
+// layer-1 node products as fp16 rows (GW_LAYOUT_ROWS_F16): 11 significant bits in front of the consumer's bf16 rounding of
+// the layer-1 activations; clamped to the fp16 range (an overflow would turn into inf, then NaN under LayerNorm)
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stg_half4(void* p, f32x4 v) {
+  half4_t h;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h[r] = (_Float16)fminf(fmaxf(v[r], -65504.f), 65504.f);
+  *(GW_AS1 half4_t*)p = h;
+}
 
 // One layer pass: acc[g][t] += W[16t.., k] . bin[g][k], K = 32 KS, NT row tiles, NTP = tiles per K-step in the packed
 // stream (NT rounded up to 4).  The stream of this pass starts at gw; its first chunk has already been issued into
@@ -328,7 +337,9 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
           const int f0 = 16 * t + 4 * q;
-          if (EPI == EPI_DEC) {
+          if (SINGLE && a.proj_half) {  // (out_ld counts halves)
+            stg_half4((_Float16*)outp + (size_t)cc[g] * (size_t)a.out_ld + f0, o[g][t]);
+          } else if (EPI == EPI_DEC) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[g][t][r]);
@@ -365,9 +376,15 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (valid[g]) {
-          float* prow = a.proj_out[sl] + (size_t)cc[g] * 256;
+          if (a.proj_half) {
+            _Float16* prow = (_Float16*)a.proj_out[sl] + (size_t)cc[g] * 256;
 #pragma unroll
-          for (int t = 0; t < HT; ++t) stg4(prow + 16 * t + 4 * q, acc[g][t]);
+            for (int t = 0; t < HT; ++t) stg_half4(prow + 16 * t + 4 * q, acc[g][t]);
+          } else {
+            float* prow = a.proj_out[sl] + (size_t)cc[g] * 256;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) stg4(prow + 16 * t + 4 * q, acc[g][t]);
+          }
         }
     }
   }
@@ -511,6 +528,10 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
       return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, true>, a, stream, grid_y, kLdsWeights);
     case 4:
       return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+    case 5:  // mlp rows + POST products of the output rows (node encoder -> layer-1 products of the encoder's edge MLP)
+      if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32)
+        return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+      return set_error(GW_E_UNSUPPORTED, "bf16 mlp + post products: hidden 256, 256 outputs, 33..128 inputs");
   }
   return set_error(GW_E_BADARG, "chain16_launch: bad kind");
 }

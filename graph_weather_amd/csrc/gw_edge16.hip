@@ -160,11 +160,22 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
     for (int p = 0; p < 2; ++p)
       if (p < a.n_proj) {
         const int r = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
-        const float* row = a.p_ptr[p] + ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
+        const size_t ro = ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
+        if (a.p_half[p]) {  // node products as fp16 rows (GW_LAYOUT_ROWS_F16): 8 bytes per row tile and lane
+          typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+          const _Float16* row = (const _Float16*)a.p_ptr[p] + ro;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          acc[t] += ldg4(row + 16 * t);
-          if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // at most 8 row pieces in flight: registers
+          for (int t = 0; t < 16; ++t) {
+            const half4_t h = *(const GW_AS1 half4_t*)(row + 16 * t);
+            acc[t] += f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+          }
+        } else {
+          const float* row = a.p_ptr[p] + ro;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            acc[t] += ldg4(row + 16 * t);
+            if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // at most 8 row pieces in flight: registers
+          }
         }
       }
     const char* wl = lds + lane * 16;
@@ -653,7 +664,10 @@ bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_
   if (w->weight_dtype != GW_DTYPE_BF16 || w->n_mid != 1 || !w->ln_gamma) return false;
   if (w->ln_width > 0 && w->ln_width != 256) return false;
   if (is_raw16(x_src) || is_raw16(x_dst)) return false;
-  if (x_src->layout != GW_LAYOUT_ROWS_F32 || x_dst->layout != GW_LAYOUT_ROWS_F32) return false;
+  // node operands: fp32 rows, or (projected only) fp16 rows of layer-1 products
+  const gw_operand* nodes[2] = {x_src, x_dst};
+  for (const gw_operand* o : nodes)
+    if (o->layout != GW_LAYOUT_ROWS_F32 && !(o->layout == GW_LAYOUT_ROWS_F16 && is_proj16(o))) return false;
   const bool raw_e = is_raw16(e_in);
   if (raw_e && (e_in->layout != GW_LAYOUT_EDGE_TILES_BF16 || !w->w1[2])) return false;
   if (!raw_e && e_in->k > 0 && e_in->layout != GW_LAYOUT_ROWS_F32) return false;
@@ -705,6 +719,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
       a.p_rows_pb[a.n_proj] = ops[i]->rows_per_batch;
       a.p_ld[a.n_proj] = ops[i]->ld;
       a.p_kind[a.n_proj] = i;
+      a.p_half[a.n_proj] = ops[i]->layout == GW_LAYOUT_ROWS_F16;
       ++a.n_proj;
     }
   const bool raw_e = is_raw16(e_in);
@@ -764,6 +779,12 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   const bool rt = a.res_tiles != nullptr;
   const bool ga = !raw_e && fuse_gather;  // layer 1 gathered inside the resident kernel
   static const int team = GW_TUNE("GW_EDGE16_TEAM", 1);
+  bool any_half = false;
+  for (int p = 0; p < a.n_proj; ++p) any_half = any_half || a.p_half[p];
+  // fp16 product rows are read by the layer-1 kernel (raw edge operand) and by the team kernel's gather - not by the lock-step
+  // kernels' gather
+  if (any_half && !raw_e && (nw == 4 || deterministic || team == 0 || !fuse_gather))
+    return set_error(GW_E_UNSUPPORTED, "edge16: fp16 product rows with all operands projected need the team-pipelined kernel (atomics mode)");
   int rc;
   if (no_res && (nw == 4 || deterministic || team == 0))
     return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual runs on the team-pipelined kernel only (atomics mode)");
@@ -774,7 +795,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     return segment_fixup_launch((int64_t)batch * a.neb, a.carry, agg, stream);
   }
   // team-pipelined form (gw_edge16t.hip): residual as bf16 tiles or none, atomics mode; the gather form needs one or two per-sample tables
-  if (team != 0 && (rt || no_res) && nw != 4 && !deterministic) {
+  if (team != 0 && ((ga && no_res) || (!ga && rt)) && nw != 4 && !deterministic) {
     int n_dyn = 0, n_shared = 0;
     for (int p = 0; p < a.n_proj; ++p) (a.p_rows_pb[p] != 0 ? n_dyn : n_shared) += 1;
     if (!ga || n_dyn == 1) {  // (two per-sample tables: the lock-step kernel below is the faster one, see gw_edge16t.hip)
@@ -791,6 +812,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     }
   }
   if (no_res) return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual needs exactly one per-sample projected table");
+  if (any_half && !raw_e) return set_error(GW_E_UNSUPPORTED, "edge16: fp16 product rows need exactly one per-sample projected table here");
   if (ga) return rt ? launch_resident(edge16_kernel<8, true, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, true>, 512, n_wg, a, stream);
   return rt ? launch_resident(edge16_kernel<8, true, false>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, false>, 512, n_wg, a, stream);
 }

@@ -39,6 +39,7 @@ struct Edge16Args {
   int p_rows_pb[3];
   int p_ld[3];
   int p_kind[3];  // 0: row = src[k], 1: dst[k], 2: k
+  int p_half[3];  // the table is fp16 rows (GW_LAYOUT_ROWS_F16; p_ld counts halves): layer-1 kernel and team gather only
   const float* b1;
   const char* w_raw;  // packed W_e (layer-1 slice of the raw edge operand), edge16_l1_kernel only
   const char* w_mid;

@@ -119,12 +119,12 @@ struct TileId {
   int eb, b;
 };
 
-// NDYN (GATHER form): projected tables with one row set per batch element (1: decoder - P_s; 2: first processor block - P_s, P_d);
-// the other projected tables are shared by the batch and cached per chunk.
+// GATHER form: exactly one projected table has a row set per batch element (the decoder's P_s); PH: that table is fp16 rows
+// (GW_LAYOUT_ROWS_F16).  The other projected tables are fp32 rows shared by the batch and cached per chunk.
 // RES: the residual e of graph_net_block.py:135 is added from bf16 edge tiles (true), or not at all (false: callers that only
 // want the aggregate - the decoder - add the segment sums of their batch-shared e into the aggregate buffer beforehand:
 // sum(LN(.) + e) = sum(LN(.)) + sum(e), and sum(e) per destination is the same for every batch element).
-template <bool GATHER, int NDYN, bool RES>
+template <bool GATHER, bool PH, bool RES>
 __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
@@ -204,10 +204,25 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   half4_t* const zc1 = (half4_t*)(lds + kT_Zc) + (threadIdx.x & 255);  // [s][thread]: + 256 s
   int cached_eb = -1;
 
+  // Unit u = 0..7 of a (column, piece) thread: 4 features = 8 bytes of one B-fragment slot of Hbuf1.
+  //   PH == false (fp32 tables): piece p reads floats 32 u + 4 p .. + 3 of a row (8 lanes = one 128-byte line per unit);
+  //                              slot: K-step u, q = p & 3, half p >> 2.
+  //   PH == true  (the per-sample table is fp16 rows): piece p reads halves 64 i + 8 p .. + 7 (16 bytes, 8 lanes = one line)
+  //                              for i = 0..3; unit u = 2 i + e holds features 64 i + 8 p + 4 e .. + 3:
+  //                              K-step 2 i + (p >> 2), q = 2 (p & 1) + e, half (p & 3) >> 1   (k = 32 s + 16 half + 4 q + r).
+  // (each offset = a per-thread part, recomputed where it is used, + a compile-time part of the unit that folds into the
+  //  instruction's immediate)
+  auto poff = [&]() -> int { return fresh(PH ? 8 * gpiece : 4 * gpiece); };                      // floats into a row
+  auto uoff = [](int u) -> int { return PH ? 64 * (u >> 1) + 4 * (u & 1) : 32 * u; };
+  auto pslot = [&](int col) -> int {                                                              // bytes into Hbuf1
+    const int ks = PH ? (gpiece >> 2) : 0;
+    const int qq = PH ? 2 * (gpiece & 1) : (gpiece & 3);
+    const int hf = PH ? (gpiece & 3) >> 1 : gpiece >> 2;
+    return fresh((col >> 4) * 8192 + ks * 1024 + (16 * qq + (col & 15)) * 16 + hf * 8);
+  };
+  auto uslot = [](int u) -> int { return PH ? (u >> 1) * 2048 + (u & 1) * 256 : u * 1024; };
   auto prep_chunk = [&](int eb) {  // new edge block: row indices + the batch-shared part of layer 1
-    int gp4 = 4 * gpiece;
-    asm volatile("" : "+v"(gp4));
-    const float* b1l = (const float*)(lds + kT_Par) + 1024 + gp4;
+    const float* b1l = (const float*)(lds + kT_Par) + 1024 + poff();
 #pragma unroll
     for (int cp = 0; cp < 2; ++cp) {
       const int kr = eb * kTileCols + 32 * cp + gcol;
@@ -220,99 +235,120 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     for (int cp = 0; cp < 2; ++cp) {
       f32x4 z[8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) z[s] = *(const f32x4*)(b1l + 32 * s);
+      for (int u = 0; u < 8; ++u) z[u] = *(const f32x4*)(b1l + uoff(u));
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        if (p < a.n_proj && a.p_rows_pb[p] == 0) {
-          const float* row = a.p_ptr[p] + (size_t)gidx[cp][p] * (size_t)a.p_ld[p] + gp4;
+        if (p < a.n_proj && a.p_rows_pb[p] == 0) {  // (batch-shared tables are fp32 rows: the host checks)
+          const float* row = a.p_ptr[p] + (size_t)gidx[cp][p] * (size_t)a.p_ld[p] + poff();
           f32x4 v[8];
 #pragma unroll
-          for (int s = 0; s < 8; ++s) v[s] = ldg4(row + 32 * s);
+          for (int u = 0; u < 8; ++u) v[u] = ldg4(row + uoff(u));
 #pragma unroll
-          for (int s = 0; s < 8; ++s) z[s] += v[s];
+          for (int u = 0; u < 8; ++u) z[u] += v[u];
         }
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
+      for (int u = 0; u < 8; ++u) {
         if (cp == 0) {
-          zc[s][0] = half2_t{(_Float16)z[s].x, (_Float16)z[s].y};
-          zc[s][1] = half2_t{(_Float16)z[s].z, (_Float16)z[s].w};
+          zc[u][0] = half2_t{(_Float16)z[u].x, (_Float16)z[u].y};
+          zc[u][1] = half2_t{(_Float16)z[u].z, (_Float16)z[u].w};
         } else {
-          zc1[256 * s] = half4_t{(_Float16)z[s].x, (_Float16)z[s].y, (_Float16)z[s].z, (_Float16)z[s].w};
+          zc1[256 * u] = half4_t{(_Float16)z[u].x, (_Float16)z[u].y, (_Float16)z[u].z, (_Float16)z[u].w};
         }
       }
     }
     cached_eb = eb;
   };
   auto gather_store = [&](const f32x4 (&z)[8], int cp, bool cvalid) {
-    const int col = 32 * cp + gcol;
-    char* out = h1 + (col >> 4) * 8192 + (16 * (gpiece & 3) + (col & 15)) * 16 + (gpiece >> 2) * 8;
+    char* out = h1 + pslot(32 * cp + gcol);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int u = 0; u < 8; ++u) {
       bf16x4 o4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(cvalid ? fmaxf(z[s][r], 0.f) : 0.f);
-      *(bf16x4*)(out + s * 1024) = o4;
+      for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(cvalid ? fmaxf(z[u][r], 0.f) : 0.f);
+      *(bf16x4*)(out + uslot(u)) = o4;
     }
   };
   auto cache_add = [&](f32x4 (&z)[8], int cp) {  // z += the cached batch-shared part of this column pass
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int u = 0; u < 8; ++u) {
       if (cp == 0) {
-        z[s] += f32x4{(float)zc[s][0][0], (float)zc[s][0][1], (float)zc[s][1][0], (float)zc[s][1][1]};
+        z[u] += f32x4{(float)zc[u][0][0], (float)zc[u][0][1], (float)zc[u][1][0], (float)zc[u][1][1]};
       } else {
-        const half4_t c = zc1[256 * s];
-        z[s] += f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
+        const half4_t c = zc1[256 * u];
+        z[u] += f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
       }
     }
   };
-  // The gather of a tile is split so that its first load round trip passes under other work: gather_issue0 requests the rows
-  // of column pass 0 (first per-sample table) at the END of half 1 - in flight across the barrier and the segment sums of half
-  // 2 - gather_finish completes pass 0 and runs pass 1.
-  int dyn[2] = {0, 0};  // per-sample tables of this launch (rows_pb != 0): exactly NDYN of them (the host checks)
+  // The gather of a tile is split so that its load round trips pass under other work.  fp32 table: gather_issue0 requests the
+  // rows of column pass 0 at the END of half 1 - in flight across the barrier; part 1 (before the segment sums of half 2)
+  // finishes pass 0 and requests pass 1 - a wave's loads queue behind its own earlier stores, so every load of the half is
+  // issued before the aggregate stores; part 2 (after them) finishes pass 1 (both passes in flight from half 1 would need 64
+  // registers across the barrier: it spills).  fp16 table: a pass is 4 loads of 16 bytes = 16 registers, so BOTH passes are
+  // requested at the end of half 1 and half 2 issues no load of its own.
+  int dyn = 0;  // the per-sample table of this launch (rows_pb != 0): exactly one (the host checks)
   if (GATHER) {
-    int nd = 0;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      if (p < a.n_proj && a.p_rows_pb[p] != 0 && nd < NDYN) dyn[nd++] = p;
+    for (int p = 2; p >= 0; --p)
+      if (p < a.n_proj && a.p_rows_pb[p] != 0) dyn = p;
   }
-  auto row_of = [&](TileId t, int p, int cp) -> const float* {
-    int gp4 = 4 * gpiece;
-    asm volatile("" : "+v"(gp4));
-    return a.p_ptr[p] + ((size_t)t.b * (size_t)a.p_rows_pb[p] + (size_t)gidx[cp][p]) * (size_t)a.p_ld[p] + gp4;
+  typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+  auto row_of = [&](TileId t, int cp) -> size_t {  // element offset of the dyn table's row for this thread's column of pass cp
+    return ((size_t)t.b * (size_t)a.p_rows_pb[dyn] + (size_t)gidx[cp][dyn]) * (size_t)a.p_ld[dyn];
   };
-  auto load_rows = [&](f32x4 (&x)[8], const float* row) {
+  auto load_rows = [&](f32x4 (&x)[8], TileId t, int cp) {
+    const float* row = a.p_ptr[dyn] + row_of(t, cp) + poff();
 #pragma unroll
-    for (int s = 0; s < 8; ++s) x[s] = ldg4(row + 32 * s);
+    for (int u = 0; u < 8; ++u) x[u] = ldg4(row + uoff(u));
   };
-  auto gather_issue0 = [&](TileId t, f32x4 (&x0)[8]) {
+  auto load_rows_h = [&](half8_t (&xh)[4], TileId t, int cp) {
+    const _Float16* row = (const _Float16*)a.p_ptr[dyn] + row_of(t, cp) + poff();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xh[i] = *(const GW_AS1 half8_t*)(row + 64 * i);
+  };
+  auto widen = [&](f32x4 (&x)[8], const half8_t (&xh)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = f32x4{(float)xh[i][0], (float)xh[i][1], (float)xh[i][2], (float)xh[i][3]};
+      x[2 * i + 1] = f32x4{(float)xh[i][4], (float)xh[i][5], (float)xh[i][6], (float)xh[i][7]};
+    }
+  };
+  // gx: 32 registers of gathered rows in flight (fp32: pass 0 as 8 x f32x4; fp16: pass 0 in gx[0..3], pass 1 in gx[4..7])
+  auto gather_issue0 = [&](TileId t, f32x4 (&gx)[8]) {
     if (t.eb != cached_eb) prep_chunk(t.eb);
-    load_rows(x0, row_of(t, dyn[0], 0));
+    if constexpr (PH) {
+      half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
+      load_rows_h(reinterpret_cast<half8_t(&)[4]>(gh[0]), t, 0);
+      load_rows_h(reinterpret_cast<half8_t(&)[4]>(gh[4]), t, 1);
+    } else {
+      load_rows(gx, t, 0);
+    }
   };
-  // part 1 (before the segment sums of half 2): pass 0 -> Hbuf1, and the rows of pass 1 requested - a wave's loads queue behind
-  // its own earlier stores, so every load of the half is issued before the aggregate stores; part 2 (after them): pass 1.
-  // (Both passes in flight from half 1 would need 64 registers across the barrier: measured in the build - it spills.)
-  auto gather_part1 = [&](TileId t, f32x4 (&x0)[8]) {
+  auto gather_part1 = [&](TileId t, f32x4 (&gx)[8]) {
     const bool v0 = t.eb * kTileCols + gcol < a.n_edges;
-    if constexpr (NDYN == 2) {
-      f32x4 x1[8];
-      load_rows(x1, row_of(t, dyn[1], 0));
-#pragma unroll
-      for (int s = 0; s < 8; ++s) x0[s] += x1[s];
+    if constexpr (PH) {
+      half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
+      f32x4 x[8];
+      widen(x, reinterpret_cast<half8_t(&)[4]>(gh[0]));
+      cache_add(x, 0);
+      gather_store(x, 0, v0);
+    } else {
+      cache_add(gx, 0);
+      gather_store(gx, 0, v0);
+      load_rows(gx, t, 1);
     }
-    cache_add(x0, 0);
-    gather_store(x0, 0, v0);
-    load_rows(x0, row_of(t, dyn[0], 1));
   };
-  auto gather_part2 = [&](TileId t, f32x4 (&x0)[8]) {
+  auto gather_part2 = [&](TileId t, f32x4 (&gx)[8]) {
     const bool v1 = t.eb * kTileCols + 32 + gcol < a.n_edges;
-    if constexpr (NDYN == 2) {
-      f32x4 x1[8];
-      load_rows(x1, row_of(t, dyn[1], 1));
-#pragma unroll
-      for (int s = 0; s < 8; ++s) x0[s] += x1[s];
+    if constexpr (PH) {
+      half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
+      f32x4 x[8];
+      widen(x, reinterpret_cast<half8_t(&)[4]>(gh[4]));
+      cache_add(x, 1);
+      gather_store(x, 1, v1);
+    } else {
+      cache_add(gx, 1);
+      gather_store(gx, 1, v1);
     }
-    cache_add(x0, 1);
-    gather_store(x0, 1, v1);
   };
   auto tile_row = [&](TileId t) -> size_t { return (size_t)(t.b * a.neb + t.eb); };
   auto prep_dma_issue = [&](TileId t) {  // 32 KiB of layer-1 activations -> Hbuf1: 8 LDS-DMA pieces of 1 KiB per team-A wave
@@ -616,11 +652,25 @@ namespace gw {
 
 int edge16t_launch(const void* edge16_args, bool gather, int n_wg, void* stream) {
   const Edge16Args& a = *(const Edge16Args*)edge16_args;
+  // Three forms exist (the others measured slower than, or did not fit the registers beside, the lock-step kernel's):
+  //   layer-1 tiles by DMA + residual tiles     (processor blocks 1..: per-sample edge features)
+  //   layer 1 gathered, no residual, the per-sample table as fp32 or fp16 rows   (decoder)
   const bool res = a.res_tiles != nullptr;
-  if (!gather) return res ? launch_team(edge16t_kernel<false, 1, true>, n_wg, a, stream) : launch_team(edge16t_kernel<false, 1, false>, n_wg, a, stream);
-  int n_dyn = 0;
-  for (int p = 0; p < a.n_proj; ++p) n_dyn += a.p_rows_pb[p] != 0 ? 1 : 0;
-  if (n_dyn == 1) return res ? launch_team(edge16t_kernel<true, 1, true>, n_wg, a, stream) : launch_team(edge16t_kernel<true, 1, false>, n_wg, a, stream);
+  if (!gather) {
+    if (!res) return set_error(GW_E_UNSUPPORTED, "edge16t: the form with a raw edge operand adds its residual from bf16 edge tiles");
+    return launch_team(edge16t_kernel<false, false, true>, n_wg, a, stream);
+  }
+  if (res) return set_error(GW_E_UNSUPPORTED, "edge16t: the gather form runs without residual");
+  int n_dyn = 0, dyn = 0;
+  for (int p = a.n_proj - 1; p >= 0; --p)
+    if (a.p_rows_pb[p] != 0) {
+      ++n_dyn;
+      dyn = p;
+    }
+  for (int p = 0; p < a.n_proj; ++p)
+    if (a.p_half[p] && (p != dyn || n_dyn != 1)) return set_error(GW_E_UNSUPPORTED, "edge16t: only the per-sample projected table may be fp16 rows");
+  if (n_dyn == 1)
+    return a.p_half[dyn] ? launch_team(edge16t_kernel<true, true, false>, n_wg, a, stream) : launch_team(edge16t_kernel<true, false, false>, n_wg, a, stream);
   // (two per-sample tables - the first processor block - stay on the lock-step kernel: measured 0.43 ms there against 0.49 ms
   //  here, its gather needs both tables of a column pass in flight and does not fit the team's register budget)
   return set_error(GW_E_UNSUPPORTED, "edge16t: the gather form takes exactly one per-sample projected table");

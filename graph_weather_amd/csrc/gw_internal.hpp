@@ -33,6 +33,8 @@ struct ChainArgs {
   const float* proj_w[4];
   float* proj_out[4];
   int n_post;
+  int proj_half;       // bf16 launches: the products are stored as fp16 rows (256 halves per row, GW_LAYOUT_ROWS_F16), clamped to
+                       // the fp16 range - half the bytes for the per-edge gathers that consume them
   // weights
   const float* w1[3];
   const float* b1;

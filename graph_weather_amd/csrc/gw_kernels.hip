@@ -794,6 +794,38 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: unsupported (hidden, n_out, k) combination");
 }
 
+int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w, float* out,
+                        int32_t out_ld, int32_t n_post, const float* const* post_w, void* const* post_out, int32_t post_layout,
+                        void* stream) {
+  if (!x || !w || n_rows < 0 || rows_per_batch <= 0 || n_post <= 0 || n_post > 4 || !post_w || !post_out)
+    return fail(GW_E_BADARG, "gw_mlp_post_forward: bad arguments");
+  if (n_rows == 0) return GW_OK;
+  if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: more than 2^31-1 rows");
+  if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out) return fail(GW_E_BADARG, "gw_mlp_post_forward: missing weights / empty operand");
+  if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: at least 2 hidden layers (n_mid >= 1) are required");
+  if (w->weight_dtype != GW_DTYPE_BF16 || w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || (w->ln_width > 0 && w->ln_width != 256))
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: bf16 weights, hidden 256, 256 outputs with LayerNorm");
+  if (post_layout != GW_LAYOUT_ROWS_F32 && post_layout != GW_LAYOUT_ROWS_F16) return fail(GW_E_BADARG, "gw_mlp_post_forward: bad post_layout");
+  if (out && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: out_ld must be a multiple of 4");
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = (int)n_rows;
+  a.cols_per_batch = rows_per_batch;
+  fill_operand(a, 0, x);
+  fill_weights(a, w);
+  a.out = out;
+  a.out_ld = out ? out_ld : 256;
+  a.out_cols = 256;
+  for (int i = 0; i < n_post; ++i) {
+    if (!post_w[i] || !post_out[i]) return fail(GW_E_BADARG, "gw_mlp_post_forward: null post slice / output");
+    a.proj_w[i] = post_w[i];
+    a.proj_out[i] = (float*)post_out[i];
+  }
+  a.n_post = n_post;
+  a.proj_half = post_layout == GW_LAYOUT_ROWS_F16;
+  return gw::chain16_launch(5, a, x->k, w->hidden, w->n_out, 1, stream);
+}
+
 size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
                                       const gw_operand* e_in, const gw_mlp_weights* w, int32_t flags) {
   if (batch <= 0 || n_edges <= 0 || !x_src || !x_dst || !e_in || !w) return 0;
@@ -848,13 +880,17 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   const bool tiles_out = e_out_any != nullptr && e_out_layout == GW_LAYOUT_EDGE_TILES_BF16;
   if (e_out_any != nullptr && e_out_layout != GW_LAYOUT_ROWS_F32 && e_out_layout != GW_LAYOUT_EDGE_TILES_BF16)
     return fail(GW_E_BADARG, "gw_edge_update_forward: bad e_out_layout");
-  if (x_src->layout != GW_LAYOUT_ROWS_F32 || x_dst->layout != GW_LAYOUT_ROWS_F32)
-    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: node operands must be fp32 rows");
+  const bool half_nodes = x_src->layout == GW_LAYOUT_ROWS_F16 || x_dst->layout == GW_LAYOUT_ROWS_F16;
+  if ((x_src->layout != GW_LAYOUT_ROWS_F32 && x_src->layout != GW_LAYOUT_ROWS_F16) ||
+      (x_dst->layout != GW_LAYOUT_ROWS_F32 && x_dst->layout != GW_LAYOUT_ROWS_F16) ||
+      (half_nodes && (save || !gw::edge16_eligible(x_src, x_dst, e_in, w))))
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: node operands must be fp32 rows (or, projected, for the bf16 path with "
+                                  "resident weights: fp16 product rows)");
   float* e_out = tiles_out ? nullptr : (float*)e_out_any;
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
   const size_t ws16 = gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");
-  if (tiles_in || tiles_out || no_res) {
+  if (tiles_in || tiles_out || no_res || half_nodes) {
     if (save || (ws16 > 0 && (!workspace || workspace_bytes < ws16)) || !gw::edge16_eligible(x_src, x_dst, e_in, w))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
                                     "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");
@@ -903,8 +939,8 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
 
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
                            const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
-                           const gw_activation_save* save, int32_t n_post, const float* const* post_w, float* const* post_out,
-                           float* zero_rows, void* stream) {
+                           const gw_activation_save* save, int32_t n_post, const float* const* post_w, void* const* post_out,
+                           int32_t post_layout, float* zero_rows, void* stream) {
   if (!x || !agg || !w || !x_out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: more than 2^31-1 rows");
@@ -933,9 +969,13 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   for (int i = 0; i < n_post; ++i) {
     if (!post_w[i] || !post_out[i]) return fail(GW_E_BADARG, "gw_node_update_forward: null post slice / output");
     a.proj_w[i] = post_w[i];
-    a.proj_out[i] = post_out[i];
+    a.proj_out[i] = (float*)post_out[i];
   }
   a.n_post = n_post;
+  if (post_layout != GW_LAYOUT_ROWS_F32 && post_layout != GW_LAYOUT_ROWS_F16) return fail(GW_E_BADARG, "gw_node_update_forward: bad post_layout");
+  if (post_layout == GW_LAYOUT_ROWS_F16 && (n_post == 0 || w->weight_dtype != GW_DTYPE_BF16))
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: fp16 post products come with bf16 weights");
+  a.proj_half = post_layout == GW_LAYOUT_ROWS_F16;
   a.zero_rows = zero_rows;
   if (w->weight_dtype == GW_DTYPE_BF16) {
     if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
@@ -946,7 +986,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
 }
 
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
-                       const float* const* w_slices, float* const* outs, int32_t out_ld, int32_t weight_dtype,
+                       const float* const* w_slices, void* const* outs, int32_t out_ld, int32_t out_layout, int32_t weight_dtype,
                        const float* relu_mask, float* zero_rows, void* stream) {
   if (!x || !w_slices || !outs || n_rows < 0 || rows_per_batch <= 0 || n_slices <= 0 || n_slices > 4)
     return fail(GW_E_BADARG, "gw_project_forward: bad arguments (1..4 slices)");
@@ -961,8 +1001,12 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   for (int i = 0; i < n_slices; ++i) {
     if (!w_slices[i] || !outs[i]) return fail(GW_E_BADARG, "gw_project_forward: null slice / output");
     a.proj_w[i] = w_slices[i];
-    a.proj_out[i] = outs[i];
+    a.proj_out[i] = (float*)outs[i];
   }
+  if (out_layout != GW_LAYOUT_ROWS_F32 && out_layout != GW_LAYOUT_ROWS_F16) return fail(GW_E_BADARG, "gw_project_forward: bad out_layout");
+  if (out_layout == GW_LAYOUT_ROWS_F16 && weight_dtype != GW_DTYPE_BF16)
+    return fail(GW_E_UNSUPPORTED, "gw_project_forward: fp16 products come with bf16 slices");
+  a.proj_half = out_layout == GW_LAYOUT_ROWS_F16;
   a.out_ld = out_ld;
   a.out_cols = 256;
   if (relu_mask && (weight_dtype != GW_DTYPE_F32 || n_slices != 1))

@@ -301,12 +301,15 @@ class GraphNetBlock(nn.Module):
 
     def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
             x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
-            tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None, post_w=None, post_zero: bool = False):
+            tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None, post_w=None, post_zero: bool = False,
+            post_half: bool = False):
         """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
         Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``).
         ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch).
         ``post_w`` (inference): packed layer-1 slices of the NEXT block's edge MLP - the node update multiplies the new rows by
-        them in the same launch (and zero-fills the next aggregate with ``post_zero``); returns (x', e', products, next_agg)."""
+        them in the same launch (and zero-fills the next aggregate with ``post_zero``); returns (x', e', products, next_agg).
+        ``post_half``: those products as fp16 rows (bf16 mode, when their consumer is the bf16 edge update with resident weights:
+        the products are gathered once per incident edge, so their bytes dominate what the edge update reads)."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
         if _autograd_on(self, x_src.tensor, x_dst.tensor, e_in.tensor, e_res, x_node.tensor, x_res):
             agg, e_out = ag.edge_update(self.edge_model.edge_mlp, plan, batch, (x_src.spec(), x_dst.spec(), e_in.spec()),
@@ -326,7 +329,7 @@ class GraphNetBlock(nn.Module):
         if post_w is not None:
             next_agg = torch.empty((batch * n_dst, 256), dtype=torch.float32, device=device) if post_zero else None
             x_new, posts = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(), res_x,
-                                                   Operand(agg, n_dst, 256), post_w=post_w, zero_rows=next_agg)
+                                                   Operand(agg, n_dst, 256), post_w=post_w, zero_rows=next_agg, post_half=post_half)
             return x_new, e_out, posts, next_agg
         x_new = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(), res_x,
                                         Operand(agg, n_dst, 256))
@@ -382,7 +385,7 @@ class GraphProcessor(nn.Module):
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
     def run_plan(self, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: bool, batch: int,
-                 want_edges: bool, pre_proj=None, tail_w=None):
+                 want_edges: bool, pre_proj=None, tail_w=None, tail_half: bool = False):
         """Layer 1 of every edge MLP is split (cat[x_s, x_d, e].W1^T = x_s.Ws^T + x_d.Wd^T + e.We^T): the node
         products are computed once per node (shared by its ~7 incident edges) and gathered per edge; when the
         incoming edge features are batch independent (first block after the encoder) their product is cached.
@@ -409,7 +412,7 @@ class GraphProcessor(nn.Module):
             elif self.use_checkpointing:
                 seg = 1
         if seg <= 0 or nb == 0:
-            x, e_cur, _, tail = self._run_blocks(0, nb, x, e, e_shared, plan, batch, want_edges, pre_proj, tail_w)
+            x, e_cur, _, tail = self._run_blocks(0, nb, x, e, e_shared, plan, batch, want_edges, pre_proj, tail_w, tail_half)
             if tail_w is not None:
                 return x, (e_cur if want_edges else None), tail
             return x, (e_cur if want_edges else None)
@@ -469,7 +472,7 @@ class GraphProcessor(nn.Module):
         return self._e0_cache
 
     def _run_blocks(self, lo: int, hi: int, x: torch.Tensor, e: torch.Tensor, e_shared: bool, plan: GraphPlan, batch: int,
-                    want_edges: bool, pre_proj=None, tail_w=None):
+                    want_edges: bool, pre_proj=None, tail_w=None, tail_half: bool = False):
         """Blocks [lo, hi) of the stack; returns (x, e, e_shared, tail products) after them (e of the last block only if
         ``want_edges``)."""
         n, n_edges = plan.n_dst, plan.num_edges
@@ -514,18 +517,24 @@ class GraphProcessor(nn.Module):
             out_kind = "tiles" if (tiled and need_e and not (last and want_edges)) else need_e
             e_res = self._e0_cache[3] if (shared and tiled) else e_cur
             # what the node update of this block also produces (inference): the next block's layer-1 node products
-            post_w, post_zero = None, False
+            post_w, post_zero, post_half = None, False, False
             if not train:
                 pm_n = blk.node_model.node_mlp.packed()
                 if i + 1 < len(self.blocks):
-                    nxt = self.blocks[i + 1].edge_model.edge_mlp.packed()
+                    nxt_mlp = self.blocks[i + 1].edge_model.edge_mlp
+                    nxt = nxt_mlp.packed()
                     if nxt.weight_dtype == pm_n.weight_dtype and i + 1 < hi:
                         post_w, post_zero = [nxt.w1[0], nxt.w1[1]], True
+                        # block i + 1 >= 1 reads per-sample edge tiles, i.e. runs its layer 1 in the bf16 layer-1 kernel, which
+                        # gathers these products once per edge: hand them over as fp16 rows
+                        post_half = (nxt_mlp.compute_dtype == torch.bfloat16 and nxt.n_mid == 1 and nxt.ln_width == 0
+                                     and nxt.gamma is not None and n_edges > 0)
                 elif tail_w is not None and all(w_.dtype == pm_n.w_out.dtype for w_ in tail_w):
                     post_w = list(tail_w)
+                    post_half = bool(tail_half)
             res = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_res, 0 if shared else n_edges,
                           Feed(x, n, "raw"), x, n, out_kind, x.device, tag="processor_edge", agg_zeroed=agg_buf,
-                          post_w=post_w, post_zero=post_zero)
+                          post_w=post_w, post_zero=post_zero, post_half=post_half)
             x, e_new = res[0], res[1]
             if post_w is not None:
                 if post_zero:
@@ -636,20 +645,68 @@ class Encoder(nn.Module):
             return wide.encode(self, features)
         feats = features.contiguous().reshape(B * G, F)
         enc_plan, _ = self._plans(features.device)
-        xg = self.node_encoder.run(feats, B * G, G)  # grid rows only
+        team = self.team_path()
+        ne = self.node_encoder
+        fused_ps = None
+        if team and ne.compute_dtype == torch.bfloat16 and not ne._layout()[4] and 32 < ne.native_k() <= 128:
+            # node encoder and the x[row] product of the edge MLP's layer 1 in ONE launch: the grid rows themselves are never
+            # written (the encoder drops them, encoder.py:219-223) - only Ws . node_encoder(features), as fp16 rows
+            pm_e0 = self.graph_processor.blocks[0].edge_model.edge_mlp.packed()
+            k = ne.native_k()
+            x2 = feats if k <= F else torch.nn.functional.pad(feats, (0, k - F))
+            fused_ps = ops.mlp_post_forward(ne.packed(), Operand(x2, G, k), B * G, G, [pm_e0.w1[0]], post_half=True)[1][0]
+            xg = None
+        else:
+            xg = ne.run(feats, B * G, G)  # grid rows only
         xm = self.mesh_embedding()
         e = self.encoder_edge_embedding(enc_plan)
         blk = self.graph_processor.blocks[0]
         _check_native_dims(*self.graph_processor._dims)
         pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
+        x_src, e_res = Feed(xg, G, "raw"), e
+        if team:
+            # bf16 inference on the team-pipelined edge kernel (csrc/gw_edge16t.hip): every operand of the edge MLP's layer 1
+            # enters as a product - Ws.xg is made once per grid node here (one edge per grid node: the same matrix work the raw
+            # operand would cost inside the edge kernel) and handed over as fp16 rows - and, e' being dropped (encoder.py:219) and
+            # e batch independent, the residual leaves the kernel: sum(LN(.) + e) = sum(LN(.)) + S, and Wa.S joins the cached
+            # node-update product of the mesh rows.
+            pm_e = blk.edge_model.edge_mlp.packed()
+            if fused_ps is None:
+                fused_ps = ops.project_forward([pm_e.w1[0]], Operand(xg, G, 256), B * G, G, out_half=True)[0]
+            x_src = Feed(fused_ps, G, "proj")
+            px_xm = self._team_node_product(blk, enc_plan, e, px_xm)
+            e_res = None
         if post_w is not None:
-            x, _, posts, agg0 = blk.run(B, enc_plan, Feed(xg, G, "raw"), Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e, 0,
+            x, _, posts, agg0 = blk.run(B, enc_plan, x_src, Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e_res, 0,
                                         Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge",
                                         post_w=post_w, post_zero=True)
             return x, posts, agg0
-        x, _ = blk.run(B, enc_plan, Feed(xg, G, "raw"), Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e, 0,
+        x, _ = blk.run(B, enc_plan, x_src, Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e_res, 0,
                        Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge")
         return x
+
+    def team_path(self) -> bool:
+        """Inference in bf16 with everything the team-pipelined edge kernel needs (see ``AssimilatorDecoder.team_path``)."""
+        blk = self.graph_processor.blocks[0]
+        mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
+        if wide.encoder_is_wide(self) or _autograd_on(self) or blk.deterministic:
+            return False
+        if mlp_e.compute_dtype != torch.bfloat16 or mlp_n.compute_dtype != torch.bfloat16:
+            return False
+        pm_e = mlp_e.packed()
+        return pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and self.graphs.enc_plan.num_edges > 0
+
+    def _team_node_product(self, blk, plan: GraphPlan, e: torch.Tensor, px_xm: torch.Tensor) -> torch.Tensor:
+        """Wx.xm + Wa.S with S[dst] = the sum of the (batch-independent) edge features e over the destination's edges: the
+        node-update layer-1 operand of the mesh rows when the edge kernel adds no residual.  Cached per weight version."""
+        def make():
+            pm_n = blk.node_model.node_mlp.packed()
+            n_e = int(e.shape[0])
+            e_sum = ag.segment_sum_rows(e, n_e, 1, 1, plan.n_dst, plan.dst_ptr(), None)
+            pa = ops.project_forward([pm_n.w1[1]], Operand(e_sum, plan.n_dst, 256), plan.n_dst, plan.n_dst)[0]
+            return wide.add_rows(px_xm, pa)
+
+        return self._cached("enc_proj_team", list(self.parameters()), make)
 
     def _static_projections(self, blk, xm: torch.Tensor, e: torch.Tensor):
         """Batch-independent layer-1 products of the encoder block (mesh rows are the same for every sample,
@@ -780,6 +837,19 @@ class AssimilatorDecoder(nn.Module):
             self._cache["dec_e"] = (key, self.edge_encoder.table(plan.edge_attr))
         return self._cache["dec_e"][1]
 
+    def team_path(self) -> bool:
+        """Inference in bf16 with everything the team-pipelined edge kernel needs (csrc/gw_edge16t.hip): one middle layer,
+        LayerNorm over all 256 features, atomics mode, node and edge MLP of the block in the same dtype.  Then the decoder's edge
+        update runs without residual (the sums of e enter the node update) and takes its layer-1 node products as fp16 rows."""
+        blk = self.graph_processor.blocks[0]
+        mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
+        if wide.decoder_is_wide(self) or _autograd_on(self) or blk.deterministic:
+            return False
+        if mlp_e.compute_dtype != torch.bfloat16 or mlp_n.compute_dtype != torch.bfloat16:
+            return False
+        pm_e = mlp_e.packed()
+        return pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and self.graphs.dec_plan.num_edges > 0
+
     def decode(self, processor_features: torch.Tensor, batch_size: int,
                residual: Optional[torch.Tensor] = None, ps: Optional[torch.Tensor] = None) -> torch.Tensor:
         """assimilator_decoder.py:173-200 (+ decoder.py:93 when ``residual`` [B*G, ld] is given).  ``ps`` (inference, fused
@@ -806,8 +876,11 @@ class AssimilatorDecoder(nn.Module):
             pe = ag.project(mlp_e, (2,), e, n_e, n_e)[0]
         else:
             pm_e = mlp_e.packed()
+            team = self.team_path()
             if ps is None:
-                ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M)[0]
+                ps = ops.project_forward([pm_e.w1[0]], Operand(processor_features.contiguous(), M, 256), B * M, M, out_half=team)[0]
+            elif ps.dtype == torch.float16 and not team:
+                raise RuntimeError("graph_weather_amd: fp16 layer-1 products were handed to a decoder that cannot take them")
             key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
             hit = self._cache.get("dec_pe")
             if hit is None or hit[0] != key:
@@ -816,7 +889,7 @@ class AssimilatorDecoder(nn.Module):
             x_node = FEED_ZERO
             if mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and n_e > 0:
                 pm_n = blk.node_model.node_mlp.packed()
-                if blk.deterministic or pm_n.weight_dtype != pm_e.weight_dtype:
+                if not team:
                     # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
                     hit = self._cache.get("dec_e_tiles")
                     if hit is None or hit[0] != key:
@@ -883,7 +956,8 @@ def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "Assimila
     x, posts, agg0 = encoder.encode(features, post_w=[first.w1[0], first.w1[1]])
     n_streams = gp.forward_streams(B)
     if n_streams <= 1:
-        x, _, tail = gp.run_plan(x, lat_plan, e_lat, True, B, False, pre_proj=(posts[0], posts[1], agg0), tail_w=[dec_e.w1[0]])
+        x, _, tail = gp.run_plan(x, lat_plan, e_lat, True, B, False, pre_proj=(posts[0], posts[1], agg0), tail_w=[dec_e.w1[0]],
+                                 tail_half=decoder.team_path())
         return decoder.decode(x, B, residual=residual, ps=None if tail is None else tail[0])
     # The mesh stack as independent per-sample chains on separate HIP streams (batch elements never interact,
     # encoder.py:212-218).  One batched launch of a mesh-sized kernel fills the chip unevenly - 1 287 64-column tiles on 512
@@ -902,7 +976,8 @@ def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "Assimila
         st.wait_stream(main)
         with torch.cuda.stream(st):
             pre = (posts[0][lo * M:hi * M], posts[1][lo * M:hi * M], agg0[lo * M:hi * M])
-            xo, _, tl = gp.run_plan(x[lo * M:hi * M], lat_plan, e_lat, True, hi - lo, False, pre_proj=pre, tail_w=[dec_e.w1[0]])
+            xo, _, tl = gp.run_plan(x[lo * M:hi * M], lat_plan, e_lat, True, hi - lo, False, pre_proj=pre, tail_w=[dec_e.w1[0]],
+                                    tail_half=decoder.team_path())
         xs.append(xo)
         tails.append(tl[0])
         lo = hi

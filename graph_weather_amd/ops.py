@@ -97,6 +97,12 @@ class Operand:
             _require(self.tensor, "edge tiles", torch.uint8)
             # rows_per_batch: n_edges = one tile set per batch element, 0 = one set shared by the batch
             return GwOperand(self.tensor.data_ptr(), None, int(self.rows_per_batch), 256, 256, 0, _lib.LAYOUT_EDGE_TILES_BF16)
+        if self.tensor.dtype == torch.float16:  # layer-1 node products as fp16 rows (include/gw_amd.h: GW_LAYOUT_ROWS_F16)
+            if not self.projected or self.index is not None:
+                raise RuntimeError("graph_weather_amd: fp16 rows are a format of projected (layer-1 product) operands only")
+            _require(self.tensor, "operand", torch.float16)
+            return GwOperand(self.tensor.data_ptr(), None, int(self.rows_per_batch), int(self.tensor.stride(0)), int(self.k), 1,
+                             _lib.LAYOUT_ROWS_F16)
         _require(self.tensor, "operand")
         if self.index is not None:
             _require(self.index, "operand index", torch.int32)
@@ -226,22 +232,42 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
     return out
 
 
+def mlp_post_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, post_w: Sequence[torch.Tensor],
+                     post_half: bool = False, want_out: bool = False):
+    """graph_net_block.py:63-77 on ``n_rows`` rows, then the products of the output rows with packed [256, 256] slices in the same
+    launch (include/gw_amd.h: gw_mlp_post_forward).  Returns (out or None, [products])."""
+    import ctypes
+
+    dev = x.tensor.device
+    out = torch.empty((n_rows, 256), dtype=torch.float32, device=dev) if want_out else None
+    n_post = len(post_w)
+    outs = [torch.empty((n_rows, 256), dtype=torch.float16 if post_half else torch.float32, device=dev) for _ in range(n_post)]
+    wp = (ctypes.c_void_p * n_post)(*[w_.data_ptr() for w_ in post_w])
+    op = (ctypes.c_void_p * n_post)(*[o_.data_ptr() for o_ in outs])
+    with on_device_of(outs[0]):
+        _lib.check(_lib.lib().gw_mlp_post_forward(n_rows, max(1, rows_per_batch), x.c(), pm.c(), None if out is None else out.data_ptr(),
+                                                  256, n_post, wp, op, _lib.LAYOUT_ROWS_F16 if post_half else _lib.LAYOUT_ROWS_F32,
+                                                  _stream(outs[0])), "gw_mlp_post_forward")
+    return out, outs
+
+
 def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, rows_per_batch: int,
                     weight_dtype: Optional[int] = None, relu_mask: Optional[torch.Tensor] = None,
-                    zero_rows: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                    zero_rows: Optional[torch.Tensor] = None, out_half: bool = False) -> List[torch.Tensor]:
     """out_s = x . W_s^T for up to four packed [256, 256] layer-1 slices in one launch (layer-1 split of
     graph_net_block.py:131-134 / :189: products over node tables are shared by all incident edges)."""
     import ctypes
 
     dev = x.tensor.device
     n = len(w_slices)
-    outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=dev) for _ in range(n)]
+    outs = [torch.empty((n_rows, 256), dtype=torch.float16 if out_half else torch.float32, device=dev) for _ in range(n)]
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w_slices])
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     if weight_dtype is None:
         weight_dtype = _lib.DTYPE_BF16 if w_slices[0].dtype == torch.bfloat16 else _lib.DTYPE_F32
     with on_device_of(outs[0]):
-        _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256, weight_dtype,
+        _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256,
+                                                 _lib.LAYOUT_ROWS_F16 if out_half else _lib.LAYOUT_ROWS_F32, weight_dtype,
                                                  None if relu_mask is None else relu_mask.data_ptr(),
                                                  None if zero_rows is None else zero_rows.data_ptr(), _stream(outs[0])),
                    "gw_project_forward")
@@ -300,7 +326,8 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
 
 def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, x_res: Operand, agg: Operand,
                         out: Optional[torch.Tensor] = None, save: Optional[SavedActivations] = None,
-                        post_w: Optional[Sequence[torch.Tensor]] = None, zero_rows: Optional[torch.Tensor] = None):
+                        post_w: Optional[Sequence[torch.Tensor]] = None, zero_rows: Optional[torch.Tensor] = None,
+                        post_half: bool = False):
     """graph_net_block.py:189-191 (NodeProcessor after aggregation).  With ``post_w`` (packed [256, 256] slices of the NEXT
     block's layer-1 weight) the products of the new rows with them are computed in the same launch: returns
     (x_new, [products]); ``zero_rows`` [n_rows, 256] is zero-filled on the side (the next block's aggregate)."""
@@ -314,12 +341,13 @@ def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Oper
     n_post = 0 if post_w is None else len(post_w)
     outs, wp, op = [], None, None
     if n_post:
-        outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=dev) for _ in range(n_post)]
+        outs = [torch.empty((n_rows, 256), dtype=torch.float16 if post_half else torch.float32, device=dev) for _ in range(n_post)]
         wp = (ctypes.c_void_p * n_post)(*[w_.data_ptr() for w_ in post_w])
         op = (ctypes.c_void_p * n_post)(*[o_.data_ptr() for o_ in outs])
     with on_device_of(out):
         _lib.check(_lib.lib().gw_node_update_forward(n_rows, rows_per_batch, x.c(), x_res.c(), agg.c(), wc, out.data_ptr(),
                                                      int(out.stride(0)), None if save is None else save.c(), n_post, wp, op,
+                                                     _lib.LAYOUT_ROWS_F16 if (post_half and n_post) else _lib.LAYOUT_ROWS_F32,
                                                      None if zero_rows is None else zero_rows.data_ptr(), _stream(out)),
                    "gw_node_update_forward")
     return (out, outs) if post_w is not None else out

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 11
+#define GW_ABI_VERSION 12
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -51,6 +51,12 @@ extern "C" {
  * gw_edge_rows_to_tiles() converts rows a caller hands over. */
 #define GW_LAYOUT_ROWS_F32 0
 #define GW_LAYOUT_EDGE_TILES_BF16 1
+/* GW_LAYOUT_ROWS_F16: layer-1 NODE PRODUCTS (X . W1_slice^T, gw_project_forward / the post products of gw_node_update_forward)
+ * as fp16 rows of 256 halves (ld counts halves), values clamped to the fp16 range - bf16 mode only: the products are gathered
+ * once per incident edge (~7 times on the mesh, ~77 times for a decoder source), so their bytes, not the edge features', are
+ * most of what an edge update reads; fp16 keeps 11 significant bits in front of the bf16 rounding of the layer-1 activation.
+ * Accepted as a projected x_src / x_dst operand by the bf16 edge update with resident weights (csrc/gw_edge16*.hip). */
+#define GW_LAYOUT_ROWS_F16 2
 
 /* flags of gw_edge_update_forward.  GW_EDGE_DETERMINISTIC: the segment sums (scatter_sum, graph_net_block.py:188) are
  * bitwise reproducible from run to run - partial sums of segments that cross a 64-edge tile are parked in per-tile carry
@@ -126,12 +132,23 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
                    const gw_operand* residual /* may be NULL */, float* out, int32_t out_ld,
                    const struct gw_activation_save* save /* may be NULL */, void* stream);
 
+/* The same MLP whose output rows y are, while still in registers, multiplied by n_post (1..4) packed [256, 256] slices:
+ * post_out[s][c] = y[c] . post_w[s]^T (rows of 256; post_layout GW_LAYOUT_ROWS_F32 / _F16) - Encoder.node_encoder on the grid
+ * rows (encoder.py:205) followed by the x[row] slice of the encoder block's edge MLP layer 1 (graph_net_block.py:131-134: one
+ * edge per grid node, so the product costs what the raw operand would cost inside the edge kernel).  out may be NULL when only
+ * the products are wanted (the encoder drops the grid rows, encoder.py:219-223).  bf16 weights, hidden 256, 256 outputs with
+ * LayerNorm, 33..128 input features. */
+int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
+                        float* out /* may be NULL */, int32_t out_ld, int32_t n_post, const float* const* post_w,
+                        void* const* post_out, int32_t post_layout, void* stream);
+
 /* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
  * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7
  * edges incident to a node, and the ones over batch-independent tables are cacheable.)
  * out_s[c, :] = x[c, :256] . W_s^T for s < n_slices (<= 4); W_s = packed [256, 256] slices from gw_pack_linear. */
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
-                       const float* const* w_slices, float* const* outs, int32_t out_ld,
+                       const float* const* w_slices, void* const* outs, int32_t out_ld,
+                       int32_t out_layout /* GW_LAYOUT_ROWS_F32, or GW_LAYOUT_ROWS_F16 (bf16 slices; out_ld in halves) */,
                        int32_t weight_dtype /* GW_DTYPE_* of the slices */,
                        const float* relu_mask /* NULL, or [n_rows, 256]: out *= (relu_mask > 0) - ReLU backward fused into an
                                                   input-gradient product (backward pass; single fp32 slice) */,
@@ -176,7 +193,8 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
                            const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
                            const struct gw_activation_save* save /* may be NULL */,
-                           int32_t n_post /* 0..4 */, const float* const* post_w, float* const* post_out,
+                           int32_t n_post /* 0..4 */, const float* const* post_w, void* const* post_out,
+                           int32_t post_layout /* GW_LAYOUT_ROWS_F32, or GW_LAYOUT_ROWS_F16 (bf16 weights) */,
                            float* zero_rows /* may be NULL */, void* stream);
 /* n_post > 0: while the new rows are still in registers they are multiplied by n_post packed [256, 256] slices (packing and
  * dtype of w) and the products written to post_out[s] [n_rows, 256]: post_out[s][j] = x_new[j] . post_w[s]^T - the layer-1

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(cdll, name), name
     L = _lib.lib()
-    assert L.gw_version() == 11
+    assert L.gw_version() == 12
     assert L.gw_packed_floats(256, 0, 256) == 256 * 256
     assert L.gw_packed_floats(78, 0, 128) == 32 * 2 * 256
     assert L.gw_packed_floats(256, 0, 102) == 28 * 4 * 256
@@ -41,7 +41,7 @@ def test_argument_validation_without_gpu():
     assert b"bad arguments" in L.gw_last_error()
     assert L.gw_edge_update_forward(0, 10, None, None, None, None, None, None, None, None, 0, None, 1, None, None, 0, 0, None) == -1
     assert L.gw_edge_update_workspace_bytes(2, 100, None, None, None, None, 0) == 0
-    assert L.gw_project_forward(10, 10, None, 1, None, None, 256, 0, None, None, None) == -1
+    assert L.gw_project_forward(10, 10, None, 1, None, None, 256, 0, 0, None, None, None) == -1
     assert L.gw_pack_linear_bf16(None, 256, 256, 0, 256, None, None) == -1
     assert L.gw_packed_bytes_bf16(256, 0, 256) == 8 * 16 * 1024  # 8 K-steps x 16 row tiles x 1 KiB
     assert L.gw_packed_bytes_bf16(78, 0, 128) == 4 * 8 * 1024    # 5 tiles padded to 8

@@ -41,17 +41,59 @@ def test_team_kernel_batch_chunks_agree_with_the_lock_step_kernel():
     pe = torch.randn((E, 256), generator=g).to(DEV)
     e = torch.randn((E, 256), generator=g).to(DEV)
     tiles = ops.edge_rows_to_tiles(e, 1, E, E)
-    out = []
-    for det in (False, True):
-        agg = torch.zeros((B * n_dst, 256), device=DEV)
-        ops.edge_update_forward(pm, B, src, dst, Operand(ps, n_src, 256, projected=True), ops.ZERO, Operand(pe, 0, 256, projected=True),
-                                Operand(tiles, 0, 256, tiles=True), n_dst, agg, None, deterministic=det)
-        out.append(agg)
+    args = (pm, B, src, dst, Operand(ps, n_src, 256, projected=True), ops.ZERO, Operand(pe, 0, 256, projected=True))
+    agg_team = torch.zeros((B * n_dst, 256), device=DEV)
+    ops.edge_update_forward(*args, ops.ZERO, n_dst, agg_team, None)  # team kernel: no residual ...
+    e_sum = torch.zeros((n_dst, 256), device=DEV).index_add_(0, dst.long(), e.to(torch.bfloat16).float())  # (test arithmetic)
+    agg_team = agg_team.reshape(B, n_dst, 256) + e_sum[None]  # ... + the per-destination sums of the bf16-rounded e
+    agg_lock = torch.zeros((B * n_dst, 256), device=DEV)
+    ops.edge_update_forward(*args, Operand(tiles, 0, 256, tiles=True), n_dst, agg_lock, None, deterministic=True)
     torch.cuda.synchronize()
-    scale = out[1].abs().max().item()
-    err = (out[0] - out[1]).abs().max().item()
+    agg_lock = agg_lock.reshape(B, n_dst, 256)
+    scale = agg_lock.abs().max().item()
+    err = (agg_team - agg_lock).abs().max().item()
     print(f"[team chunks] E={E} B={B}: team vs lock-step max {err:.3e} of scale {scale:.3e}")
     assert 0 < err <= 1e-2 * scale
+
+
+def test_fp16_product_rows_equal_fp32_rows_of_the_same_values():
+    """GW_LAYOUT_ROWS_F16: the layer-1 node products as fp16 rows give what fp32 rows holding the same (fp16-representable) values
+    give - in the team kernel's gather (decoder form) and in the layer-1 kernel of a block with per-sample edge tiles."""
+    rs = np.random.RandomState(21)
+    B, n_src, n_dst, E = 3, 90, 64, 1100
+    pm = _edge_mlp(rs)
+    dst_np = np.sort(rs.randint(0, n_dst, size=E))
+    dst = torch.from_numpy(dst_np.astype(np.int32)).to(DEV)
+    src = torch.from_numpy(rs.randint(0, n_src, size=E).astype(np.int32)).to(DEV)
+    ps16 = torch.from_numpy(rs.standard_normal((B * n_src, 256)).astype(np.float32)).to(DEV).half()
+    pd16 = torch.from_numpy(rs.standard_normal((B * n_dst, 256)).astype(np.float32)).to(DEV).half()
+    pe = torch.from_numpy(rs.standard_normal((E, 256)).astype(np.float32)).to(DEV)
+    # decoder form: one per-sample table, shared edge products, no residual
+    res = []
+    for tab in (ps16, ps16.float()):
+        agg = torch.zeros((B * n_dst, 256), device=DEV)
+        ops.edge_update_forward(pm, B, src, dst, Operand(tab, n_src, 256, projected=True), ops.ZERO, Operand(pe, 0, 256, projected=True),
+                                ops.ZERO, n_dst, agg, None)
+        res.append(agg)
+    torch.cuda.synchronize()
+    assert (res[0] - res[1]).abs().max().item() <= 2e-5 * res[1].abs().max().item()
+    # processor form: per-sample edge tiles as the raw operand and residual, both node tables per sample
+    e = torch.from_numpy(rs.standard_normal((B * E, 256)).astype(np.float32)).to(DEV)
+    tiles = ops.edge_rows_to_tiles(e, B, E, E)
+    res = []
+    for a_, b_ in ((ps16, pd16), (ps16.float(), pd16.float())):
+        agg = torch.zeros((B * n_dst, 256), device=DEV)
+        e_out = torch.empty(ops.edge_tiles_bytes(B, E), dtype=torch.uint8, device=DEV)
+        ops.edge_update_forward(pm, B, src, dst, Operand(a_, n_src, 256, projected=True), Operand(b_, n_dst, 256, projected=True),
+                                Operand(tiles, E, 256, tiles=True), Operand(tiles, E, 256, tiles=True), n_dst, agg, e_out)
+        res.append((agg, e_out))
+    torch.cuda.synchronize()
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 2e-5 * res[1][0].abs().max().item()
+    assert torch.equal(res[0][1], res[1][1])  # e' tiles: bitwise (same products, same order inside a tile)
+    # fp16 rows are a format of projected operands of the resident-weight path only
+    with pytest.raises(RuntimeError):
+        ops.edge_update_forward(pm, B, src, dst, Operand(ps16, n_src, 256, projected=False), ops.ZERO, Operand(pe, 0, 256, projected=True),
+                                ops.ZERO, n_dst, res[0][0], None)
 
 
 def test_team_kernel_without_residual_plus_segment_sums_of_e():
@@ -76,7 +118,9 @@ def test_team_kernel_without_residual_plus_segment_sums_of_e():
     want = agg_res.reshape(B, n_dst, 256)
     got = agg_no.reshape(B, n_dst, 256) + e_sum[None]
     err = (got - want).abs().max().item()
-    assert err <= 2e-5 * want.abs().max().item(), err
+    # (the residual form runs on the lock-step kernel, the other on the team kernel: same bf16 products; fp16 cache of the shared
+    #  layer-1 part, v_rsq and summation order differ - a few 1e-3 of the scale; a dropped or doubled residual would be O(1))
+    assert err <= 1e-2 * want.abs().max().item(), err
     # e' cannot be produced without its residual operand
     with pytest.raises(RuntimeError):
         ops.edge_update_forward(*args, ops.ZERO, n_dst, agg_no, torch.empty((B * E, 256), device=DEV))
