@@ -24,7 +24,7 @@ EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
     "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector",
     "gw_mlp_forward", "gw_mlp_post_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
-    "gw_edge_rows_to_tiles", "gw_node_update_forward",
+    "gw_edge_rows_to_tiles", "gw_node_update_forward", "gw_node_update_head_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
     "gw_segment_sum_rows", "gw_normalized_mse_backward", "gw_adamw_step", "gw_nudging_forward", "gw_nudging_backward",
     "gw_linear_forward", "gw_linear_gather_forward", "gw_layernorm_forward", "gw_add_rows", "gw_gather_rows_wide", "gw_segment_sum_rows_wide",
@@ -125,6 +125,9 @@ def lib():
     L.gw_node_update_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwOperand),
                                          POINTER(GwMlpWeights), c_void_p, c_int32, POINTER(GwActivationSave), c_int32,
                                          POINTER(c_void_p), POINTER(c_void_p), c_int32, c_void_p, c_void_p]
+    L.gw_node_update_head_forward.restype = c_int
+    L.gw_node_update_head_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwOperand), POINTER(GwMlpWeights),
+                                              POINTER(GwMlpWeights), POINTER(GwOperand), c_void_p, c_int32, c_void_p]
     L.gw_project_forward.restype = c_int
     L.gw_project_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), c_int32, POINTER(c_void_p), POINTER(c_void_p),
                                      c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]

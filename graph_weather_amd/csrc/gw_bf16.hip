@@ -163,7 +163,7 @@ __device__ __forceinline__ const float* operand_row16(const float* ptr, const in
 }
 
 // K1S: 32-wide K-steps of a raw layer-1 operand (8: k = 256, 4: k <= 128, 1: k <= 32); HT / OT: hidden / output row tiles.
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST = false>
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds16[];
   constexpr int HTP = (HT + 3) / 4 * 4, OTP = (OT + 3) / 4 * 4;
@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     for (int g = 0; g < NG; ++g) relu_to_bin<HT>(reinterpret_cast<bf16x8(&)[HKS]>(bin[g]), acc[g]);
     __builtin_amdgcn_sched_barrier(0);
     init_bias16<OT>(o, a.b_out, q);
-    pass16<HKS, BKS, OT, OTP>(o, bin, w_out, POST ? (const char*)a.proj_w[0] : nullptr, POST ? H_CS * H_STEP : 0, lds16, parity, lane, wave);
+    pass16<HKS, BKS, OT, OTP>(o, bin, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
+                              POST ? H_CS * H_STEP : (HEAD ? 2 * 8 * 1024 : 0), lds16, parity, lane, wave);
   }
 
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   }
 
   // ---- residual ----
-  if (!SINGLE && a.res_ptr != nullptr) {
+  if (!SINGLE && !HEAD && a.res_ptr != nullptr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const float* rrow = operand_row16(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]);
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
 
   // ---- store ----
   float* outp = SINGLE ? a.proj_out[blockIdx.y] : a.out;
-  if (outp != nullptr) {
+  if (!HEAD && outp != nullptr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (valid[g]) {
@@ -346,6 +347,49 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
           } else {
             stg4(orow + f0, o[g][t]);
           }
+        }
+      }
+    }
+  }
+
+
+  // ---- HEAD: the output head on the new rows while they are still in registers (ChainArgs): 256 -> 128 relu -> 128 relu ->
+  // <= 80 features (+ residual rows), e.g. AssimilatorDecoder.node_decoder + the Decoder residual (assimilator_decoder.py:197,
+  // decoder.py:93) behind the decoder's node update: the [rows, 256] table between them (1 GB at 1 degree, batch 16) is never
+  // written or read ----
+  if constexpr (HEAD) {
+    static_assert(!HEAD || (OT == 16 && HT == 16 && SHARE_ACC && !POST && !SINGLE), "HEAD follows a 256-wide node update");
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bin[g][s] = pack8(o[g][2 * s], o[g][2 * s + 1]);  // (no relu: the head's input is the LayerNorm output)
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int HS = 8 * 1024;  // bytes of one K-step of a packed slice with <= 8 row tiles
+    f32x4 hh[NG][8];
+    init_bias16<8>(hh, a.hd_b1, q);
+    pass16<8, BKS, 8, 8>(hh, bin, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, lds16, parity, lane, wave);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) relu_to_bin<8>(reinterpret_cast<bf16x8(&)[4]>(bin[g]), hh[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    init_bias16<8>(hh, a.hd_b2, q);
+    pass16<4, BKS, 8, 8>(hh, bin, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, lds16, parity, lane, wave);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) relu_to_bin<8>(reinterpret_cast<bf16x8(&)[4]>(bin[g]), hh[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 y[NG][5];
+    init_bias16<5>(y, a.hd_b3, q);
+    pass16<4, BKS, 5, 8>(y, bin, (const char*)a.hd_w3, nullptr, 0, lds16, parity, lane, wave);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (valid[g]) {
+        const float* rrow = a.res_ptr ? operand_row16(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]) : nullptr;
+        float* orow = a.out + (size_t)cc[g] * (size_t)a.out_ld;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const int f0 = 16 * t + 4 * q;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) stg1(orow + f0 + r, y[g][t][r] + (rrow ? ldg1(rrow + f0 + r) : 0.f));
         }
       }
     }
@@ -528,6 +572,8 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
       return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, true>, a, stream, grid_y, kLdsWeights);
     case 4:
       return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+    case 6:  // node update + output head (decoder)
+      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true>, a, stream, 1, kLdsWeights);
     case 5:  // mlp rows + POST products of the output rows (node encoder -> layer-1 products of the encoder's edge MLP)
       if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32)
         return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);

@@ -33,6 +33,14 @@ struct ChainArgs {
   const float* proj_w[4];
   float* proj_out[4];
   int n_post;
+  // HEAD mode (bf16 node update of the decoder): the new rows never leave the registers - they feed the output head
+  // (AssimilatorDecoder.node_decoder, 256 -> 128 -> 128 -> <= 80 features, no norm) and only its output (+ residual) is stored
+  const float* hd_w1;  // packed [128, 256]
+  const float* hd_b1;
+  const float* hd_w2;  // packed [128, 128]
+  const float* hd_b2;
+  const float* hd_w3;  // packed [<= 80, 128] (5 row tiles)
+  const float* hd_b3;
   int proj_half;       // bf16 launches: the products are stored as fp16 rows (256 halves per row, GW_LAYOUT_ROWS_F16), clamped to
                        // the fp16 range - half the bytes for the per-edge gathers that consume them
   // weights
@@ -71,7 +79,8 @@ struct ChainArgs {
   float* save_y;
 };
 
-// bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices), 4 node update + POST.
+// bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices), 4 node update + POST,
+// 5 mlp + POST, 6 node update + output head.
 int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
 
 // debug timestamp hook (gw_debug_timestamps) and tuning overrides, defined in gw_kernels.hip

@@ -985,6 +985,45 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }
 
+int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
+                                const gw_mlp_weights* w, const gw_mlp_weights* head, const gw_operand* residual, float* out,
+                                int32_t out_ld, void* stream) {
+  if (!x || !agg || !w || !head || !out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_head_forward: bad arguments");
+  if (n_rows == 0) return GW_OK;
+  if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: more than 2^31-1 rows");
+  if (w->weight_dtype != GW_DTYPE_BF16 || head->weight_dtype != GW_DTYPE_BF16)
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: bf16 weights only (the fp32 path runs the two launches)");
+  if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out || bad_layers(w) || w->n_mid != 1 || !w->ln_gamma ||
+      (w->ln_width > 0 && w->ln_width != 256))
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: node MLP must be 512 -> 256 -> 256 -> 256 with LayerNorm");
+  if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: agg must be 256 wide (raw)");
+  if (x->k != 0 && (bad256(x) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: x must be 256 wide or zeros");
+  if (head->hidden != 128 || head->n_mid != 1 || head->n_out > 80 || head->n_out <= 0 || head->ln_gamma || !head->w1[0] || !head->b1 ||
+      !head->w_mid || !head->b_mid || !head->w_out || !head->b_out)
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: the head must be 256 -> 128 -> 128 -> <= 80 features without norm");
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_cols = (int)n_rows;
+  a.cols_per_batch = rows_per_batch;
+  fill_operand(a, 0, x);
+  fill_operand(a, 1, agg);
+  fill_weights(a, w);
+  a.hd_w1 = head->w1[0];
+  a.hd_b1 = head->b1;
+  a.hd_w2 = head->w_mid;
+  a.hd_b2 = head->b_mid;
+  a.hd_w3 = head->w_out;
+  a.hd_b3 = head->b_out;
+  if (residual && residual->k != 0) {
+    if (!residual->ptr) return fail(GW_E_BADARG, "gw_node_update_head_forward: null residual");
+    fill_residual(a, residual);
+  }
+  a.out = out;
+  a.out_ld = out_ld;
+  a.out_cols = head->n_out;
+  return gw::chain16_launch(6, a, 256, 256, 256, 1, stream);
+}
+
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
                        const float* const* w_slices, void* const* outs, int32_t out_ld, int32_t out_layout, int32_t weight_dtype,
                        const float* relu_mask, float* zero_rows, void* stream) {

@@ -302,7 +302,7 @@ class GraphNetBlock(nn.Module):
     def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
             x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
             tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None, post_w=None, post_zero: bool = False,
-            post_half: bool = False):
+            post_half: bool = False, head=None):
         """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
         Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``).
         ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch).
@@ -326,6 +326,14 @@ class GraphNetBlock(nn.Module):
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src, plan.dst, x_src.operand(), x_dst.operand(),
                                 e_in.operand(), res_op, n_dst, agg, e_out, tag=tag, deterministic=self.deterministic)
         res_x = ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256)
+        if head is not None:
+            # (bf16 inference, decoder) the node update and the output head that follows it in one launch: ``head`` = (packed
+            # head MLP, residual operand or None); returns the head's output instead of the new node rows
+            if x_res is not None:
+                raise RuntimeError("graph_weather_amd: the fused node update + head has no node residual (decoder rows are zeros)")
+            y = ops.node_update_head_forward(self.node_model.node_mlp.packed(), head[0], batch * n_dst, n_dst, x_node.operand(),
+                                             Operand(agg, n_dst, 256), head[1])
+            return y, e_out
         if post_w is not None:
             next_agg = torch.empty((batch * n_dst, 256), dtype=torch.float32, device=device) if post_zero else None
             x_new, posts = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(), res_x,
@@ -908,18 +916,27 @@ class AssimilatorDecoder(nn.Module):
                                                                              plan.n_dst, plan.n_dst)[0])
                     x_node = Feed(self._cache["dec_e_sum"][1], 0, "proj")
                     e = None
-        if not train and x_node is not FEED_ZERO:
-            xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), None, 0, x_node, None, 0, False, dev,
-                            tag="decoder_edge")
-        else:
-            xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
-                            tag="decoder_edge")
         res = None
         if residual is not None:
             if residual.dim() != 2 or residual.shape[0] != B * G or residual.shape[1] < self.output_dim:
                 raise RuntimeError("graph_weather_amd: the residual (start features) must have batch*num_latlons rows of at least "
                                    "output_dim = %d features, got %s" % (self.output_dim, tuple(residual.shape)))
             res = Operand(residual, G, self.output_dim)
+        if not train and x_node is not FEED_ZERO:
+            head = None
+            nd = self.node_decoder
+            if nd.compute_dtype == torch.bfloat16 and not wide.is_wide(nd) and not nd._layout()[4]:
+                pm_h = nd.packed()
+                if pm_h.hidden == 128 and pm_h.n_mid == 1 and pm_h.n_out <= 80 and pm_h.gamma is None:
+                    head = (pm_h, res)  # node update + node_decoder (+ residual) in one launch: the grid-row table is never written
+            out, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), None, 0, x_node, None, 0, False, dev,
+                             tag="decoder_edge", head=head)
+            if head is not None:
+                return out.reshape(B, G, self.output_dim)
+            xg = out
+        else:
+            xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
+                            tag="decoder_edge")
         y = self.node_decoder.run(xg, B * G, G, residual=res)
         if y.shape[1] != self.output_dim:
             y = y[:, :self.output_dim]

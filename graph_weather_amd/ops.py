@@ -353,6 +353,21 @@ def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Oper
     return (out, outs) if post_w is not None else out
 
 
+def node_update_head_forward(pm: PackedMLP, head: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, agg: Operand,
+                             residual: Optional[Operand]) -> torch.Tensor:
+    """graph_net_block.py:189-191 followed by the output head (+ residual) in one launch: include/gw_amd.h:
+    gw_node_update_head_forward.  Returns [n_rows, head.n_out]."""
+    out = torch.empty((n_rows, head.n_out), dtype=torch.float32, device=agg.tensor.device)
+    wc = pm.c((x.k > 0 and not x.projected, True, False))
+    rc = residual.c() if residual is not None else None
+    if rc is not None:
+        rc.k = head.n_out
+    with on_device_of(out):
+        _lib.check(_lib.lib().gw_node_update_head_forward(n_rows, rows_per_batch, x.c(), agg.c(), wc, head.c(), rc, out.data_ptr(),
+                                                          int(out.stride(0)), _stream(out)), "gw_node_update_head_forward")
+    return out
+
+
 def normalized_mse_forward(pred: torch.Tensor, target: torch.Tensor, lat_weights: torch.Tensor,
                            inv_var: Optional[torch.Tensor]) -> torch.Tensor:
     """losses.py:66-94."""

@@ -202,6 +202,15 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
  * (graph_net_block.py:293-301) needs no projection launch between blocks.  zero_rows: [n_rows, 256] filled with zeros on the
  * side (the next block's aggregate buffer).  Inference only (save must be NULL), out_ld 256. */
 
+/* ---- NodeProcessor.forward followed by the output head, one launch (bf16 weights) -------------------------------------
+ * AssimilatorDecoder.forward after its edge update (assimilator_decoder.py:195-200) + the Decoder residual (decoder.py:93):
+ *   x_new[j] = LN(MLP_node(cat[x[j], agg[j]]))            (graph_net_block.py:189-191; the decoder's rows are zeros: no x_res)
+ *   out[j, :n] = MLP_head(x_new[j]) + residual[j, :n]     (node_decoder 256 -> 128 -> 128 -> n <= 80 features, no norm)
+ * x_new stays in registers: the [rows, 256] table between the two MLPs is neither written nor read. */
+int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
+                                const gw_mlp_weights* w, const gw_mlp_weights* head, const gw_operand* residual /* may be NULL */,
+                                float* out, int32_t out_ld, void* stream);
+
 /* ---- NormalizedMSELoss.forward (losses.py:66-94, normalize on/off) ---------------------------------------
  * loss = mean_{b,n}( w_lat[n / num_lon] * mean_c( (pred-target)^2 [/ var_c] ) ); *loss_out must be zeroed. */
 int gw_normalized_mse_forward(const float* pred, const float* target,

@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/r03j; mkdir -p $OUT
+OUT=gpurun_out/r03k; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_edge16.py tests/test_gpu_round2.py tests/test_gpu_parity.py -m gpu -q -s -x --timeout 600 -p no:cacheprovider -k "round3 or edge16 or bf16 or c3 or determin or post or integration or team or fp16 or flat or graphcast" > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -n 12 $OUT/pytest.log
 timeout 400 python bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $OUT/bench_c3.log 2>&1; echo "rc=$?" >> $OUT/bench_c3.log; tail -n 2 $OUT/bench_c3.log | cut -c1-300
