@@ -25,6 +25,12 @@
 
 using namespace gw;
 
+#ifdef GW_TUNING
+#define GW_TUNE16(a) ((a).tune16)
+#else
+#define GW_TUNE16(a) 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -77,7 +83,7 @@ __device__ __forceinline__ void stg_half4(void* p, f32x4 v) {
 template <int KS, int BKS, int NT, int NTP>
 __device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)[NG][BKS], const char* __restrict__ gw,
                                        const char* __restrict__ next_gw, int next_bytes, const char* lds, int& parity,
-                                       int lane, int wave) {
+                                       int lane, int wave, int tune = 0) {
   constexpr int STEP_BYTES = NTP * 1024;
   constexpr int CS = (2 * STEP_BYTES <= kBufBytes) ? 2 : 1;  // K-steps per chunk
   constexpr int NCH = (KS + CS - 1) / CS;
@@ -87,32 +93,51 @@ __device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)
     (void)dummy;
     const int steps_c = (KS - c * CS) < CS ? (KS - c * CS) : CS;
     wait_vm16<0>();
-    lds_barrier16();  // chunk c has landed for every wave; nobody still reads the other buffer
-    if (c + 1 < NCH) {
-      const int sn = (KS - (c + 1) * CS) < CS ? (KS - (c + 1) * CS) : CS;
-      issue_bytes(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
-    } else if (next_gw != nullptr) {
-      issue_bytes(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+    if (!(tune & 4)) lds_barrier16();  // chunk c has landed for every wave; nobody still reads the other buffer
+    if (!(tune & 1)) {
+      if (c + 1 < NCH) {
+        const int sn = (KS - (c + 1) * CS) < CS ? (KS - (c + 1) * CS) : CS;
+        issue_bytes(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+      } else if (next_gw != nullptr) {
+        issue_bytes(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+      }
+    }
+    if (tune & 2) {
+      parity ^= 1;
+      continue;
     }
     const char* buf = lds + parity * kBufBytes + lane * 16;
+    // The A fragments (4 row tiles = one "unit" of 4 ds_read_b128) travel through a ring of three register sets, requested two
+    // units ahead of the MFMAs that use them: this kernel runs ONE wave per SIMD, so an LDS round trip that is waited for right
+    // after its request (what the compiler schedules on its own: 2 reads, wait, 2 MFMAs) is exposed in full (measured: 6 % of
+    // the row-wise launches; the rest of their per-chunk time is not the weight stream either - neither two chunks in flight
+    // nor a per-workgroup rotation of the piece order moved it, profiles/r03 notes in DESIGN.md).
+    constexpr int UPS = NTP / 4;           // units per K-step
+    const int NU = steps_c * UPS;          // units of this chunk (<= 2 * UPS)
+    bf16x8 af[3][4];
+    auto ldu = [&](bf16x8 (&f)[4], int u) {
+      const int su = u / UPS, t4 = u - su * UPS;
 #pragma unroll
-    for (int s = 0; s < CS; ++s) {
-      if (s < steps_c) {
+      for (int tt = 0; tt < 4; ++tt) f[tt] = *(const bf16x8*)(buf + su * STEP_BYTES + (t4 * 4 + tt) * 1024);
+    };
+    ldu(af[0], 0);
+    if (NU > 1) ldu(af[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t4 = 0; t4 < NTP / 4; ++t4) {
-          bf16x8 afrag[4];
+    for (int u = 0; u < CS * UPS; ++u) {
+      if (u < NU) {
+        if (u + 2 < NU) ldu(af[(u + 2) % 3], u + 2);
+        const int su = u / UPS, t4 = u - su * UPS;
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt) afrag[tt] = *(const bf16x8*)(buf + s * STEP_BYTES + (t4 * 4 + tt) * 1024);
+        for (int tt = 0; tt < 4; ++tt) {
+          if (t4 * 4 + tt < NT) {
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt) {
-            if (t4 * 4 + tt < NT) {
-#pragma unroll
-              for (int g = 0; g < NG; ++g)
-                acc[g][t4 * 4 + tt] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[tt], bin[g][c * CS + s], acc[g][t4 * 4 + tt], 0, 0, 0);
-            }
+            for (int g = 0; g < NG; ++g)
+              acc[g][t4 * 4 + tt] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u % 3][tt], bin[g][c * CS + su], acc[g][t4 * 4 + tt], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     parity ^= 1;
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
             nx = w1[i2];
             nb = K1FIRST;
           }
-        pass16<K1S, BKS, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave);
+        pass16<K1S, BKS, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave, GW_TUNE16(a));
       } else if (prj[i]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -262,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
       const bool last = (l + 1 == a.n_mid);
       const char* nx = last ? w_out : w_mid + (size_t)(l + 1) * HKS * H_STEP;
       const int nb = last ? O_CS * O_STEP : H_CS * H_STEP;
-      pass16<HKS, BKS, HT, HTP>(acc, bin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave);
+      pass16<HKS, BKS, HT, HTP>(acc, bin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave, GW_TUNE16(a));
     }
     // ---- output layer ----
 #pragma unroll
@@ -270,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     init_bias16<OT>(o, a.b_out, q);
     pass16<HKS, BKS, OT, OTP>(o, bin, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
-                              POST ? H_CS * H_STEP : (HEAD ? 2 * 8 * 1024 : 0), lds16, parity, lane, wave);
+                              POST ? H_CS * H_STEP : (HEAD ? 2 * 8 * 1024 : 0), lds16, parity, lane, wave, GW_TUNE16(a));
   }
 
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
@@ -367,18 +392,18 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     constexpr int HS = 8 * 1024;  // bytes of one K-step of a packed slice with <= 8 row tiles
     f32x4 hh[NG][8];
     init_bias16<8>(hh, a.hd_b1, q);
-    pass16<8, BKS, 8, 8>(hh, bin, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, lds16, parity, lane, wave);
+    pass16<8, BKS, 8, 8>(hh, bin, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
     for (int g = 0; g < NG; ++g) relu_to_bin<8>(reinterpret_cast<bf16x8(&)[4]>(bin[g]), hh[g]);
     __builtin_amdgcn_sched_barrier(0);
     init_bias16<8>(hh, a.hd_b2, q);
-    pass16<4, BKS, 8, 8>(hh, bin, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, lds16, parity, lane, wave);
+    pass16<4, BKS, 8, 8>(hh, bin, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
     for (int g = 0; g < NG; ++g) relu_to_bin<8>(reinterpret_cast<bf16x8(&)[4]>(bin[g]), hh[g]);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 y[NG][5];
     init_bias16<5>(y, a.hd_b3, q);
-    pass16<4, BKS, 5, 8>(y, bin, (const char*)a.hd_w3, nullptr, 0, lds16, parity, lane, wave);
+    pass16<4, BKS, 5, 8>(y, bin, (const char*)a.hd_w3, nullptr, 0, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (valid[g]) {
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     for (int sl = 0; sl < a.n_post; ++sl) {
       init_bias16<HT>(acc, nullptr, q);  // (acc aliases o: the new rows have been stored and packed into bin)
       const char* nx = sl + 1 < a.n_post ? (const char*)a.proj_w[sl + 1] : nullptr;
-      pass16<8, BKS, HT, HTP>(acc, bin, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, lds16, parity, lane, wave);
+      pass16<8, BKS, HT, HTP>(acc, bin, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (valid[g]) {
@@ -552,6 +577,12 @@ int launch16(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes) {
 namespace gw {
 
 int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream) {
+#ifdef GW_TUNING
+  {
+    static const int t16 = GW_TUNE("GW_CHAIN16_TUNE", 0);
+    a.tune16 = t16;
+  }
+#endif
   switch (kind) {
     case 0:  // mlp rows
       if (hidden == 256 && n_out == 256) {

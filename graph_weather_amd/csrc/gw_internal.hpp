@@ -41,6 +41,7 @@ struct ChainArgs {
   const float* hd_b2;
   const float* hd_w3;  // packed [<= 80, 128] (5 row tiles)
   const float* hd_b3;
+  int tune16;          // tuning builds only (GW_CHAIN16_TUNE): timing experiments of the bf16 chain kernel (wrong results)
   int proj_half;       // bf16 launches: the products are stored as fp16 rows (256 halves per row, GW_LAYOUT_ROWS_F16), clamped to
                        // the fp16 range - half the bytes for the per-edge gathers that consume them
   // weights

@@ -82,9 +82,19 @@ def set_deterministic(module: nn.Module, flag: bool = True) -> nn.Module:
     use per-tile carry records added in tile order instead of fp32 atomics, whose order is not fixed (include/gw_amd.h:
     GW_EDGE_DETERMINISTIC).  The reference's ``scatter_add_`` is order-nondeterministic on a GPU as well - this is an extra,
     at a small cost (the carry records, one more small launch per edge update; the bf16 path uses its 4-wave kernel)."""
-    for m in module.modules():
-        if isinstance(m, GraphNetBlock):
-            m.deterministic = bool(flag)
+    blocks = [m for m in module.modules() if isinstance(m, GraphNetBlock)]
+    if flag:
+        for m in blocks:
+            mlp = m.edge_model.edge_mlp
+            if mlp.compute_dtype == torch.float32 and (mlp._layout()[4] or mlp._norm() is None or len(mlp._linears()) != 3):
+                # carry records exist in the hand-scheduled fp32 edge kernel (native 256 widths, LayerNorm, two hidden layers) and in
+                # the bf16 kernels; zero-padded narrow blocks, norm_type=None and deeper MLPs run on the general fp32 kernel
+                raise NotImplementedError("graph_weather_amd: deterministic segment sums are implemented for message-passing blocks "
+                                          "of the native width (256) with LayerNorm and hidden_layers = 2 (float32), or bfloat16 "
+                                          "matrix products; this block is %d -> %d wide with norm %s"
+                                          % (mlp.hidden_dim, mlp.out_dim, "LayerNorm" if mlp._norm() is not None else "None"))
+    for m in blocks:
+        m.deterministic = bool(flag)
     return module
 
 
@@ -522,7 +532,15 @@ class GraphProcessor(nn.Module):
             else:
                 e_in = Feed(e_cur, n_edges, "raw")
             need_e = want_edges or not last
-            out_kind = "tiles" if (tiled and need_e and not (last and want_edges)) else need_e
+            # e' stays in the bf16 tile format only when the block that consumes it reads tiles too (same compute dtype and
+            # shape: set_compute_dtype applied to a sub-module can leave neighbours in different modes)
+            nxt_tiled = False
+            if i + 1 < len(self.blocks) and not last:
+                nm = self.blocks[i + 1].edge_model.edge_mlp
+                npk = nm.packed() if not train else None
+                nxt_tiled = (npk is not None and nm.compute_dtype == torch.bfloat16 and npk.n_mid == 1 and npk.ln_width == 0
+                             and npk.gamma is not None)
+            out_kind = "tiles" if (tiled and need_e and nxt_tiled) else need_e
             e_res = self._e0_cache[3] if (shared and tiled) else e_cur
             # what the node update of this block also produces (inference): the next block's layer-1 node products
             post_w, post_zero, post_half = None, False, False
