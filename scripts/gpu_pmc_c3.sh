@@ -34,16 +34,21 @@ for name in ("fetch", "write", "sq", "grbm"):
     for d in sorted(by_disp):
         rs = by_disp[d]
         k = rs[0]["Kernel_Name"]
-        m = re.search(r"(edge16_kernel<[^>]*>|edge16_l1_kernel|edge16_gather_kernel)", k)
+        m = re.search(r"(edge16t_kernel<[^>]*>|edge16_kernel<[^>]*>|edge16_l1_kernel|chain16_kernel<[^>]*>)", k)
         if not m: continue
         kind = m.group(1)
         i = pos[kind]; pos[kind] += 1
-        # per forward: <.., GATHER = true> twice (first processor block, decoder), <.., GATHER = false> and the layer-1
-        # kernel once per processor block 1..8
-        if kind.startswith("edge16_kernel") and kind.rstrip(">").endswith("true"):
-            label = "block0" if i % 2 == 0 else "decoder"
-        else:
+        # per forward (round 3): the team kernel's gather form runs twice (encoder edge update, then decoder), its DMA form and
+        # the layer-1 kernel once per processor block 1..8, the lock-step kernel once (first processor block); the chain16
+        # kernels (node-side MLPs) are averaged per instantiation
+        if kind.startswith("edge16t_kernel<true"):
+            label = "encoder" if i % 2 == 0 else "decoder"
+        elif kind.startswith("edge16t_kernel") or kind == "edge16_l1_kernel":
             label = "blocks1-8"
+        elif kind.startswith("edge16_kernel"):
+            label = "block0"
+        else:
+            label = "node side"
         for r in rs:
             key = (kind, label, r["Counter_Name"])
             a = res[key]
@@ -56,7 +61,7 @@ for k, v in summary.items():
     if "WRITE_SIZE" in v: v["hbm_write_bytes (WRITE_SIZE KiB x 1024)"] = v["WRITE_SIZE"] * 1024.0
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
         v["mfma_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
-json.dump(summary, open(os.path.join(out, "pmc_c3_edge16.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+json.dump(summary, open(os.path.join(out, "pmc_c3.json"), "w"), indent=1)
+print(json.dumps({k: {c: v[c] for c in v if c.startswith(('hbm', 'mfma'))} for k, v in summary.items()}, indent=1))
 PY
 rm -f $GRAFT_REPO_ROOT/$OUT/raw_*.csv
