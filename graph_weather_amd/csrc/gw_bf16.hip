@@ -35,8 +35,11 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int NG = 2;                       // 16-column groups per wave (4 would halve the weight stream again but spills)
-constexpr int kCols16 = 4 * NG * 16;        // columns per workgroup (256)
+// A workgroup is NW waves x NG 16-column groups per wave.  4 x 2 (128 columns, one wave per SIMD, ~450 registers: every A
+// fragment read from LDS feeds two MFMAs) is the form of the general kernels; the row-wise launches of the fused forward are
+// bound by their row loads / stores, which one lock-stepped workgroup per CU cannot overlap with anything, and run as 4 x 1
+// (64 columns, <= 256 registers, TWO workgroups per CU: twice the weight DMA and LDS reads per column, but one workgroup's
+// row traffic under the other's MFMA phases - measured 14-30 % faster; 8 x 1 in one workgroup sits between).
 constexpr int kBufBytes = 32768;            // one weight chunk buffer (2 K-steps x 16 tiles x 1 KiB)
 constexpr int kStageLd16 = 260;
 constexpr int kStageFloats16 = 64 * kStageLd16;
@@ -51,9 +54,10 @@ __device__ __forceinline__ void lds_barrier16() { asm volatile("s_waitcnt lgkmcn
 
 // DMA `bytes` (multiple of 1 KiB) of the packed weight stream into LDS at byte offset lds_off; pieces round-robin
 // over the 4 waves.
+template <int NW>
 __device__ __forceinline__ void issue_bytes(const char* __restrict__ g, int bytes, unsigned lds_off, int lane, int wave) {
   const int npieces = bytes >> 10;
-  for (int p = wave; p < npieces; p += 4)
+  for (int p = wave; p < npieces; p += NW)
     glds16_asm_s((const float*)(g + (size_t)p * 1024), (unsigned)lane * 16u,
                  __builtin_amdgcn_readfirstlane(lds_off + (unsigned)p * 1024u));
 }
@@ -80,7 +84,7 @@ __device__ __forceinline__ void stg_half4(void* p, f32x4 v) {
 // One layer pass: acc[g][t] += W[16t.., k] . bin[g][k], K = 32 KS, NT row tiles, NTP = tiles per K-step in the packed
 // stream (NT rounded up to 4).  The stream of this pass starts at gw; its first chunk has already been issued into
 // buffer `parity`; while the last chunk computes, the first chunk of the next pass (next_gw, next_bytes) is issued.
-template <int KS, int BKS, int NT, int NTP>
+template <int NW, int NG, int KS, int BKS, int NT, int NTP>
 __device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)[NG][BKS], const char* __restrict__ gw,
                                        const char* __restrict__ next_gw, int next_bytes, const char* lds, int& parity,
                                        int lane, int wave, int tune = 0) {
@@ -97,9 +101,9 @@ __device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)
     if (!(tune & 1)) {
       if (c + 1 < NCH) {
         const int sn = (KS - (c + 1) * CS) < CS ? (KS - (c + 1) * CS) : CS;
-        issue_bytes(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+        issue_bytes<NW>(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
       } else if (next_gw != nullptr) {
-        issue_bytes(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+        issue_bytes<NW>(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
       }
     }
     if (tune & 2) {
@@ -144,7 +148,7 @@ __device__ __forceinline__ void pass16(f32x4 (&acc)[NG][NT], const bf16x8 (&bin)
   }
 }
 
-template <int NT>
+template <int NG, int NT>
 __device__ __forceinline__ void init_bias16(f32x4 (&acc)[NG][NT], const float* __restrict__ bias, int q) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -155,7 +159,7 @@ __device__ __forceinline__ void init_bias16(f32x4 (&acc)[NG][NT], const float* _
 }
 
 // bin[s] <- bf16(row[k(s,q,i)]) for a raw operand row (valid features [0, kvalid))
-template <int KS, bool FULL>
+template <int KS, bool FULL, int DEPTH = 4>
 __device__ __forceinline__ void load_raw16(bf16x8 (&bin)[KS], const float* __restrict__ row, int kvalid, int q) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -172,7 +176,8 @@ __device__ __forceinline__ void load_raw16(bf16x8 (&bin)[KS], const float* __res
       }
     }
     bin[s] = pack8(lo, hi);
-    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 8 row pieces in flight per group: registers are scarce
+    // at most 2 DEPTH row pieces in flight per group (DEPTH = 4 where registers are scarce: one wave per SIMD with two groups)
+    if ((s & (DEPTH - 1)) == DEPTH - 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -188,8 +193,11 @@ __device__ __forceinline__ const float* operand_row16(const float* ptr, const in
 }
 
 // K1S: 32-wide K-steps of a raw layer-1 operand (8: k = 256, 4: k <= 128, 1: k <= 32); HT / OT: hidden / output row tiles.
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST = false, bool HEAD = false>
-__global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST = false, bool HEAD = false, int NW = 4,
+          int NG = 2>
+__global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kernel(const ChainArgs a) {
+  constexpr int kCols16 = NW * NG * 16;  // columns per workgroup
+  static_assert(EPI != EPI_EDGE || (NW == 4 && NG == 2), "the segment-sum epilogue walks 64 columns per round on 4 waves");
   extern __shared__ __attribute__((aligned(16))) char lds16[];
   constexpr int HTP = (HT + 3) / 4 * 4, OTP = (OT + 3) / 4 * 4;
   constexpr int HKS = HT / 2;  // K-steps of a layer fed by the hidden activations
@@ -200,12 +208,14 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   const int j = lane & 15;
   const int q = lane >> 4;
   const int tile_c0 = blockIdx.x * kCols16;
+  // (measured and dropped: per-batch tiles walked batch-innermost and XCD-aware, so that batch-shared operand rows come from the
+  // XCD's L2 - the head launch 1.19 -> 1.18 ms, the mesh-sized node updates 0.168 -> 0.175 ms)
 
   int cc[NG], bb[NG], kk[NG];
   bool valid[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    const int c_raw = tile_c0 + g * 64 + wave * 16 + j;
+    const int c_raw = tile_c0 + g * (NW * 16) + wave * 16 + j;
     valid[g] = c_raw < a.n_cols;
     cc[g] = valid[g] ? c_raw : a.n_cols - 1;
     bb[g] = cc[g] / a.cols_per_batch;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   {
     const char* first = on[0] ? w1[0] : (on[1] ? w1[1] : (on[2] ? w1[2] : after_l1));
     const int first_bytes = (on[0] || on[1] || on[2]) ? K1FIRST : after_l1_bytes;
-    issue_bytes(first, first_bytes, 0u, lane, wave);
+    issue_bytes<NW>(first, first_bytes, 0u, lane, wave);
   }
 
   // ---- layer 1 ----
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
   constexpr bool SHARE_ACC = (OT == HT);
   f32x4 acc[NG][HT];
   bf16x8 bin[NG][BKS];
-  init_bias16<HT>(acc, a.b1, q);
+  init_bias16<NG, HT>(acc, a.b1, q);
   {
 #pragma unroll
     for (int i = 0; i < NSEG; ++i) {
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
-          load_raw16<K1S, K1FULL>(reinterpret_cast<bf16x8(&)[K1S]>(bin[g]), row, a.seg_k[i], q);
+          load_raw16<K1S, K1FULL, (NG == 1 ? 8 : 4)>(reinterpret_cast<bf16x8(&)[K1S]>(bin[g]), row, a.seg_k[i], q);
           __builtin_amdgcn_sched_barrier(0);
         }
         const char* nx = after_l1;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
             nx = w1[i2];
             nb = K1FIRST;
           }
-        pass16<K1S, BKS, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave, GW_TUNE16(a));
+        pass16<NW, NG, K1S, BKS, HT, HTP>(acc, bin, w1[i], nx, nb, lds16, parity, lane, wave, GW_TUNE16(a));
       } else if (prj[i]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -283,18 +293,18 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) relu_to_bin<HT>(reinterpret_cast<bf16x8(&)[HKS]>(bin[g]), acc[g]);
       __builtin_amdgcn_sched_barrier(0);
-      init_bias16<HT>(acc, a.b_mid + l * (HT * 16), q);
+      init_bias16<NG, HT>(acc, a.b_mid + l * (HT * 16), q);
       const bool last = (l + 1 == a.n_mid);
       const char* nx = last ? w_out : w_mid + (size_t)(l + 1) * HKS * H_STEP;
       const int nb = last ? O_CS * O_STEP : H_CS * H_STEP;
-      pass16<HKS, BKS, HT, HTP>(acc, bin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave, GW_TUNE16(a));
+      pass16<NW, NG, HKS, BKS, HT, HTP>(acc, bin, w_mid + (size_t)l * HKS * H_STEP, nx, nb, lds16, parity, lane, wave, GW_TUNE16(a));
     }
     // ---- output layer ----
 #pragma unroll
     for (int g = 0; g < NG; ++g) relu_to_bin<HT>(reinterpret_cast<bf16x8(&)[HKS]>(bin[g]), acc[g]);
     __builtin_amdgcn_sched_barrier(0);
-    init_bias16<OT>(o, a.b_out, q);
-    pass16<HKS, BKS, OT, OTP>(o, bin, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
+    init_bias16<NG, OT>(o, a.b_out, q);
+    pass16<NW, NG, HKS, BKS, OT, OTP>(o, bin, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
                               POST ? H_CS * H_STEP : (HEAD ? 2 * 8 * 1024 : 0), lds16, parity, lane, wave, GW_TUNE16(a));
   }
 
@@ -391,19 +401,19 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     constexpr int HS = 8 * 1024;  // bytes of one K-step of a packed slice with <= 8 row tiles
     f32x4 hh[NG][8];
-    init_bias16<8>(hh, a.hd_b1, q);
-    pass16<8, BKS, 8, 8>(hh, bin, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, lds16, parity, lane, wave, GW_TUNE16(a));
+    init_bias16<NG, 8>(hh, a.hd_b1, q);
+    pass16<NW, NG, 8, BKS, 8, 8>(hh, bin, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
     for (int g = 0; g < NG; ++g) relu_to_bin<8>(reinterpret_cast<bf16x8(&)[4]>(bin[g]), hh[g]);
     __builtin_amdgcn_sched_barrier(0);
-    init_bias16<8>(hh, a.hd_b2, q);
-    pass16<4, BKS, 8, 8>(hh, bin, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, lds16, parity, lane, wave, GW_TUNE16(a));
+    init_bias16<NG, 8>(hh, a.hd_b2, q);
+    pass16<NW, NG, 4, BKS, 8, 8>(hh, bin, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
     for (int g = 0; g < NG; ++g) relu_to_bin<8>(reinterpret_cast<bf16x8(&)[4]>(bin[g]), hh[g]);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 y[NG][5];
-    init_bias16<5>(y, a.hd_b3, q);
-    pass16<4, BKS, 5, 8>(y, bin, (const char*)a.hd_w3, nullptr, 0, lds16, parity, lane, wave, GW_TUNE16(a));
+    init_bias16<NG, 5>(y, a.hd_b3, q);
+    pass16<NW, NG, 4, BKS, 5, 8>(y, bin, (const char*)a.hd_w3, nullptr, 0, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (valid[g]) {
@@ -439,9 +449,9 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const ChainArgs a) {
     }
 #pragma unroll 1
     for (int sl = 0; sl < a.n_post; ++sl) {
-      init_bias16<HT>(acc, nullptr, q);  // (acc aliases o: the new rows have been stored and packed into bin)
+      init_bias16<NG, HT>(acc, nullptr, q);  // (acc aliases o: the new rows have been stored and packed into bin)
       const char* nx = sl + 1 < a.n_post ? (const char*)a.proj_w[sl + 1] : nullptr;
-      pass16<8, BKS, HT, HTP>(acc, bin, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, lds16, parity, lane, wave, GW_TUNE16(a));
+      pass16<NW, NG, 8, BKS, HT, HTP>(acc, bin, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (valid[g]) {
@@ -564,11 +574,11 @@ __global__ void pack_linear_bf16_kernel(const float* __restrict__ w, int n_out, 
 }
 
 template <typename K>
-int launch16(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes) {
+int launch16(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes, int threads = 256, int cols = 128) {
   static DeviceOnce once;  // per template instantiation and device
   if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEdge);
-  const int grid = (a.n_cols + kCols16 - 1) / kCols16;
-  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(256), lds_bytes, (hipStream_t)stream, a);
+  const int grid = (a.n_cols + cols - 1) / cols;
+  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(threads), lds_bytes, (hipStream_t)stream, a);
   return check_launch("chain16_kernel launch");
 }
 
@@ -581,6 +591,43 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
   {
     static const int t16 = GW_TUNE("GW_CHAIN16_TUNE", 0);
     a.tune16 = t16;
+  }
+#endif
+  // The row-wise launches of the fused forward (node update, + post products, + head, node encoder + post products) run as
+  // 4 waves x 1 group with two workgroups per CU (see the note above).  Tuning builds: GW_CHAIN16_NW=4 selects 4 x 2, 8 selects 8 x 1.
+#ifdef GW_TUNING
+  static const int nw = GW_TUNE("GW_CHAIN16_NW", 41);
+  if (nw == 8) {
+    switch (kind) {
+      case 2:
+        return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, false, 8, 1>, a, stream, 1, kLdsWeights, 512);
+      case 4:
+        return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true, false, 8, 1>, a, stream, 1, kLdsWeights, 512);
+      case 6:
+        return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true, 8, 1>, a, stream, 1, kLdsWeights, 512);
+      case 5:
+        if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32)
+          return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true, false, 8, 1>, a, stream, 1, kLdsWeights, 512);
+        break;
+      default:
+        break;
+    }
+  }
+  if (nw == 4) {
+    switch (kind) {
+      case 2:
+        return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+      case 4:
+        return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+      case 6:
+        return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true>, a, stream, 1, kLdsWeights);
+      case 5:
+        if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32)
+          return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+        break;
+      default:
+        break;
+    }
   }
 #endif
   switch (kind) {
@@ -598,16 +645,16 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
     case 1:
       return launch16(chain16_kernel<8, true, 3, 16, 16, EPI_EDGE, false>, a, stream, 1, kLdsEdge);
     case 2:
-      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false>, a, stream, 1, kLdsWeights);
+      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, false, 4, 1>, a, stream, 1, kLdsWeights, 256, 64);
     case 3:
       return launch16(chain16_kernel<8, true, 1, 16, 16, EPI_ROWS, true>, a, stream, grid_y, kLdsWeights);
     case 4:
-      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true, false, 4, 1>, a, stream, 1, kLdsWeights, 256, 64);
     case 6:  // node update + output head (decoder)
-      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true>, a, stream, 1, kLdsWeights);
+      return launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true, 4, 1>, a, stream, 1, kLdsWeights, 256, 64);
     case 5:  // mlp rows + POST products of the output rows (node encoder -> layer-1 products of the encoder's edge MLP)
       if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32)
-        return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true>, a, stream, 1, kLdsWeights);
+        return launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true, false, 4, 1>, a, stream, 1, kLdsWeights, 256, 64);
       return set_error(GW_E_UNSUPPORTED, "bf16 mlp + post products: hidden 256, 256 outputs, 33..128 inputs");
   }
   return set_error(GW_E_BADARG, "chain16_launch: bad kind");
