@@ -15,14 +15,14 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16 = 0, 1, 2
 EDGE_DETERMINISTIC = 1
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
-    "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector",
+    "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector", "gw_pack_many",
     "gw_mlp_forward", "gw_mlp_post_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
     "gw_edge_rows_to_tiles", "gw_node_update_forward", "gw_node_update_head_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
@@ -42,6 +42,18 @@ class GwMlpWeights(Structure):
     _fields_ = [("w1", c_void_p * 3), ("b1", c_void_p), ("w_mid", c_void_p), ("b_mid", c_void_p), ("w_out", c_void_p),
                 ("b_out", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("hidden", c_int32),
                 ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32), ("ln_width", c_int32)]
+
+
+PACK_MAX_ITEMS = 16
+
+
+class GwPackItem(Structure):  # include/gw_amd.h: gw_pack_item
+    _fields_ = [("w", c_void_p), ("stride_f", c_int64), ("stride_k", c_int64), ("n_out", c_int32), ("kseg", c_int32),
+                ("rows", c_int32), ("reserved", c_int32), ("out", c_void_p)]
+
+
+class GwPadItem(Structure):  # include/gw_amd.h: gw_pad_item
+    _fields_ = [("v", c_void_p), ("n", c_int32), ("n_out", c_int32), ("out", c_void_p)]
 
 
 class GwActivationSave(Structure):
@@ -104,6 +116,8 @@ def lib():
     L.gw_padded_n.argtypes = [c_int]
     L.gw_pad_vector.restype = c_int
     L.gw_pad_vector.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+    L.gw_pack_many.restype = c_int
+    L.gw_pack_many.argtypes = [c_int32, c_int32, POINTER(GwPackItem), c_int32, POINTER(GwPadItem), c_void_p]
     L.gw_mlp_forward.restype = c_int
     L.gw_mlp_forward.argtypes = [c_int64, c_int32, POINTER(GwOperand), POINTER(GwMlpWeights), POINTER(GwOperand),
                                  c_void_p, c_int32, POINTER(GwActivationSave), c_void_p]

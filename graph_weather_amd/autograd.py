@@ -91,20 +91,40 @@ def segment_sum_rows(rows: torch.Tensor, rows_pb_in: int, batch: int, batch_out:
 
 def _packed_transposed(mlp, layer: int, W: torch.Tensor, lo: int, hi: int):
     """Packed stream of W[:, lo:hi]^T of (kernel-shaped) Linear ``layer`` (cached per weight version) for the fast
-    input-gradient product d @ W[:, lo:hi] through the forward's single-layer kernel; only for 256 x 256 blocks, else None."""
+    input-gradient product d @ W[:, lo:hi] through the forward's single-layer kernel; only for 256 x 256 blocks, else None.
+    On a miss every such block of the MLP is packed by one ``gw_pack_many`` launch, straight from the weights (the items
+    address the transposed block by strides: no transposed copy)."""
     if W.shape[0] != 256 or hi - lo != 256:
         return None
     cache = mlp.__dict__.setdefault("_packed_t", {})
-    key = (layer, lo, hi)
     ver = mlp.native_key()  # versions of the parameters W was derived from (W itself may be a fresh zero-padded copy)
-    hit = cache.get(key)
-    if hit is None or hit[0] != ver:
-        Wt = W.detach()[:, lo:hi].t().contiguous()  # [256 (k), 256 (f)]: "Linear" that maps gradients back
-        n = _L().gw_packed_floats(256, 0, 256)
-        out = torch.empty(n, dtype=torch.float32, device=W.device)
-        _lib.check(_L().gw_pack_linear(Wt.data_ptr(), 256, 256, 0, 256, out.data_ptr(), _st(W)), "gw_pack_linear (transposed)")
-        cache[key] = (ver, out)
-    return cache[key][1]
+    if cache.get("ver") != ver:
+        cache.clear()
+        cache["ver"] = ver
+        with torch.no_grad():
+            ps = [p.detach() for p in mlp.native_params()]
+        n_lin = (len(ps) - (2 if mlp._norm() is not None else 0)) // 2
+        blocks = []
+        for l in range(n_lin):
+            Wl = ps[2 * l]
+            if Wl.shape[0] != 256:
+                continue
+            if Wl.dtype != torch.float32 or not Wl.is_contiguous():
+                Wl = Wl.contiguous().float()
+            for a, b in (mlp.native_splits() if l == 0 else ((0, int(Wl.shape[1])),)):
+                if b - a == 256:
+                    blocks.append((l, a, b, Wl))
+        if blocks:
+            n = int(_L().gw_packed_floats(256, 0, 256))
+            buf = torch.empty(len(blocks) * n, dtype=torch.float32, device=W.device)
+            mats = []
+            for i, (l, a, b, Wl) in enumerate(blocks):
+                out = buf[i * n:(i + 1) * n]
+                # "Linear" that maps gradients back: output feature f = input column a + f, input feature k = row k of W
+                mats.append((Wl.data_ptr() + 4 * a, 1, int(Wl.shape[1]), 256, 256, out.data_ptr()))
+                cache[(l, a, b)] = out
+            ops.pack_many(_lib.DTYPE_F32, mats, [], _st(W))
+    return cache.get((layer, lo, hi))
 
 
 def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: int,

@@ -557,6 +557,55 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, int n, int npad, 
   if (i < npad) out[i] = i < n ? v[i] : 0.f;
 }
 
+// ---- gw_pack_many: all slices / vectors of an MLP in one launch (blockIdx.y = item; the last y packs the vectors) --------
+struct PackManyArgs {
+  gw_pack_item m[GW_PACK_MAX_ITEMS];
+  gw_pad_item v[GW_PACK_MAX_ITEMS];
+  int nsteps[GW_PACK_MAX_ITEMS];  // K-steps of the item's stream
+  int ntq[GW_PACK_MAX_ITEMS];     // fp32: row-tile quads (nt4); bf16: row tiles rounded up to 4 (ntp)
+  int n_mats, n_vecs, bf16;
+};
+
+__global__ void pack_many_kernel(const PackManyArgs a) {
+  const int it = blockIdx.y;
+  if (it < a.n_mats) {
+    const float* __restrict__ w = a.m[it].w;
+    const long long sf = a.m[it].stride_f, sk = a.m[it].stride_k;
+    const int n_out = a.m[it].n_out, kseg = a.m[it].kseg, ntq = a.ntq[it];
+    if (!a.bf16) {  // (pack_linear_kernel's order)
+      float* __restrict__ out = (float*)a.m[it].out;
+      const size_t total = (size_t)a.nsteps[it] * ntq * 256;
+      for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ti = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        const int b4 = (int)((i >> 8) % ntq);
+        const int s = (int)((i >> 8) / ntq);
+        const int f = 16 * (4 * b4 + ti) + (lane & 15);
+        const int kk = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
+        out[i] = (f < n_out && kk < kseg) ? w[(long long)f * sf + (long long)kk * sk] : 0.f;
+      }
+    } else {        // (pack_linear_bf16_kernel's order, gw_bf16.hip)
+      __bf16* __restrict__ out = (__bf16*)a.m[it].out;
+      const size_t total = (size_t)a.nsteps[it] * ntq * 512;
+      for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        const int lane = (int)((e >> 3) & 63);
+        const int tile = (int)((e >> 9) % ntq);
+        const int s = (int)((e >> 9) / ntq);
+        const int f = 16 * tile + (lane & 15);
+        const int kx = 32 * s + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+        out[e] = (__bf16)((f < n_out && kx < kseg) ? w[(long long)f * sf + (long long)kx * sk] : 0.f);
+      }
+    }
+  } else {
+    for (int vi = 0; vi < a.n_vecs; ++vi) {
+      const int n = a.v[vi].n, nw = a.v[vi].n_out > n ? a.v[vi].n_out : n, npad = ((nw + 31) / 32) * 32;
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x)
+        a.v[vi].out[i] = i < n ? a.v[vi].v[i] : 0.f;
+    }
+  }
+}
+
 // ---- NormalizedMSELoss (losses.py:66-94) ----------------------------------------------------------------
 __global__ void nmse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                             const float* __restrict__ inv_var, int inv_var_full, const float* __restrict__ lat_w, int num_lon,
@@ -719,6 +768,39 @@ int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, f
 }
 
 int gw_padded_n(int n) { return ((n + 31) / 32) * 32; }
+
+int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats, int32_t n_vecs, const gw_pad_item* vecs,
+                 void* stream) {
+  if (n_mats < 0 || n_vecs < 0 || n_mats > GW_PACK_MAX_ITEMS || n_vecs > GW_PACK_MAX_ITEMS || (n_mats > 0 && !mats) ||
+      (n_vecs > 0 && !vecs) || (weight_dtype != GW_DTYPE_F32 && weight_dtype != GW_DTYPE_BF16))
+    return fail(GW_E_BADARG, "gw_pack_many: bad arguments");
+  if (n_mats == 0 && n_vecs == 0) return GW_OK;
+  PackManyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_mats = n_mats;
+  a.n_vecs = n_vecs;
+  a.bf16 = weight_dtype == GW_DTYPE_BF16;
+  for (int i = 0; i < n_mats; ++i) {
+    const gw_pack_item& m = mats[i];
+    if (!m.w || !m.out || m.n_out <= 0 || m.kseg <= 0) return fail(GW_E_BADARG, "gw_pack_many: bad matrix item");
+    a.m[i] = m;
+    if (m.rows != 0 && m.rows < m.n_out) return fail(GW_E_BADARG, "gw_pack_many: rows < n_out");
+    const int nt = ((m.rows > m.n_out ? m.rows : m.n_out) + 15) / 16;
+    if (a.bf16) {  // (gw_packed_bytes_bf16)
+      a.nsteps[i] = m.kseg <= 32 ? 1 : (m.kseg <= 128 ? 4 : (m.kseg + 31) / 32);
+      a.ntq[i] = (nt + 3) / 4 * 4;
+    } else {       // (gw_packed_floats)
+      a.nsteps[i] = packed_steps_f32(m.kseg);
+      a.ntq[i] = (nt + 3) / 4;
+    }
+  }
+  for (int i = 0; i < n_vecs; ++i) {
+    if (!vecs[i].v || !vecs[i].out || vecs[i].n <= 0) return fail(GW_E_BADARG, "gw_pack_many: bad vector item");
+    a.v[i] = vecs[i];
+  }
+  hipLaunchKernelGGL(pack_many_kernel, dim3(64, n_mats + (n_vecs > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("pack_many_kernel launch");
+}
 
 int gw_pad_vector(const float* v, int n, float* out, void* stream) {
   if (!v || !out || n <= 0) return fail(GW_E_BADARG, "gw_pad_vector: bad arguments");

@@ -128,6 +128,26 @@ class SavedActivations:
                                 None if self.pre_norm is None else self.pre_norm.data_ptr())
 
 
+def pack_many(weight_dtype: int, mats, vecs, stream: int) -> None:
+    """gw_pack_many over any number of items.  mats: (w_ptr, stride_f, stride_k, n_out, kseg, out_ptr[, rows]); vecs: (v_ptr, n,
+    out_ptr[, n_out]) - rows / n_out: size of the packed item when it is larger than the source (zero rows of an output head)."""
+    L = _lib.lib()
+    M = _lib.PACK_MAX_ITEMS
+    mi = vi = 0
+    while mi < len(mats) or vi < len(vecs):
+        mc, vc = mats[mi:mi + M], vecs[vi:vi + M]
+        ma = (_lib.GwPackItem * max(len(mc), 1))()
+        for k, it in enumerate(mc):
+            w, sf, sk, n_out, kseg, out = it[:6]
+            ma[k] = _lib.GwPackItem(w, sf, sk, n_out, kseg, it[6] if len(it) > 6 else 0, 0, out)
+        va = (_lib.GwPadItem * max(len(vc), 1))()
+        for k, it in enumerate(vc):
+            va[k] = _lib.GwPadItem(it[0], it[1], it[3] if len(it) > 3 else 0, it[2])
+        _lib.check(L.gw_pack_many(weight_dtype, len(mc), ma, len(vc), va, stream), "gw_pack_many")
+        mi += len(mc)
+        vi += len(vc)
+
+
 class PackedMLP:
     """Device-resident packed form of one reference ``MLP`` (graph_net_block.py:45-61)."""
 
@@ -154,47 +174,59 @@ class PackedMLP:
         guard = on_device_of(weights[0])
         guard.__enter__()  # every packing launch below runs with the weights' GPU current (released at the end of __init__)
 
-        def pack(w, k_lo, k_hi):
-            w = w.detach().contiguous().float()
-            if self.weight_dtype == _lib.DTYPE_BF16:  # bf16 MFMA A-operand stream (rounded to nearest even)
-                nb = L.gw_packed_bytes_bf16(int(w.shape[0]), k_lo, k_hi)
-                out = torch.empty(nb // 2, dtype=torch.bfloat16, device=dev)
-                _lib.check(L.gw_pack_linear_bf16(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), k_lo, k_hi, out.data_ptr(),
-                                                 st), "gw_pack_linear_bf16")
-                return out
-            n = L.gw_packed_floats(int(w.shape[0]), k_lo, k_hi)
-            out = torch.empty(n, dtype=torch.float32, device=dev)
-            _lib.check(L.gw_pack_linear(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), k_lo, k_hi, out.data_ptr(), st),
-                       "gw_pack_linear")
+        # Every slice and vector of the MLP goes through ONE gw_pack_many launch (27 MLPs x ~10 packing launches per weight
+        # version otherwise: the bulk of a forward right after an optimizer step).  Items address the parameters in place.
+        bf16 = self.weight_dtype == _lib.DTYPE_BF16
+        mats, vecs, keep = [], [], []
+
+        def src(t):
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.contiguous().float()
+            keep.append(t)
+            return t
+
+        def out_for(n_out, kseg):
+            if bf16:
+                return torch.empty(L.gw_packed_bytes_bf16(n_out, 0, kseg) // 2, dtype=torch.bfloat16, device=dev)
+            return torch.empty(L.gw_packed_floats(n_out, 0, kseg), dtype=torch.float32, device=dev)
+
+        def pack(w, k_lo, k_hi, out=None, rows=0):
+            w = src(w)
+            n_out, k_total = int(w.shape[0]), int(w.shape[1])
+            if out is None:
+                out = out_for(max(n_out, rows), k_hi - k_lo)
+            mats.append((w.data_ptr() + 4 * k_lo, k_total, 1, n_out, k_hi - k_lo, out.data_ptr(), rows))
             return out
 
-        def pad(v):
-            v = v.detach().contiguous().float()
-            out = torch.empty(L.gw_padded_n(int(v.shape[0])), dtype=torch.float32, device=dev)
-            _lib.check(L.gw_pad_vector(v.data_ptr(), int(v.shape[0]), out.data_ptr(), st), "gw_pad_vector")
+        def pad(v, out=None, n_out=0):
+            v = src(v)
+            if out is None:
+                out = torch.empty(L.gw_padded_n(max(int(v.shape[0]), n_out)), dtype=torch.float32, device=dev)
+            vecs.append((v.data_ptr(), int(v.shape[0]), out.data_ptr(), n_out))
             return out
 
         self.w1 = [pack(weights[0], lo, hi) for lo, hi in splits]
         self.b1 = pad(biases[0])
         if self.n_mid:
-            self.w_mid = torch.cat([pack(w, 0, self.hidden) for w in weights[1:-1]])
-            self.b_mid = torch.cat([pad(b) for b in biases[1:-1]])
+            one = out_for(self.hidden, self.hidden)
+            nb = int(L.gw_padded_n(self.hidden))
+            self.w_mid = torch.empty(self.n_mid * one.numel(), dtype=one.dtype, device=dev)
+            self.b_mid = torch.empty(self.n_mid * nb, dtype=torch.float32, device=dev)
+            for l, (w, b) in enumerate(zip(weights[1:-1], biases[1:-1])):
+                pack(w, 0, self.hidden, out=self.w_mid[l * one.numel():(l + 1) * one.numel()])
+                pad(b, out=self.b_mid[l * nb:(l + 1) * nb])
         else:
             self.w_mid = self.b_mid = None
-        w_last, b_last = weights[-1], biases[-1]
-        if self.n_out < 80:
-            # output heads run on a fixed 5-tile (80 row) kernel variant: pad the last Linear with zero rows so that the
-            # packed stream has the tile count that kernel walks (n_out itself still masks the stores)
-            w_last = torch.cat([w_last.detach().float(), w_last.new_zeros((80 - self.n_out, w_last.shape[1]), dtype=torch.float32)])
-            b_last = torch.cat([b_last.detach().float(), b_last.new_zeros(80 - self.n_out, dtype=torch.float32)])
-        self.w_out = pack(w_last, 0, self.hidden)
-        self.b_out = pad(b_last)
-        def pad_head(v):  # LayerNorm on a head: the kernel reads affine parameters for all 80 rows of its 5 tiles
-            v = v.detach().float()
-            return torch.cat([v, v.new_zeros(80 - self.n_out)]) if self.n_out < 80 else v
-
-        self.gamma = pad(pad_head(ln[0])) if ln is not None else None
-        self.beta = pad(pad_head(ln[1])) if ln is not None else None
+        # output heads (n_out < 80) run on a fixed 5-tile (80 row) kernel variant: the last Linear, its bias and a LayerNorm on
+        # the head are packed as 80 rows (rows n_out..79 zero; n_out itself still masks the stores)
+        head = 80 if self.n_out < 80 else 0
+        self.w_out = pack(weights[-1], 0, self.hidden, rows=head)
+        self.b_out = pad(biases[-1], n_out=head)
+        self.gamma = pad(ln[0], n_out=head) if ln is not None else None
+        self.beta = pad(ln[1], n_out=head) if ln is not None else None
+        pack_many(self.weight_dtype, mats, vecs, st)
+        del keep
         guard.__exit__(None, None, None)
 
     def c(self, active: Sequence[bool] = (True, True, True)) -> GwMlpWeights:

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 12
+#define GW_ABI_VERSION 13
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -85,6 +85,34 @@ int gw_pack_linear_bf16(const float* w, int n_out, int k_total, int k_lo, int k_
 /* Zero-pad a vector (bias / LayerNorm gamma, beta) to a multiple of 32 floats. out has gw_padded_n(n). */
 int gw_padded_n(int n);
 int gw_pad_vector(const float* v, int n, float* out, void* stream);
+/* (v13) Every matrix slice and vector of one MLP (or any other set) packed by ONE launch: what MLP.__init__ creates
+ * (graph_net_block.py:45-61) is 3-5 Linear layers and a LayerNorm, i.e. ~10 gw_pack_linear / gw_pad_vector launches of a few
+ * microseconds each per MLP and weight version - 27 MLPs per forecaster, every training step.  A matrix item is addressed by
+ * strides, element (f, k) of the slice = w[f * stride_f + k * stride_k], so a column slice of nn.Linear.weight is
+ * {w + k_lo, k_total, 1} and the transposed block the backward's input-gradient products stream ("Linear" that maps
+ * gradients back, W[:, lo:hi]^T) is {w + lo, 1, k_total} - no transposed copy is materialised.  Rows n_out.. of the last
+ * 16-row tile quad and input features kseg.. of the last K-step are zero.  The item arrays are HOST memory (copied into the
+ * launch); at most GW_PACK_MAX_ITEMS matrices and GW_PACK_MAX_ITEMS vectors per call. */
+#define GW_PACK_MAX_ITEMS 16
+typedef struct gw_pack_item {
+  const float* w;      /* device pointer to element (0, 0) of the slice */
+  int64_t stride_f;    /* floats between consecutive output features (rows of nn.Linear.weight: k_total) */
+  int64_t stride_k;    /* floats between consecutive input features (1) */
+  int32_t n_out;       /* output features of the slice */
+  int32_t kseg;        /* input features of the slice */
+  int32_t rows;        /* rows of the packed stream, >= n_out (0 = n_out): an output head with n_out < 80 features is packed as
+                          80 rows, the tile count its kernel variant walks; rows n_out.. are zero */
+  int32_t reserved;
+  void* out;           /* gw_packed_floats(rows, 0, kseg) floats, or gw_packed_bytes_bf16(rows, 0, kseg) bytes */
+} gw_pack_item;
+typedef struct gw_pad_item {
+  const float* v;      /* device pointer, n floats */
+  int32_t n;
+  int32_t n_out;       /* entries written, >= n (0 = n), rounded up to gw_padded_n(); entries n.. are zero */
+  float* out;          /* gw_padded_n(max(n, n_out)) floats */
+} gw_pad_item;
+int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats, int32_t n_vecs, const gw_pad_item* vecs,
+                 void* stream);
 
 /* One input operand of a fused MLP ("segment" of the concatenated input). */
 typedef struct gw_operand {

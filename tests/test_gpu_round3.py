@@ -187,3 +187,88 @@ def test_graphcast_with_a_wide_processor_only():
     scale = (want - feats).abs().max().item()
     err = (got.cpu() - want).abs().max().item()
     assert err <= 2e-4 * max(scale, 1.0), (err, scale)
+
+
+def test_pack_many_equals_the_single_item_packers_bitwise():
+    """gw_pack_many (ABI v13: every slice / vector of an MLP in one launch, items addressed by strides) produces the streams of
+    gw_pack_linear / gw_pack_linear_bf16 / gw_pad_vector bit for bit: column slices, a head with 78 rows, narrow K variants, and
+    the transposed block of the backward (against packing an explicitly transposed copy)."""
+    from graph_weather_amd import _lib, ops
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(3)
+    W0 = torch.randn(256, 768, device=DEV)
+    Wh = torch.randn(78, 128, device=DEV)
+    Wk = torch.randn(256, 102, device=DEV)
+    W2 = torch.randn(256, 2, device=DEV)
+    vs = [torch.randn(n, device=DEV) for n in (256, 78, 128, 5)]
+    cases = [(W0, 0, 256), (W0, 256, 512), (W0, 512, 768), (Wh, 0, 128), (Wk, 0, 102), (W2, 0, 2)]
+    for bf16 in (False, True):
+        dt = _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32
+        want, got, mats = [], [], []
+        for w, lo, hi in cases:
+            if bf16:
+                nb = L.gw_packed_bytes_bf16(int(w.shape[0]), lo, hi)
+                a = torch.zeros(nb // 2, dtype=torch.bfloat16, device=DEV)
+                b = torch.ones_like(a)
+                _lib.check(L.gw_pack_linear_bf16(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), lo, hi, a.data_ptr(), st), "pack")
+            else:
+                n = L.gw_packed_floats(int(w.shape[0]), lo, hi)
+                a = torch.zeros(n, device=DEV)
+                b = torch.ones_like(a)
+                _lib.check(L.gw_pack_linear(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), lo, hi, a.data_ptr(), st), "pack")
+            want.append(a)
+            got.append(b)
+            mats.append((w.data_ptr() + 4 * lo, int(w.shape[1]), 1, int(w.shape[0]), hi - lo, b.data_ptr()))
+        # the transposed 256 x 256 block W0[:, 256:512]^T, in place, against a packed explicit transpose
+        Wt = W0[:, 256:512].t().contiguous()
+        if bf16:
+            a = torch.zeros(L.gw_packed_bytes_bf16(256, 0, 256) // 2, dtype=torch.bfloat16, device=DEV)
+            _lib.check(L.gw_pack_linear_bf16(Wt.data_ptr(), 256, 256, 0, 256, a.data_ptr(), st), "pack")
+        else:
+            a = torch.zeros(L.gw_packed_floats(256, 0, 256), device=DEV)
+            _lib.check(L.gw_pack_linear(Wt.data_ptr(), 256, 256, 0, 256, a.data_ptr(), st), "pack")
+        b = torch.ones_like(a)
+        want.append(a)
+        got.append(b)
+        mats.append((W0.data_ptr() + 4 * 256, 1, 768, 256, 256, b.data_ptr()))
+        vwant, vgot, vecs = [], [], []
+        for v in vs:
+            a = torch.zeros(L.gw_padded_n(int(v.shape[0])), device=DEV)
+            b = torch.ones_like(a)
+            _lib.check(L.gw_pad_vector(v.data_ptr(), int(v.shape[0]), a.data_ptr(), st), "pad")
+            vwant.append(a)
+            vgot.append(b)
+            vecs.append((v.data_ptr(), int(v.shape[0]), b.data_ptr()))
+        ops.pack_many(dt, mats, vecs, st)
+        torch.cuda.synchronize()
+        for a, b in zip(want + vwant, got + vgot):
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    # an output head: 78 rows packed as the 80 rows its kernel variant walks == packing the explicitly zero-padded matrix / vector
+    Wh80 = torch.cat([Wh, Wh.new_zeros(2, 128)])
+    b78 = torch.randn(78, device=DEV)
+    b80 = torch.cat([b78, b78.new_zeros(2)])
+    for n_small in (78, 32):
+        Ws_, bs_ = Wh[:n_small].contiguous(), b78[:n_small].contiguous()
+        W80 = torch.cat([Ws_, Ws_.new_zeros(80 - n_small, 128)])
+        v80 = torch.cat([bs_, bs_.new_zeros(80 - n_small)])
+        a = torch.zeros(L.gw_packed_floats(80, 0, 128), device=DEV)
+        _lib.check(L.gw_pack_linear(W80.data_ptr(), 80, 128, 0, 128, a.data_ptr(), st), "pack")
+        b = torch.ones_like(a)
+        va = torch.zeros(L.gw_padded_n(80), device=DEV)
+        _lib.check(L.gw_pad_vector(v80.data_ptr(), 80, va.data_ptr(), st), "pad")
+        vb = torch.ones_like(va)
+        ops.pack_many(_lib.DTYPE_F32, [(Ws_.data_ptr(), 128, 1, n_small, 128, b.data_ptr(), 80)], [(bs_.data_ptr(), n_small, vb.data_ptr(), 80)], st)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(va, vb)
+    # more items than one launch takes: chunked by the host wrapper
+    many = [(W0.data_ptr(), 768, 1, 256, 256, torch.empty(L.gw_packed_floats(256, 0, 256), device=DEV)) for _ in range(20)]
+    ops.pack_many(_lib.DTYPE_F32, [m[:5] + (m[5].data_ptr(),) for m in many], [], st)
+    torch.cuda.synchronize()
+    ref = torch.empty(L.gw_packed_floats(256, 0, 256), device=DEV)
+    _lib.check(L.gw_pack_linear(W0.data_ptr(), 256, 768, 0, 256, ref.data_ptr(), st), "pack")
+    torch.cuda.synchronize()
+    assert all(torch.equal(m[5], ref) for m in many)
+    with pytest.raises(RuntimeError):
+        ops.pack_many(7, [many[0][:5] + (many[0][5].data_ptr(),)], [], st)
