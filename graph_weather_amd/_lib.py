@@ -22,7 +22,7 @@ EDGE_DETERMINISTIC = 1
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
-    "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector", "gw_pack_many",
+    "gw_pack_linear_bf16", "gw_padded_n", "gw_pad_vector", "gw_pack_many", "gw_mlp_chain_backward",
     "gw_mlp_forward", "gw_mlp_post_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
     "gw_edge_rows_to_tiles", "gw_node_update_forward", "gw_node_update_head_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
@@ -116,6 +116,9 @@ def lib():
     L.gw_padded_n.argtypes = [c_int]
     L.gw_pad_vector.restype = c_int
     L.gw_pad_vector.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+    L.gw_mlp_chain_backward.restype = c_int
+    L.gw_mlp_chain_backward.argtypes = [c_int64, c_void_p, c_int32, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                        c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p]
     L.gw_pack_many.restype = c_int
     L.gw_pack_many.argtypes = [c_int32, c_int32, POINTER(GwPackItem), c_int32, POINTER(GwPadItem), c_void_p]
     L.gw_mlp_forward.restype = c_int

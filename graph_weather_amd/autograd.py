@@ -141,17 +141,36 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
     return out
 
 
+def chain_backward(d: torch.Tensor, chain, fan):
+    """gw_mlp_chain_backward: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows x 256."""
+    import ctypes as C
+
+    def arr(ptrs):
+        a = (C.c_void_p * max(len(ptrs), 1))()
+        for i, v in enumerate(ptrs):
+            a[i] = v
+        return a
+
+    _lib.check(_L().gw_mlp_chain_backward(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), len(chain),
+                                          arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
+                                          arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]),
+                                          arr([f[1].data_ptr() for f in fan]), _st(d)), "gw_mlp_chain_backward")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # backward of the Linear/ReLU chain shared by all fused ops
 # ---------------------------------------------------------------------------------------------------------------------
 def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
-                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None, ln_width: int = 0):
+                        gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None, ln_width: int = 0,
+                        fan: Sequence[Tuple[int, int]] = (), fan_out: Optional[dict] = None):
     """Backward through [LayerNorm] <- Linear_L <- ReLU <- ... <- Linear_1 <- ReLU, down to the output of Linear_0.
 
     ``weights`` = [W0, b0, W1, b1, ..., WL, bL, (gamma, beta)] (state_dict order of the reference ``MLP.model``);
     ``grads`` has the same length and is filled in place for W1..WL, every bias and gamma / beta.  W0's gradient
     depends on how the caller feeds layer 0 (concatenated operands, gathers, pre-multiplied tables) and is left to it.
-    Returns (dz0 [rows, hidden] = gradient at the output of Linear_0, already masked by its ReLU, device)."""
+    Returns (dz0 [rows, hidden] = gradient at the output of Linear_0, already masked by its ReLU, device).
+    ``fan``: column blocks (lo, hi) of W0 whose input gradients dz0 @ W0[:, lo:hi] the caller wants; ``fan_out[(lo, hi)]``
+    receives them (from the fused chain launch when the MLP has the kernel shapes, from single products otherwise)."""
     n_lin = (len(weights) - (2 if has_norm else 0)) // 2
     if n_lin < 2:
         raise RuntimeError("MLP needs at least one hidden layer")
@@ -169,6 +188,37 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1], ln_width)
     else:
         d = dout.contiguous()
+    # Kernel-shaped MLPs (256 wide, at most two Linear layers above layer 0): the whole chain of masked input-gradient products
+    # and the requested layer-0 blocks in ONE launch (gw_mlp_chain_backward); the weight-gradient GEMMs read what it stored.
+    fused = None
+    if (mlp is not None and 2 <= n_lin <= 3 and d.shape[1] == 256 and d.stride(0) % 4 == 0 and d.shape[0] > 0
+            and all(saved.hidden[l].shape[1] == 256 and saved.hidden[l].stride(0) == 256 for l in range(n_lin - 1))):
+        pts = [_packed_transposed(mlp, l, weights[2 * l], 0, int(weights[2 * l].shape[1])) for l in range(n_lin - 1, 0, -1)]
+        if all(p is not None for p in pts):
+            fblk = [(tuple(blk), _packed_transposed(mlp, 0, weights[0], blk[0], blk[1])) for blk in (fan if fan_out is not None else ())]
+            fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
+            rows = int(d.shape[0])
+            outs = [torch.empty((rows, 256), dtype=torch.float32, device=d.device) for _ in pts]
+            fouts = [torch.empty((rows, 256), dtype=torch.float32, device=d.device) for _ in fblk]
+            chain_backward(d, [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
+                           [(ft, t) for (_, ft), t in zip(fblk, fouts)])
+            fused = outs
+            for (blk, _), t in zip(fblk, fouts):
+                fan_out[blk] = t
+    if fused is not None:
+        ds = [d] + fused  # ds[i]: gradient at the output of Linear_{n_lin-1-i}
+        for i, l in enumerate(range(n_lin - 1, 0, -1)):
+            gW, gb = zs[2 * l], zs[2 * l + 1]
+            gemm_tn_acc(ds[i], saved.hidden[l - 1], gW, colsum=gb)
+            grads[2 * l], grads[2 * l + 1] = gW, gb
+        d = ds[-1]
+        grads[1] = zs[1]
+        relu_backward(d, None, grads[1])
+        if fan_out is not None:
+            for lo, hi in fan:
+                if (lo, hi) not in fan_out:
+                    fan_out[(lo, hi)] = input_grad(mlp, 0, d, weights[0], lo, hi)
+        return d, d.device
     # Every Linear_l (l >= 1) gets its weight gradient d_l^T h_{l-1} and, from the same GEMM, its bias gradient (column
     # sums of d_l); the input gradient d_l W_l is masked by the ReLU that produced h_{l-1} in the product's epilogue.
     for l in range(n_lin - 1, 0, -1):
@@ -182,6 +232,9 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     # Linear_0's bias gradient: column sums of dz0 (its weight gradient is the caller's: it depends on the operands)
     grads[1] = zs[1]
     relu_backward(d, None, grads[1])
+    if fan_out is not None and mlp is not None:
+        for lo, hi in fan:
+            fan_out[(lo, hi)] = input_grad(mlp, 0, d, weights[0], lo, hi)
     return d, d.device
 
 
@@ -205,13 +258,15 @@ class MLPRowsFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x2, res, *params = ctx.saved_tensors
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
-                                     ctx.mlp.out_dim)
         W0 = params[0]
+        fan = [(0, int(W0.shape[1]))] if ctx.needs_input_grad[1] else []
+        fo: dict = {}
+        dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
+                                     ctx.mlp.out_dim, fan=fan, fan_out=fo)
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
         gemm_tn_acc(dz0, x2, gW0)
         grads[0] = gW0
-        dx = input_grad(ctx.mlp, 0, dz0, W0, 0, int(W0.shape[1])) if ctx.needs_input_grad[1] else None
+        dx = fo[fan[0]] if fan else None
         dres = None
         if ctx.has_res and ctx.needs_input_grad[2]:
             # y = MLP(x) + res[:, :n_out]: the identity term of d(out)/d(features) (multi-step rollouts feed the output back in)
@@ -366,7 +421,10 @@ class EdgeUpdateFunction(torch.autograd.Function):
         dn = gather_rows(dagg.contiguous(), plan.n_dst, plan.dst, B, E, add)
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         has_norm = mlp._norm() is not None
-        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim)
+        fan = [tuple(mlp.native_splits()[i]) for i, sp in enumerate(specs) if sp.mode == "raw" and ctx.needs_input_grad[5 + i]]
+        fo: dict = {}
+        dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim,
+                                     fan=fan, fan_out=fo)
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
         tensors = (x_src, x_dst, e_in)
@@ -384,7 +442,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
                 g = t if (idx is None and sp.rows_pb > 0) else gather_rows(t, sp.rows_pb, idx, B, E)
                 gemm_tn_acc(dz0, g, gW0, c_col0=lo)
                 if ctx.needs_input_grad[5 + i]:
-                    dg = input_grad(mlp, 0, dz0, W0, lo, hi)
+                    dg = fo[(lo, hi)]
                     dts[i] = _scatter_rows(dg, i, plan, B, sp.rows_pb, n_rows_tab[i])
         grads[0] = gW0
         de_res = None
@@ -424,14 +482,17 @@ class NodeUpdateFunction(torch.autograd.Function):
         dout = dout.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         has_norm = ctx.mlp._norm() is not None
-        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, ctx.mlp, ctx.mlp.out_dim)
+        (xlo, xhi), (alo, ahi) = mlp.native_splits()
+        sp = ctx.x_spec
+        fan = ([(alo, ahi)] if ctx.needs_input_grad[7] else []) + ([(xlo, xhi)] if (sp.mode == "raw" and ctx.needs_input_grad[5]) else [])
+        fo: dict = {}
+        dz0, _ = _mlp_chain_backward(dout, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, ctx.mlp, ctx.mlp.out_dim,
+                                     fan=fan, fan_out=fo)
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
-        (xlo, xhi), (alo, ahi) = mlp.native_splits()
         gemm_tn_acc(dz0, agg, gW0, c_col0=alo)
-        dagg = input_grad(mlp, 0, dz0, W0, alo, ahi) if ctx.needs_input_grad[7] else None
+        dagg = fo[(alo, ahi)] if ctx.needs_input_grad[7] else None
         dx = None
-        sp = ctx.x_spec
 
         def over_batch(rows):  # gradient of a table shared by the batch: sum the per-sample rows
             ident = torch.arange(rpb + 1, dtype=torch.int32, device=rows.device)
@@ -441,7 +502,7 @@ class NodeUpdateFunction(torch.autograd.Function):
             xg = x if sp.rows_pb > 0 else gather_rows(x, 0, None, batch, rpb)
             gemm_tn_acc(dz0, xg, gW0, c_col0=xlo)
             if ctx.needs_input_grad[5]:
-                dx = input_grad(mlp, 0, dz0, W0, xlo, xhi)
+                dx = fo[(xlo, xhi)]
                 if sp.rows_pb == 0:
                     dx = over_batch(dx)
         elif sp.mode == "proj" and ctx.needs_input_grad[5]:

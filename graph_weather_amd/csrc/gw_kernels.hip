@@ -557,6 +557,69 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, int n, int npad, 
   if (i < npad) out[i] = i < n ? v[i] : 0.f;
 }
 
+// ---- gw_mlp_chain_backward: the Linear / ReLU chain of an MLP walked backwards, register-resident ---------------------------
+// d_0 = d;  d_{i+1} = (d_i . W_i) * (h_i > 0) for the n_chain Linear layers above layer 1 (W_i: the layer's weight, streamed as
+// the packed transposed block; h_i: the ReLU output that fed the layer, from the forward's activation save); then the input
+// gradients of layer 1, d_n . W1[:, block], for up to 3 operand blocks.  The forward kernel's structure: the accumulator of one
+// product is the B operand of the next, weights stream through LDS (double buffered DMA, two workgroups per CU); every d_i is
+// stored once (the weight-gradient GEMMs read it) and never read back by this chain.
+struct BwdChainArgs {
+  const float* d;
+  const float* w[5];
+  const float* mask[2];
+  float* out[5];
+  long long n_rows;
+  int d_ld, n_chain, n_fan;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HS = 64, HSTEPF = 1024;  // K-steps / floats per step of a 256 -> 256 product
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const long long c_raw = (long long)blockIdx.x * kColsPerWG + wave * kColsPerWave + j;
+  const bool valid = c_raw < a.n_rows;
+  const long long c = valid ? c_raw : a.n_rows - 1;
+  const int n_prod = a.n_chain + a.n_fan;
+  int parity = 0;
+  issue_chunk(a.w[0], kChunkSteps * HSTEPF, lds, lane, wave);
+  float x[HS];
+  load_operand<HS, true>(x, a.d + (size_t)c * (size_t)a.d_ld, 256, q);
+#pragma unroll 1
+  for (int p = 0; p < n_prod; ++p) {
+    const bool chain = p < a.n_chain;
+    f32x4 mv[16];
+    if (chain) {  // the ReLU output that gates this product: fetched underneath its MFMAs
+      const float* mrow = a.mask[p] + (size_t)c * 256;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) mv[t] = ldg4(mrow + 16 * t + 4 * q);
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* nx = p + 1 < n_prod ? a.w[p + 1] : nullptr;
+    mma_pass<HS, 16, false>(acc, x, a.w[p], nx, nx ? kChunkSteps * HSTEPF : 0, lds, parity, lane, wave, nullptr, false, nullptr,
+                            false, q);
+    if (chain) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = mv[t][r] > 0.f ? acc[t][r] : 0.f;
+          acc[t][r] = v;
+          x[4 * t + r] = v;  // (accumulator layout == B-operand layout of the next product)
+        }
+    }
+    if (valid) {
+      float* orow = a.out[p] + (size_t)c * 256;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) stg4(orow + 16 * t + 4 * q, acc[t]);
+    }
+  }
+}
+
 // ---- gw_pack_many: all slices / vectors of an MLP in one launch (blockIdx.y = item; the last y packs the vectors) --------
 struct PackManyArgs {
   gw_pack_item m[GW_PACK_MAX_ITEMS];
@@ -800,6 +863,39 @@ int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats,
   }
   hipLaunchKernelGGL(pack_many_kernel, dim3(64, n_mats + (n_vecs > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("pack_many_kernel launch");
+}
+
+int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const float* const* chain_w,
+                          const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const float* const* fan_w,
+                          float* const* fan_out, void* stream) {
+  if (n_rows < 0 || !d || d_ld < 256 || d_ld % 4 != 0 || n_chain < 0 || n_chain > 2 || n_fan < 0 || n_fan > 3 || n_chain + n_fan < 1 ||
+      (n_chain > 0 && (!chain_w || !chain_mask || !chain_out)) || (n_fan > 0 && (!fan_w || !fan_out)))
+    return fail(GW_E_BADARG, "gw_mlp_chain_backward: bad arguments");
+  if (n_rows == 0) return GW_OK;
+  BwdChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d = d;
+  a.d_ld = d_ld;
+  a.n_rows = n_rows;
+  a.n_chain = n_chain;
+  a.n_fan = n_fan;
+  for (int i = 0; i < n_chain; ++i) {
+    if (!chain_w[i] || !chain_mask[i] || !chain_out[i]) return fail(GW_E_BADARG, "gw_mlp_chain_backward: NULL chain item");
+    a.w[i] = chain_w[i];
+    a.mask[i] = chain_mask[i];
+    a.out[i] = chain_out[i];
+  }
+  for (int i = 0; i < n_fan; ++i) {
+    if (!fan_w[i] || !fan_out[i]) return fail(GW_E_BADARG, "gw_mlp_chain_backward: NULL fan item");
+    a.w[n_chain + i] = fan_w[i];
+    a.out[n_chain + i] = fan_out[i];
+  }
+  static DeviceOnce once;
+  if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  const long long grid = (n_rows + kColsPerWG - 1) / kColsPerWG;
+  if (grid > 0x7fffffffLL) return fail(GW_E_BADARG, "gw_mlp_chain_backward: too many rows");
+  hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
+  return check_launch("bwd_chain_kernel launch");
 }
 
 int gw_pad_vector(const float* v, int n, float* out, void* stream) {

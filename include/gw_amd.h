@@ -170,6 +170,17 @@ int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand
                         float* out /* may be NULL */, int32_t out_ld, int32_t n_post, const float* const* post_w,
                         void* const* post_out, int32_t post_layout, void* stream);
 
+/* (v13) Backward of the Linear / ReLU chain of an MLP (graph_net_block.py:45-61; what autograd runs for loss.backward(),
+ * train/run.py:517-519, as one addmm-backward + threshold_backward pair per layer) in one launch, register-resident like the
+ * forward: d_0 = d [n_rows, 256 (ld d_ld)];  d_{i+1} = (d_i . W_i) * (mask_i > 0) for i < n_chain (<= 2), each stored to
+ * chain_out[i] [n_rows, 256] (the weight-gradient products read them); then fan_out[s] = d_{n_chain} . Wf_s for s < n_fan (<= 3):
+ * the input gradients of the first Linear's operand blocks.  chain_w / fan_w: packed TRANSPOSED 256 x 256 blocks
+ * (gw_pack_many with {w + lo, 1, k_total}); chain_mask[i]: the ReLU output that fed layer i [n_rows, 256] (gw_activation_save).
+ * fp32 only. */
+int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const float* const* chain_w,
+                          const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const float* const* fan_w,
+                          float* const* fan_out, void* stream);
+
 /* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
  * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7
  * edges incident to a node, and the ones over batch-independent tables are cacheable.)

@@ -272,3 +272,41 @@ def test_pack_many_equals_the_single_item_packers_bitwise():
     assert all(torch.equal(m[5], ref) for m in many)
     with pytest.raises(RuntimeError):
         ops.pack_many(7, [many[0][:5] + (many[0][5].data_ptr(),)], [], st)
+
+
+@pytest.mark.parametrize("rows", [1, 64, 1000, 4097])
+def test_chain_backward_kernel_against_torch(rows):
+    """gw_mlp_chain_backward (ABI v13): d1 = (d W2) * (h1 > 0), dz0 = (d1 W1) * (h0 > 0), fan products dz0 W0[:, block] - one
+    launch - against the same products in torch fp64 (ragged row counts; 1, 2 chain links; 0..3 fan blocks)."""
+    from graph_weather_amd import _lib, autograd as ag, ops
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    W2, W1 = (torch.randn(256, 256, generator=g) / 16).to(DEV), (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    W0 = (torch.randn(256, 768, generator=g) / 16).to(DEV)
+    d = torch.randn(rows, 256, generator=g).to(DEV)
+    h1, h0 = torch.randn(rows, 256, generator=g).relu().to(DEV), torch.randn(rows, 256, generator=g).relu().to(DEV)
+    n = int(L.gw_packed_floats(256, 0, 256))
+    blocks = [(W2, 0), (W1, 0), (W0, 0), (W0, 256), (W0, 512)]
+    buf = torch.empty(len(blocks) * n, device=DEV)
+    ops.pack_many(_lib.DTYPE_F32, [(W.data_ptr() + 4 * lo, 1, int(W.shape[1]), 256, 256, buf[i * n:].data_ptr())
+                                   for i, (W, lo) in enumerate(blocks)], [], st)
+    pk = [buf[i * n:(i + 1) * n] for i in range(len(blocks))]
+    dd = d.double()
+    r1 = (dd @ W2.double()) * (h1 > 0)
+    r0 = (r1 @ W1.double()) * (h0 > 0)
+    for n_chain in (1, 2):
+        for n_fan in (0, 1, 3):
+            outs = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(n_chain)]
+            fouts = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(n_fan)]
+            chain = [(pk[0], h1, outs[0])] + ([(pk[1], h0, outs[1])] if n_chain == 2 else [])
+            ag.chain_backward(d, chain, [(pk[2 + s], fouts[s]) for s in range(n_fan)])
+            torch.cuda.synchronize()
+            last = r0 if n_chain == 2 else r1
+            want = [r1, r0][:n_chain] + [last @ W0.double()[:, 256 * s:256 * (s + 1)] for s in range(n_fan)]
+            for got, ref in zip(outs + fouts, want):
+                scale = ref.abs().max().item() + 1e-12
+                assert (got.double() - ref).abs().max().item() <= 2e-5 * scale
+    with pytest.raises(RuntimeError):
+        ag.chain_backward(d, [], [])
