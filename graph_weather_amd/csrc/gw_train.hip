@@ -633,9 +633,10 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     if (k == 0) return GW_OK;  // nothing to add
     // slab of rows per block: enough blocks to fill the chip (>= ~1024), each at least 256 rows deep
     const int tiles = (int)((m + 127) / 128) * ((n + 127) / 128);
-    int64_t k_slab = (k * tiles + 1023) / 1024;
+    static const int tn_target = GW_TUNE("GW_TN_TARGET", 1024), tn_min = GW_TUNE("GW_TN_MIN", 256);
+    int64_t k_slab = (k * tiles + tn_target - 1) / tn_target;
     k_slab = ((k_slab + 63) / 64) * 64;
-    if (k_slab < 256) k_slab = 256;
+    if (k_slab < tn_min) k_slab = tn_min;
     if (k_slab > 4096) k_slab = 4096;
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
     if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
