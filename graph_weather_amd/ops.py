@@ -265,15 +265,20 @@ def mlp_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, res
 
 
 def mlp_post_forward(pm: PackedMLP, x: Operand, n_rows: int, rows_per_batch: int, post_w: Sequence[torch.Tensor],
-                     post_half: bool = False, want_out: bool = False):
+                     post_half: bool = False, want_out: bool = False, out: Optional[torch.Tensor] = None,
+                     post_out: Optional[Sequence[torch.Tensor]] = None):
     """graph_net_block.py:63-77 on ``n_rows`` rows, then the products of the output rows with packed [256, 256] slices in the same
-    launch (include/gw_amd.h: gw_mlp_post_forward).  Returns (out or None, [products])."""
+    launch (include/gw_amd.h: gw_mlp_post_forward).  Returns (out or None, [products]); ``out`` / ``post_out``: caller's buffers."""
     import ctypes
 
     dev = x.tensor.device
-    out = torch.empty((n_rows, 256), dtype=torch.float32, device=dev) if want_out else None
+    if out is None and want_out:
+        out = torch.empty((n_rows, 256), dtype=torch.float32, device=dev)
     n_post = len(post_w)
-    outs = [torch.empty((n_rows, 256), dtype=torch.float16 if post_half else torch.float32, device=dev) for _ in range(n_post)]
+    outs = (list(post_out) if post_out is not None else
+            [torch.empty((n_rows, 256), dtype=torch.float16 if post_half else torch.float32, device=dev) for _ in range(n_post)])
+    for o_ in outs:
+        _require(o_, "post product rows", torch.float16 if post_half else torch.float32)
     wp = (ctypes.c_void_p * n_post)(*[w_.data_ptr() for w_ in post_w])
     op = (ctypes.c_void_p * n_post)(*[o_.data_ptr() for o_ in outs])
     with on_device_of(outs[0]):
@@ -386,10 +391,12 @@ def node_update_forward(pm: PackedMLP, n_rows: int, rows_per_batch: int, x: Oper
 
 
 def node_update_head_forward(pm: PackedMLP, head: PackedMLP, n_rows: int, rows_per_batch: int, x: Operand, agg: Operand,
-                             residual: Optional[Operand]) -> torch.Tensor:
+                             residual: Optional[Operand], out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """graph_net_block.py:189-191 followed by the output head (+ residual) in one launch: include/gw_amd.h:
     gw_node_update_head_forward.  Returns [n_rows, head.n_out]."""
-    out = torch.empty((n_rows, head.n_out), dtype=torch.float32, device=agg.tensor.device)
+    if out is None:
+        out = torch.empty((n_rows, head.n_out), dtype=torch.float32, device=agg.tensor.device)
+    _require(out, "out")
     wc = pm.c((x.k > 0 and not x.projected, True, False))
     rc = residual.c() if residual is not None else None
     if rc is not None:

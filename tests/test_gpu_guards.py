@@ -250,3 +250,110 @@ def test_node_update_with_post_products_stays_inside_its_buffers(dtype, rows, B,
         return res
 
     _both(run)
+
+
+def _pack_bf16(w):
+    L = ops._lib.lib()
+    wd = w.to(DEV).contiguous()
+    buf = torch.empty(L.gw_packed_bytes_bf16(int(wd.shape[0]), 0, int(wd.shape[1])) // 2, dtype=torch.bfloat16, device=DEV)
+    ops._lib.check(L.gw_pack_linear_bf16(wd.data_ptr(), int(wd.shape[0]), int(wd.shape[1]), 0, int(wd.shape[1]), buf.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "pack")
+    return buf
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("B,n_src,n_dst,E,use_e", [(2, 50, 40, 333, True), (1, 7, 5, 64, True), (3, 9, 4, 5, False), (16, 20, 30, 1000, True),
+                                                   (4, 33, 17, 129, True)])
+def test_team_edge_update_without_residual_stays_inside_its_buffers(half, B, n_src, n_dst, E, use_e):
+    """Round-3 form of the decoder / encoder edge update (csrc/gw_edge16t.hip, gathered, e_res.k == 0): one per-sample table of
+    projected rows (fp32 or fp16), the batch-shared per-edge products, nothing written but the aggregate."""
+    rs = np.random.RandomState(E + 3)
+    mlp = _mlp(rs, 768, 256, 256, True, torch.bfloat16)
+    src, dst = _graph(rs, n_src, n_dst, E)
+    ps = torch.from_numpy(rs.standard_normal((B * n_src, 256)).astype(np.float32))
+    pe = torch.from_numpy(rs.standard_normal((E, 256)).astype(np.float32))
+
+    def run(g):
+        pm = _packed(g, mlp, ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+        agg = g.wrap(torch.zeros(B * n_dst, 256))
+        tab = g.wrap(ps.half() if half else ps)
+        ops.edge_update_forward(pm, B, g.wrap(src), g.wrap(dst), Operand(tab, n_src, 256, projected=True), ops.ZERO,
+                                Operand(g.wrap(pe), 0, 256, projected=True) if use_e else ops.ZERO, ops.ZERO, n_dst, agg, None)
+        return {"agg": agg}
+
+    _both(run)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("rows,B,in_dim,want_out", [(1000, 2, 102, False), (77, 1, 78, True), (333, 3, 128, False), (1, 1, 40, True)])
+def test_mlp_with_post_products_stays_inside_its_buffers(half, rows, B, in_dim, want_out):
+    """gw_mlp_post_forward (node encoder + the first layer-1 product of the encoder's edge MLP, one launch), bf16."""
+    rs = np.random.RandomState(rows + in_dim)
+    mlp = _mlp(rs, in_dim, 256, 256, True, torch.bfloat16)
+    post = torch.from_numpy((rs.standard_normal((256, 256)) / 16).astype(np.float32))
+    n = rows * B
+    x = torch.from_numpy(rs.standard_normal((n, in_dim)).astype(np.float32))
+
+    def run(g):
+        pm = _packed(g, mlp, ((0, in_dim),), torch.bfloat16)
+        pw = g.wrap(_pack_bf16(post))
+        out = g.wrap(torch.zeros(n, 256)) if want_out else None
+        po = g.wrap(torch.zeros(n, 256, dtype=torch.float16 if half else torch.float32))
+        ops.mlp_post_forward(pm, Operand(g.wrap(x), rows, in_dim), n, rows, [pw], post_half=half, out=out, post_out=[po])
+        res = {"post": po}
+        if want_out:
+            res["out"] = out
+        return res
+
+    _both(run)
+
+
+@pytest.mark.parametrize("rows,B,n_out,with_res", [(1000, 2, 78, True), (77, 1, 78, False), (333, 3, 37, True), (1, 1, 80, True)])
+def test_node_update_with_head_stays_inside_its_buffers(rows, B, n_out, with_res):
+    """gw_node_update_head_forward (decoder node update + output head + residual, one launch), bf16; the x operand is the projected
+    batch-shared table the round-3 decoder feeds (rows_per_batch 0)."""
+    rs = np.random.RandomState(rows + n_out)
+    mlp = _mlp(rs, 512, 256, 256, True, torch.bfloat16)
+    head = _mlp(rs, 256, 128, n_out, False, torch.bfloat16)
+    n = rows * B
+    xp = torch.from_numpy(rs.standard_normal((rows, 256)).astype(np.float32))
+    a = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
+    feats = torch.from_numpy(rs.standard_normal((n, 102)).astype(np.float32))
+
+    def run(g):
+        pm = _packed(g, mlp, ((0, 256), (256, 512)), torch.bfloat16)
+        hd = _packed(g, head, ((0, 256),), torch.bfloat16)
+        out = g.wrap(torch.zeros(n, n_out))
+        ops.node_update_head_forward(pm, hd, n, rows, Operand(g.wrap(xp), 0, 256, projected=True), Operand(g.wrap(a), rows, 256),
+                                     Operand(g.wrap(feats), rows, n_out) if with_res else None, out=out)
+        return {"out": out}
+
+    _both(run)
+
+
+@pytest.mark.parametrize("rows,n_chain,n_fan", [(1000, 2, 3), (77, 1, 0), (1, 2, 1), (4097, 2, 2)])
+def test_chain_backward_stays_inside_its_buffers(rows, n_chain, n_fan):
+    """gw_mlp_chain_backward: gradient rows, ReLU masks, transposed packs and every output between canaries."""
+    from graph_weather_amd import autograd as ag
+
+    rs = np.random.RandomState(rows + n_fan)
+    L = ops._lib.lib()
+    Ws = [torch.from_numpy((rs.standard_normal((256, 256)) / 16).astype(np.float32)) for _ in range(n_chain + n_fan)]
+    d = torch.from_numpy(rs.standard_normal((rows, 256)).astype(np.float32))
+    hs = [torch.from_numpy(np.maximum(rs.standard_normal((rows, 256)), 0).astype(np.float32)) for _ in range(n_chain)]
+
+    def run(g):
+        n = int(L.gw_packed_floats(256, 0, 256))
+        pk = []
+        for w in Ws:
+            wd = w.to(DEV)
+            buf = torch.empty(n, device=DEV)
+            ops.pack_many(ops._lib.DTYPE_F32, [(wd.data_ptr(), 1, 256, 256, 256, buf.data_ptr())], [], torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            pk.append(g.wrap(buf))
+        outs = [g.wrap(torch.zeros(rows, 256)) for _ in range(n_chain + n_fan)]
+        ag.chain_backward(g.wrap(d), [(pk[i], g.wrap(hs[i]), outs[i]) for i in range(n_chain)],
+                          [(pk[n_chain + s], outs[n_chain + s]) for s in range(n_fan)])
+        return {f"o{i}": o for i, o in enumerate(outs)}
+
+    _both(run)
