@@ -161,12 +161,27 @@ __device__ __forceinline__ void init_bias16(f32x4 (&acc)[NG][NT], const float* _
 // bin[s] <- bf16(row[k(s,q,i)]) for a raw operand row (valid features [0, kvalid))
 template <int KS, bool FULL, int DEPTH = 4>
 __device__ __forceinline__ void load_raw16(bf16x8 (&bin)[KS], const float* __restrict__ row, int kvalid, int q) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool pairs = !FULL && (kvalid & 1) == 0 && ((size_t)row & 7) == 0;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     f32x4 lo, hi;
     if (FULL) {
       lo = ldg4(row + 32 * s + 4 * q);
       hi = ldg4(row + 32 * s + 16 + 4 * q);
+    } else if (pairs) {
+      // rows of an even number of floats at an 8-byte aligned base (the 102 input features of the node encoder: 408-byte rows):
+      // 8-byte loads - half the load instructions of the scalar form, which is what this launch's input phase is made of
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const int k0 = 32 * s + 4 * q + r, k1 = k0 + 16;
+        const f32x2 a = k0 < kvalid ? *(const GW_AS1 f32x2*)(row + k0) : f32x2{0.f, 0.f};
+        const f32x2 b = k1 < kvalid ? *(const GW_AS1 f32x2*)(row + k1) : f32x2{0.f, 0.f};
+        lo[r] = a.x;
+        lo[r + 1] = a.y;
+        hi[r] = b.x;
+        hi[r + 1] = b.y;
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -273,11 +288,22 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kerne
       } else if (prj[i]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+          if (a.seg_half[i]) {  // fp16 product rows (GW_LAYOUT_ROWS_F16): 8 bytes per row tile and lane
+            const int r = a.seg_idx[i] ? ldgi(a.seg_idx[i] + kk[g]) : kk[g];
+            const _Float16* row = (const _Float16*)a.seg_ptr[i] + ((size_t)bb[g] * (size_t)a.seg_rows_pb[i] + (size_t)r) * (size_t)a.seg_ld[i];
 #pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            acc[g][t] += ldg4(row + 16 * t + 4 * q);
-            if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < HT; ++t) {
+              const half4_t h = *(const GW_AS1 half4_t*)(row + 16 * t + 4 * q);
+              acc[g][t] += f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+              if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+            const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              acc[g][t] += ldg4(row + 16 * t + 4 * q);
+              if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
@@ -419,12 +445,24 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kerne
       if (valid[g]) {
         const float* rrow = a.res_ptr ? operand_row16(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]) : nullptr;
         float* orow = a.out + (size_t)cc[g] * (size_t)a.out_ld;
+        // rows of an even number of floats at 8-byte aligned bases (78 outputs, 102-float feature rows): 8-byte accesses
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const bool pairs = (a.out_cols & 1) == 0 && ((size_t)orow & 7) == 0 && ((size_t)rrow & 7) == 0;
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
           const int f0 = 16 * t + 4 * q;
+          if (pairs) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (f0 + r < a.out_cols) stg1(orow + f0 + r, y[g][t][r] + (rrow ? ldg1(rrow + f0 + r) : 0.f));
+            for (int r = 0; r < 4; r += 2)
+              if (f0 + r < a.out_cols) {
+                const f32x2 rv = rrow ? *(const GW_AS1 f32x2*)(rrow + f0 + r) : f32x2{0.f, 0.f};
+                *(GW_AS1 f32x2*)(orow + f0 + r) = f32x2{y[g][t][r] + rv.x, y[g][t][r + 1] + rv.y};
+              }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (f0 + r < a.out_cols) stg1(orow + f0 + r, y[g][t][r] + (rrow ? ldg1(rrow + f0 + r) : 0.f));
+          }
         }
       }
     }

@@ -26,6 +26,7 @@ struct ChainArgs {
   int seg_ld[3];
   int seg_k[3];
   int seg_proj[3];     // operand is already multiplied by its layer-1 weight slice: rows are [hidden] wide
+  int seg_half[3];     // ... and stored as fp16 rows (GW_LAYOUT_ROWS_F16; seg_ld counts halves): bf16 kernels only
   // single-layer projection mode: blockIdx.y selects the weight slice / output table.
   // POST mode (node update): after LayerNorm + residual the new rows x' are multiplied, still in registers, by n_post packed
   // [256, 256] slices - the layer-1 products of the NEXT block's edge MLP (P_s = x' Ws^T, P_d = x' Wd^T) - and written to

@@ -780,6 +780,7 @@ void fill_operand(ChainArgs& a, int i, const gw_operand* op) {
   a.seg_ld[i] = op->ld;
   a.seg_k[i] = op->k;
   a.seg_proj[i] = op->projected;
+  a.seg_half[i] = op->layout == GW_LAYOUT_ROWS_F16;
 }
 
 void fill_residual(ChainArgs& a, const gw_operand* op) {
@@ -789,7 +790,12 @@ void fill_residual(ChainArgs& a, const gw_operand* op) {
   a.res_ld = op->ld;
 }
 
-bool bad256(const gw_operand* op) { return op->k != 256 || op->ld % 4 != 0 || !op->ptr; }
+// a 256-wide row table in fp32 rows - or, with allow_half (projected operands of the bf16 node-side kernels), fp16 product rows
+bool bad256(const gw_operand* op, bool allow_half = false) {
+  if (op->k != 256 || op->ld % 4 != 0 || !op->ptr) return true;
+  if (op->layout == GW_LAYOUT_ROWS_F32) return false;
+  return !(allow_half && op->layout == GW_LAYOUT_ROWS_F16 && op->projected);
+}
 
 }  // namespace
 
@@ -928,6 +934,8 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: more than 2^31-1 rows");
   if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out)
     return fail(GW_E_BADARG, "gw_mlp_forward: missing weights / empty operand");
+  if (x->layout != GW_LAYOUT_ROWS_F32 || (residual && residual->layout != GW_LAYOUT_ROWS_F32))
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: operands are fp32 rows");
   if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: at least 2 hidden layers (n_mid >= 1) are required");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -980,6 +988,7 @@ int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: more than 2^31-1 rows");
   if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out) return fail(GW_E_BADARG, "gw_mlp_post_forward: missing weights / empty operand");
+  if (x->layout != GW_LAYOUT_ROWS_F32) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: x is fp32 rows");
   if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: at least 2 hidden layers (n_mid >= 1) are required");
   if (w->weight_dtype != GW_DTYPE_BF16 || w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || (w->ln_width > 0 && w->ln_width != 256))
     return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: bf16 weights, hidden 256, 256 outputs with LayerNorm");
@@ -1043,7 +1052,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   const gw_operand* ops[3] = {x_src, x_dst, e_in};
   for (int i = 0; i < 3; ++i) {
     if (ops[i]->k == 0) continue;
-    if (bad256(ops[i]) || (!ops[i]->projected && !w->w1[i]))
+    if (ops[i]->k != 256 || ops[i]->ld % 4 != 0 || !ops[i]->ptr || (!ops[i]->projected && !w->w1[i]))  // (layouts: checked below)
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: operands must be 256 wide (or k=0 for zeros)");
   }
   // e_res->k == 0: no residual - for callers that want only the aggregate and have added the segment sums of their (batch-
@@ -1052,12 +1061,16 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   if (no_res && (e_out_any != nullptr || save || !gw::edge16_eligible(x_src, x_dst, e_in, w) || (flags & GW_EDGE_DETERMINISTIC)))
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: an edge update without residual (e_res.k == 0) is implemented for the bf16 "
                                   "path with resident weights, without e_out, activation saving or deterministic sums");
-  if (!no_res && bad256(e_res)) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
+  if (!no_res && (e_res->k != 256 || e_res->ld % 4 != 0 || !e_res->ptr))
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
   // edge tiles (bf16) are a format of the bf16 path with resident weights only
   const bool tiles_in = (e_in->k > 0 && e_in->layout == GW_LAYOUT_EDGE_TILES_BF16) || e_res->layout == GW_LAYOUT_EDGE_TILES_BF16;
   const bool tiles_out = e_out_any != nullptr && e_out_layout == GW_LAYOUT_EDGE_TILES_BF16;
   if (e_out_any != nullptr && e_out_layout != GW_LAYOUT_ROWS_F32 && e_out_layout != GW_LAYOUT_EDGE_TILES_BF16)
     return fail(GW_E_BADARG, "gw_edge_update_forward: bad e_out_layout");
+  if ((e_in->k > 0 && e_in->layout != GW_LAYOUT_ROWS_F32 && e_in->layout != GW_LAYOUT_EDGE_TILES_BF16) ||
+      (!no_res && e_res->layout != GW_LAYOUT_ROWS_F32 && e_res->layout != GW_LAYOUT_EDGE_TILES_BF16))
+    return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: edge operands are fp32 rows or bf16 edge tiles");
   const bool half_nodes = x_src->layout == GW_LAYOUT_ROWS_F16 || x_dst->layout == GW_LAYOUT_ROWS_F16;
   if ((x_src->layout != GW_LAYOUT_ROWS_F32 && x_src->layout != GW_LAYOUT_ROWS_F16) ||
       (x_dst->layout != GW_LAYOUT_ROWS_F32 && x_dst->layout != GW_LAYOUT_ROWS_F16) ||
@@ -1126,7 +1139,8 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
     return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: only hidden=256, out=256");
   if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: at least 2 hidden layers (n_mid >= 1) are required");
   if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide (raw)");
-  if (x->k != 0 && (bad256(x) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide or zeros");
+  if (x->k != 0 && (bad256(x, w->weight_dtype == GW_DTYPE_BF16) || (!x->projected && !w->w1[0])))
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide (fp32 rows; fp16 product rows with bf16 weights) or zeros");
   if (x_res && x_res->k != 0 && bad256(x_res)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x_res must be 256 wide");
   if (out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: out_ld must be a multiple of 4");
   ChainArgs a;
@@ -1175,7 +1189,7 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
       (w->ln_width > 0 && w->ln_width != 256))
     return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: node MLP must be 512 -> 256 -> 256 -> 256 with LayerNorm");
   if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: agg must be 256 wide (raw)");
-  if (x->k != 0 && (bad256(x) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: x must be 256 wide or zeros");
+  if (x->k != 0 && (bad256(x, true) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: x must be 256 wide or zeros");
   if (head->hidden != 128 || head->n_mid != 1 || head->n_out > 80 || head->n_out <= 0 || head->ln_gamma || !head->w1[0] || !head->b1 ||
       !head->w_mid || !head->b_mid || !head->w_out || !head->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: the head must be 256 -> 128 -> 128 -> <= 80 features without norm");
@@ -1193,7 +1207,7 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   a.hd_w3 = head->w_out;
   a.hd_b3 = head->b_out;
   if (residual && residual->k != 0) {
-    if (!residual->ptr) return fail(GW_E_BADARG, "gw_node_update_head_forward: null residual");
+    if (!residual->ptr || residual->layout != GW_LAYOUT_ROWS_F32) return fail(GW_E_BADARG, "gw_node_update_head_forward: bad residual");
     fill_residual(a, residual);
   }
   a.out = out;

@@ -930,8 +930,10 @@ class AssimilatorDecoder(nn.Module):
                     hit = self._cache.get("dec_e_sum")
                     if hit is None or hit[0] != key:
                         e_sum = ag.segment_sum_rows(e, n_e, 1, 1, plan.n_dst, plan.dst_ptr(), None)
+                        # (fp16 rows, like every layer-1 product of the bf16 path: the node update adds them to its fp32
+                        # accumulator and rounds the sum to bf16)
                         self._cache["dec_e_sum"] = (key, ops.project_forward([pm_n.w1[1]], Operand(e_sum, plan.n_dst, 256),
-                                                                             plan.n_dst, plan.n_dst)[0])
+                                                                             plan.n_dst, plan.n_dst, out_half=True)[0])
                     x_node = Feed(self._cache["dec_e_sum"][1], 0, "proj")
                     e = None
         res = None

@@ -228,7 +228,9 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
 /* ---- NodeProcessor.forward after aggregation (graph_net_block.py:189-191) -------------------------------
  *   x_new[b, j] = LN(MLP(cat[x[b, j], agg[b, j]])) + x_res[b, j]
  * x may be raw, pre-projected or zeros (k == 0: the decoder's lat/lon rows are zeros, assimilator_decoder.py:84,
- * 190 - the x-slice of layer 1 is skipped); x_res = raw node rows for the residual (NULL or k == 0: none). */
+ * 190 - the x-slice of layer 1 is skipped); x_res = raw node rows for the residual (NULL or k == 0: none).  With bf16
+ * weights a pre-projected x may be fp16 product rows (GW_LAYOUT_ROWS_F16, ld in halves); every other operand of the row-wise
+ * entry points is fp32 rows - any other layout is rejected. */
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
                            const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
                            const struct gw_activation_save* save /* may be NULL */,

@@ -310,3 +310,37 @@ def test_chain_backward_kernel_against_torch(rows):
                 assert (got.double() - ref).abs().max().item() <= 2e-5 * scale
     with pytest.raises(RuntimeError):
         ag.chain_backward(d, [], [])
+
+
+def test_node_update_takes_fp16_projected_rows_and_other_layouts_are_rejected():
+    """bf16 node update (+ head): a projected x operand as fp16 rows gives the result of the same values as fp32 rows; layouts an
+    entry point does not read are refused instead of being misread as fp32 (fp16 rows with fp32 weights, as a raw operand, as agg)."""
+    import numpy as np
+    from graph_weather_amd import ops
+    from graph_weather_amd.ops import Operand, PackedMLP
+
+    rs = np.random.RandomState(11)
+    def mk(dims, norm):
+        ws = [torch.from_numpy((rs.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)).to(DEV) for i in range(3)]
+        bs = [torch.from_numpy((0.1 * rs.standard_normal(dims[i + 1])).astype(np.float32)).to(DEV) for i in range(3)]
+        ln = (torch.ones(dims[3], device=DEV), torch.zeros(dims[3], device=DEV)) if norm else None
+        return ws, bs, ln
+    node, head = mk([512, 256, 256, 256], True), mk([256, 128, 128, 78], False)
+    rows, B = 300, 2
+    n = rows * B
+    xp = torch.from_numpy(rs.standard_normal((rows, 256)).astype(np.float32)).to(DEV).half()  # (values exactly representable in fp16)
+    agg = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    for dt in (torch.bfloat16,):
+        pm = PackedMLP(node[0], node[1], node[2], ((0, 256), (256, 512)), dt)
+        hd = PackedMLP(head[0], head[1], None, ((0, 256),), dt)
+        a = ops.node_update_forward(pm, n, rows, Operand(xp.float(), 0, 256, projected=True), ops.ZERO, Operand(agg, rows, 256))
+        b = ops.node_update_forward(pm, n, rows, Operand(xp, 0, 256, projected=True), ops.ZERO, Operand(agg, rows, 256))
+        c = ops.node_update_head_forward(pm, hd, n, rows, Operand(xp.float(), 0, 256, projected=True), Operand(agg, rows, 256), None)
+        d = ops.node_update_head_forward(pm, hd, n, rows, Operand(xp, 0, 256, projected=True), Operand(agg, rows, 256), None)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(c, d)
+    pm32 = PackedMLP(node[0], node[1], node[2], ((0, 256), (256, 512)), torch.float32)
+    with pytest.raises(RuntimeError):
+        ops.node_update_forward(pm32, n, rows, Operand(xp, 0, 256, projected=True), ops.ZERO, Operand(agg, rows, 256))
+    with pytest.raises(RuntimeError):  # fp16 rows are a format of projected operands
+        ops.node_update_forward(pm, n, rows, Operand(xp, 0, 256), ops.ZERO, Operand(agg, rows, 256))
