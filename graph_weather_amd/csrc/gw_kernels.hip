@@ -201,6 +201,8 @@ __device__ __forceinline__ void add_projected(f32x4 (&acc)[NT], const float* __r
 // in[s] <- row[k(s,q)], k(s,q) = 16*(s>>2) + 4*q + (s&3)
 template <int KSTEPS, bool FULL>
 __device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* __restrict__ row, int kvalid, int q) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool pairs = !FULL && (kvalid & 1) == 0 && ((size_t)row & 7) == 0;
 #pragma unroll
   for (int i = 0; i < KSTEPS / 4; ++i) {
     if (FULL) {
@@ -209,6 +211,15 @@ __device__ __forceinline__ void load_operand(float (&in)[KSTEPS], const float* _
       in[4 * i + 1] = v.y;
       in[4 * i + 2] = v.z;
       in[4 * i + 3] = v.w;
+    } else if (pairs) {
+      // rows of an even number of floats at an 8-byte aligned base (102 input features: 408-byte rows): 8-byte loads
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const int k = 16 * i + 4 * q + r;
+        const f32x2 v = (k < kvalid) ? *(const GW_AS1 f32x2*)(row + k) : f32x2{0.f, 0.f};
+        in[4 * i + r] = v.x;
+        in[4 * i + r + 1] = v.y;
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -439,12 +450,24 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   if (!SINGLE && a.res_ptr != nullptr) {
     if (EPI == EPI_DEC) {
       const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const bool pairs = (a.out_cols & 1) == 0 && ((size_t)rrow & 7) == 0;  // (78 of the 102 features of a 408-byte row)
 #pragma unroll
       for (int t = 0; t < OT; ++t) {
         const int f0 = 16 * t + 4 * q;
+        if (pairs) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (f0 + r < a.out_cols) o[t][r] += ldg1(rrow + f0 + r);
+          for (int r = 0; r < 4; r += 2)
+            if (f0 + r < a.out_cols) {
+              const f32x2 v = *(const GW_AS1 f32x2*)(rrow + f0 + r);
+              o[t][r] += v.x;
+              o[t][r + 1] += v.y;
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) o[t][r] += ldg1(rrow + f0 + r);
+        }
       }
     } else {
 #pragma unroll
@@ -460,9 +483,16 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
     for (int t = 0; t < OT; ++t) {
       const int f0 = 16 * t + 4 * q;
       if (EPI == EPI_DEC) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        if ((a.out_cols & 1) == 0 && ((size_t)orow & 7) == 0) {  // 78-float rows: 8-byte stores
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[t][r]);
+          for (int r = 0; r < 4; r += 2)
+            if (f0 + r < a.out_cols) *(GW_AS1 f32x2*)(orow + f0 + r) = f32x2{o[t][r], o[t][r + 1]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[t][r]);
+        }
       } else {
         stg4(orow + f0, o[t]);
       }
