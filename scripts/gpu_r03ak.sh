@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, call ak: uneven split of the segment sums between the teams
+OUT=gpurun_out/r03ak; mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+rm -rf /tmp/prof && mkdir -p /tmp/prof
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $GRAFT_REPO_ROOT/bench.py --config c3 --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $GRAFT_REPO_ROOT/$OUT/rocprof_c3.log 2>&1)
+find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $OUT/c3_kernel_stats.csv \; 2>/dev/null
+grep "edge16" $OUT/c3_kernel_stats.csv | cut -c1-170
+timeout 300 python bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra 2>&1 | tail -n 1 | cut -c1-330
+timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -p no:cacheprovider -k "guards or c3 or bf16 or round3 or edge16" 2>&1 | tail -n 3
