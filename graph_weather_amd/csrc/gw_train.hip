@@ -656,7 +656,11 @@ int gw_relu_backward(int64_t rows, int32_t width, const float* dh, int32_t ld_dh
   if (!dh || rows < 0 || width <= 0) return fail(GW_E_BADARG, "gw_relu_backward: bad arguments");
   if (rows == 0) return GW_OK;
   if (width > 256) return relu_mask_wide_launch(rows, width, dh, ld_dh, h, ld_h, dz, ld_dz, db, stream);  // wide models (gw_wide.hip)
-  const int strip = 256;  // few blocks per column: the bias-gradient atomics of all blocks hit the same 256 addresses
+  // few blocks per column - the bias-gradient atomics of all blocks hit the same 256 addresses - but enough of them to fill the
+  // chip: mesh-sized inputs (11 764 rows at 1 degree, batch 2) ran on 46 blocks with a fixed strip of 256 rows
+  int strip = (int)((rows + 1023) / 1024);
+  strip = (strip + 15) / 16 * 16;
+  if (strip > 256) strip = 256;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((rows + strip - 1) / strip)), dim3(256), 0, (hipStream_t)stream, rows, width,
                      dh, ld_dh, h, ld_h, dz, ld_dz, db, strip);
   return check_launch("relu_bwd_kernel launch");
@@ -668,7 +672,11 @@ int gw_layernorm_backward(int64_t rows, int32_t width, const float* dn, int32_t 
     return fail(GW_E_BADARG, "gw_layernorm_backward: bad arguments");
   if (rows == 0) return GW_OK;
   if (width > 256) return ln_bwd_wide_launch(rows, width, dn, ld_dn, y, ld_y, gamma, dy, ld_dy, dgamma, dbeta, stream);
-  const int strip = 512;
+  // rows per block: 512 for large inputs (one set of dgamma / dbeta atomics per block), down to 16 so that mesh-sized inputs
+  // still spread over ~1 000 blocks (they ran on 23 blocks - 87 us for 36 MB - with the fixed strip)
+  int strip = (int)((rows + 1023) / 1024);
+  strip = (strip + 15) / 16 * 16;
+  if (strip > 512) strip = 512;
   const dim3 grid((unsigned)((rows + strip - 1) / strip));
   if (width == 256 && (ld_dn | ld_y | ld_dy) % 4 == 0) {
     hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, dn, ld_dn, y, ld_y, gamma, dy, ld_dy, dgamma,
