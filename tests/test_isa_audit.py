@@ -175,3 +175,40 @@ def test_wide_kernels_have_no_scratch_and_the_gemm_keeps_three_waves_per_simd(tm
     for family, count in (("ln_fwd_wide_kernel", 4), ("ln_bwd_wide_kernel", 4), ("gather_sum_kernel", 1), ("segment_sum_wide_kernel", 1),
                           ("gather_wide_kernel", 1), ("relu_mask_wide_kernel", 1), ("add_rows_kernel", 1)):
         assert sum(family in k for k in seen) == count, (family, list(seen))
+
+
+@pytest.mark.timeout(600)
+def test_row_wise_kernels_keep_the_register_budget_of_two_workgroups_per_cu(tmp_path):
+    """The 64-column forms of the bf16 row-wise kernel (csrc/gw_bf16.hip: 4 waves x 1 group; node update, + post products, + head,
+    node encoder + post products) owe their speed to TWO workgroups per CU - one's row traffic under the other's MFMA phases -
+    which holds only while a wave needs <= 256 registers and nothing spills; same for the fp32 chain kernels (two 64-column
+    workgroups per CU by design) and the register-resident backward chain of round 3 (csrc/gw_kernels.hip)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+
+    def kernels(fname):
+        src = os.path.join(ROOT, "graph_weather_amd", "csrc", fname)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "k.o", "-save-temps"]
+        subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+        text = (tmp_path / (fname[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read_text()
+        out = {}
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+            meta = m.group(2)
+            out[m.group(1)] = (int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)),
+                               int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)))
+        return out
+
+    k16 = kernels("gw_bf16.hip")
+    four_by_one = {n: v for n, v in k16.items() if "chain16_kernel" in n and n.endswith("ELi4ELi1EEEvN2gw9ChainArgsE")}
+    assert len(four_by_one) == 4, sorted(four_by_one)  # node update | + post products | + head | mlp + post products
+    for name, (vgpr, scratch) in four_by_one.items():
+        assert vgpr <= 256 and scratch == 0, (name, vgpr, scratch)
+    k32 = kernels("gw_kernels.hip")
+    bwd = [v for n, v in k32.items() if "bwd_chain_kernel" in n]
+    assert len(bwd) == 1 and bwd[0][0] <= 256 and bwd[0][1] == 0, bwd
+    chains = {n: v for n, v in k32.items() if "chain_kernel" in n and "bwd" not in n}
+    assert len(chains) >= 8
+    for name, (vgpr, scratch) in chains.items():
+        # (the general 3-operand edge form parks 28 bytes of loop invariants: bounded, it is not on the forecaster's path)
+        assert vgpr <= 256 and scratch <= 32, (name, vgpr, scratch)
