@@ -1,0 +1,8 @@
+#!/bin/bash
+OUT=gpurun_out/r03an; mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+rm -rf /tmp/prof && mkdir -p /tmp/prof
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $GRAFT_REPO_ROOT/bench.py --config c3 --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $GRAFT_REPO_ROOT/$OUT/rocprof_c3.log 2>&1)
+find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $OUT/c3_kernel_stats.csv \; 2>/dev/null
+grep "edge16" $OUT/c3_kernel_stats.csv | cut -c1-150
+timeout 600 python -m pytest tests -m gpu -q -x --timeout 600 -p no:cacheprovider -k "guards or c3 or bf16 or edge16" 2>&1 | tail -n 2
