@@ -467,6 +467,59 @@ def run_train_extra(dev, steps=5, warmup=2):
     return out
 
 
+def _rank_entry(rank, world, port, argv, backend, device, model_factory, train_factories):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    main(argv, backend=backend, device=device, model_factory=model_factory, train_factories=train_factories)
+
+
+def self_launch(args, argv, backend, device, model_factory, train_factories) -> None:
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): build the graphs ONCE here, then fork N ranks
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would) that each run main() - one
+    process per GPU over RCCL, rank 0 prints the one JSON line on the inherited stdout.  The fork happens before this process
+    has touched the HIP runtime, so every child creates its own context on its own device; the children find the index arrays
+    of the three graphs in the forked memory (graphs.build_forecast_graphs keeps the last builds) instead of rebuilding them
+    per rank.  Exits non-zero if any rank fails (the others are terminated: a dead peer would leave them in a collective)."""
+    import multiprocessing as mp
+    import socket
+
+    from graph_weather_amd.graphs import build_forecast_graphs
+    from graph_weather_amd.utils import regular_lat_lons
+
+    cfg = dict(CONFIGS[args.config])
+    if args.grid is not None:
+        cfg["grid"] = args.grid
+    if model_factory is None:
+        build_forecast_graphs(regular_lat_lons(cfg["grid"]), cfg["resolution"])  # memoised: the ranks inherit it
+    else:
+        model_factory(cfg, "cpu")  # a stand-in factory builds (and thereby memoises) whatever graphs it uses
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    sys.stdout.flush()
+    ctx = mp.get_context("fork")
+    raw = list(sys.argv[1:] if argv is None else argv)
+    procs = [ctx.Process(target=_rank_entry, args=(r, args.gpus, port, raw, backend, device, model_factory, train_factories))
+             for r in range(args.gpus)]
+    for p in procs:
+        p.start()
+    failed = None
+    alive = set(range(len(procs)))
+    while alive and failed is None:
+        for r in sorted(alive):
+            procs[r].join(timeout=0.2)
+            if procs[r].exitcode is not None:
+                alive.discard(r)
+                if procs[r].exitcode != 0:
+                    failed = (r, procs[r].exitcode)
+                    break
+    if failed is not None:
+        for r in alive:
+            procs[r].terminate()  # (exact children of this process)
+        for p in procs:
+            p.join(timeout=10)
+        raise SystemExit("bench.py: rank %d of %d exited with code %s" % (failed[0], args.gpus, failed[1]))
+
+
 def main(argv=None, backend="nccl", device=None, model_factory=None, train_factories=None):
     """``backend`` / ``device`` / ``model_factory`` / ``train_factories`` exist for the world-2 gloo tests (tests/test_sharding.py),
     which drive this very function on CPU with a stand-in model: rank / launch / barrier / max-over-ranks / JSON path (and,
@@ -491,11 +544,14 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
 
     from graph_weather_amd import sharding as sh
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (see self_launch)
+        return self_launch(args, argv, backend, device, model_factory, train_factories)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started inside a launcher with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     on_gpu = device is None
     if on_gpu:
         torch.cuda.set_device(local_rank)
@@ -609,5 +665,22 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
         dist.destroy_process_group()
 
 
+def _cli():
+    """Entry of `python bench.py ...`.  GW_BENCH_BACKEND / GW_BENCH_DEVICE / GW_BENCH_FACTORY ("module:function") select the
+    process-group backend, a non-GPU device and a stand-in model factory: the hooks tests/test_sharding.py uses to run this
+    very command line (self-launch included) on CPU over gloo."""
+    kw = {}
+    if os.environ.get("GW_BENCH_BACKEND"):
+        kw["backend"] = os.environ["GW_BENCH_BACKEND"]
+    if os.environ.get("GW_BENCH_DEVICE"):
+        kw["device"] = os.environ["GW_BENCH_DEVICE"]
+    if os.environ.get("GW_BENCH_FACTORY"):
+        import importlib
+
+        mod, fn = os.environ["GW_BENCH_FACTORY"].split(":")
+        kw["model_factory"] = getattr(importlib.import_module(mod), fn)
+    main(**kw)
+
+
 if __name__ == "__main__":
-    main()
+    _cli()

@@ -217,8 +217,28 @@ def check_topology(module, expected_hash: str, strict: bool = False) -> bool:
     return False
 
 
+_BUILT: list = []  # the last few (key, ForecastGraphs): see build_forecast_graphs
+
+
 def build_forecast_graphs(lat_lons, resolution: int = 2, provider=None) -> ForecastGraphs:
+    """The three graphs of a forecaster.  The last two builds of the process are kept (keyed by a digest of the coordinates,
+    the resolution and the provider; the index arrays are read-only by convention): models built again on the same grid - the
+    bench's configurations, ranks forked by ``bench.py --gpus N`` after the launcher built them - share one set."""
+    import hashlib
+
     provider = provider if provider is not None else _mesh.get_provider()
+    ll = np.ascontiguousarray(np.asarray(lat_lons, dtype=np.float64).reshape(-1, 2))
+    key = (hashlib.sha256(ll.tobytes()).hexdigest(), int(resolution), id(provider) if not isinstance(provider, _mesh.H3Like) else "builtin")
+    for k, g in _BUILT:
+        if k == key:
+            return g
+    g = _build_forecast_graphs(lat_lons, resolution, provider)
+    _BUILT.append((key, g))
+    del _BUILT[:-2]
+    return g
+
+
+def _build_forecast_graphs(lat_lons, resolution: int, provider) -> ForecastGraphs:
     if isinstance(provider, _mesh.H3Like):
         parts = _build_vectorised(lat_lons, resolution)
     else:  # pragma: no cover

@@ -671,7 +671,7 @@ class Encoder(nn.Module):
             return wide.encode(self, features)
         feats = features.contiguous().reshape(B * G, F)
         enc_plan, _ = self._plans(features.device)
-        team = self.team_path()
+        team = self.team_path(features)
         ne = self.node_encoder
         fused_ps = None
         if team and ne.compute_dtype == torch.bfloat16 and not ne._layout()[4] and 32 < ne.native_k() <= 128:
@@ -711,11 +711,13 @@ class Encoder(nn.Module):
                        Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge")
         return x
 
-    def team_path(self) -> bool:
-        """Inference in bf16 with everything the team-pipelined edge kernel needs (see ``AssimilatorDecoder.team_path``)."""
+    def team_path(self, features: Optional[torch.Tensor] = None) -> bool:
+        """Inference in bf16 with everything the team-pipelined edge kernel needs (see ``AssimilatorDecoder.team_path``).
+        ``features``: the call's input - an input that requires grad keeps the call on the differentiable path (which raises
+        for bf16: no silent drop of d/d(features) through the non-differentiable fused launches)."""
         blk = self.graph_processor.blocks[0]
         mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
-        if wide.encoder_is_wide(self) or _autograd_on(self) or blk.deterministic:
+        if wide.encoder_is_wide(self) or _autograd_on(self, features) or blk.deterministic:
             return False
         if mlp_e.compute_dtype != torch.bfloat16 or mlp_n.compute_dtype != torch.bfloat16:
             return False

@@ -52,6 +52,10 @@ class AdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         state_dict = dict(state_dict)
         fs = state_dict.pop("gw_flat_state", None)
+        if fs is not None and self.flat is None:
+            # the flat moments / step cannot be dropped silently: a per-parameter AdamW would restart them from zero
+            raise ValueError("graph_weather_amd.AdamW: state_dict carries 'gw_flat_state' (saved from an optimizer built with "
+                             "flat=...); build this optimizer with flat= as well to resume it")
         super().load_state_dict(state_dict)
         if self.flat is not None:
             if fs is None:

@@ -176,6 +176,10 @@ class FlatGradients:
         def hook(param):
             if not self._sync:  # accumulation step (no_sync): the gradient stays local
                 return
+            if self._ctx is None or self._ctx.world <= 1:
+                # one process (or not attached): nothing is launched from the hooks, so there is no in-flight collective a
+                # second backward could corrupt - local accumulation and zero_grad(set_to_none=False) loops just work
+                return
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] < 0:
@@ -184,7 +188,7 @@ class FlatGradients:
                 raise RuntimeError("graph_weather_amd.FlatGradients: a parameter received a second gradient in one step - run "
                                    "every backward() but the last under flat.no_sync() (gradient accumulation), and call "
                                    "flat.allreduce() / flat.zero_() between steps")
-            if self._pending[b] == 0 and self._handles[b] is None and self._ctx is not None and self._ctx.world > 1:
+            if self._pending[b] == 0 and self._handles[b] is None:
                 self._launch(b)
         return hook
 
@@ -235,6 +239,7 @@ class FlatGradients:
         """Average the gradients over the ranks: launch the buckets the backward has not already launched, wait for all of
         them, scale by 1 / world (one kernel over the flat buffer).  Returns the number of collectives of this step."""
         if ctx.world == 1:
+            self._rearm()  # (nothing was counted or launched; keeps the per-step state well defined all the same)
             return 0
         self._ctx = ctx
         n = 0

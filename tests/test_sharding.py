@@ -305,3 +305,71 @@ def test_flat_gradient_buckets_overlap_world_two_gloo(tmp_path):
     world = 2
     mp.spawn(_flat_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"flat{r}").exists() for r in range(world))
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_from_a_clean_environment(tmp_path):
+    """`python bench.py --gpus 2 ...` as the driver would type it on an 8-GPU node - NO launcher, no RANK / WORLD_SIZE in the
+    environment: bench.py forks its own ranks (bench.self_launch), rank 0 prints the one JSON line, the exit code is 0.  Runs the
+    real command line in a subprocess; the GW_BENCH_* hooks put it on gloo / CPU with the stand-in model."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(GW_BENCH_BACKEND="gloo", GW_BENCH_DEVICE="cpu", GW_BENCH_FACTORY="tests.test_sharding:_stub_factory",
+               PYTHONPATH=root + os.pathsep + env.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 4  # c2: batch 2 on each of the two ranks
+    # a failing rank makes the launcher exit non-zero (bad factory -> every rank raises)
+    env["GW_BENCH_FACTORY"] = "tests.test_sharding:_failing_factory"
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+
+
+_FAIL_CALLS = {"n": 0}
+
+
+def _failing_factory(cfg, dev):
+    """Works in the launcher (which builds the graphs once through it), raises in the ranks."""
+    if "WORLD_SIZE" in os.environ:
+        raise RuntimeError("rank failure injected by the test")
+    return _stub_factory(cfg, dev)
+
+
+def test_forecast_graphs_are_built_once_per_grid():
+    from graph_weather_amd.graphs import build_forecast_graphs
+    from graph_weather_amd.utils import regular_lat_lons
+
+    ll = regular_lat_lons(30.0)
+    a, b = build_forecast_graphs(ll, 2), build_forecast_graphs(list(ll), 2)
+    assert a is b
+    assert build_forecast_graphs(regular_lat_lons(20.0), 2) is not a
+
+
+def test_flat_gradients_world_one_second_step_with_zero_grad_in_place():
+    """a single-process FlatGradients whose gradients are zeroed with optimizer.zero_grad(set_to_none=False) (not
+    flat.zero_()) must train for more than one step, attached to a world-1 context or not; local accumulation likewise."""
+    for attach in (False, True):
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(4, 3)
+        flat = sharding.FlatGradients(lin.parameters(), bucket_bytes=16)
+        ctx = sharding.ShardContext(0, 0, 1, None)
+        if attach:
+            flat.attach(ctx)
+        opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+        for step in range(3):
+            opt.zero_grad(set_to_none=False)
+            lin(torch.randn(5, 4)).square().mean().backward()
+            lin(torch.randn(5, 4)).square().mean().backward()  # accumulation without no_sync(): fine with one rank
+            assert flat.allreduce(ctx) == 0
+            opt.step()
+        assert flat.views_intact()
