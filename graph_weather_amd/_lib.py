@@ -15,10 +15,10 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 DTYPE_F32, DTYPE_BF16 = 0, 1
-LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16 = 0, 1, 2
-EDGE_DETERMINISTIC = 1
+LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16, LAYOUT_ROWS_BF16K = 0, 1, 2, 3
+EDGE_DETERMINISTIC, EDGE_SEGMENT_TILES, EDGE_AGG_BF16K = 1, 2, 4
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",

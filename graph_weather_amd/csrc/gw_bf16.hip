@@ -272,8 +272,16 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kerne
       if (on[i]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
-          load_raw16<K1S, K1FULL, (NG == 1 ? 8 : 4)>(reinterpret_cast<bf16x8(&)[K1S]>(bin[g]), row, a.seg_k[i], q);
+          if (K1S == 8 && a.seg_bf16k[i]) {
+            // bf16 rows in K order (GW_LAYOUT_ROWS_BF16K: the aggregate written by the segment-aligned edge kernel): position
+            // 32 s + 8 q + i holds feature k(s, q, i) - the lane's B fragment of K-step s is one 16-byte load, no conversion
+            const __bf16* rowb = (const __bf16*)a.seg_ptr[i] + ((size_t)bb[g] * (size_t)a.seg_rows_pb[i] + (size_t)kk[g]) * (size_t)a.seg_ld[i];
+#pragma unroll
+            for (int s = 0; s < (K1S == 8 ? 8 : 0); ++s) bin[g][s] = *(const GW_AS1 bf16x8*)(rowb + 32 * s + 8 * q);
+          } else {
+            const float* row = operand_row16(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+            load_raw16<K1S, K1FULL, (NG == 1 ? 8 : 4)>(reinterpret_cast<bf16x8(&)[K1S]>(bin[g]), row, a.seg_k[i], q);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         const char* nx = after_l1;

@@ -703,9 +703,12 @@ int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int3
 
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, bool deterministic, void* stream) {
+                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, int32_t flags, void* stream) {
+  const bool deterministic = (flags & GW_EDGE_DETERMINISTIC) != 0;
   Edge16Args a;
   memset(&a, 0, sizeof(a));
+  a.seg_tiles = (flags & GW_EDGE_SEGMENT_TILES) != 0;
+  a.agg_bf16k = (flags & GW_EDGE_AGG_BF16K) != 0;
   a.batch = batch;
   a.n_edges = n_edges;
   a.n_dst = n_dst;
@@ -764,6 +767,27 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   }
   static const int n_wg = (GW_TUNE("GW_EDGE16_WGS", 256) + 7) / 8 * 8;  // persistent workgroups: one per CU, a multiple of 8 (XCD round-robin)
   const bool fuse_gather = fuse_gather_on();
+  static const int nw = GW_TUNE("GW_EDGE16_NW", 8);
+  static const int team = GW_TUNE("GW_EDGE16_TEAM", 1);
+  // what only the team-pipelined kernel takes - checked before anything is enqueued (launch 1 below writes the workspace)
+  bool any_half = false;
+  for (int p = 0; p < a.n_proj; ++p) any_half = any_half || a.p_half[p];
+  const bool team_only = nw == 4 || deterministic || team == 0;
+  // fp16 product rows are read by the layer-1 kernel (raw edge operand) and by the team kernel's gather - not by the lock-step
+  // kernels' gather
+  if (any_half && !raw_e && (team_only || !fuse_gather))
+    return set_error(GW_E_UNSUPPORTED, "edge16: fp16 product rows with all operands projected need the team-pipelined kernel (atomics mode)");
+  if (no_res && team_only)
+    return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual runs on the team-pipelined kernel only (atomics mode)");
+  if (a.seg_tiles && (team_only || raw_e || !fuse_gather || !no_res))
+    return set_error(GW_E_UNSUPPORTED, "edge16: segment-aligned tiles run on the team-pipelined kernel (gathered layer 1, no residual)");
+  if (no_res || (any_half && !raw_e) || a.seg_tiles) {
+    int n_dyn = 0;
+    for (int p = 0; p < a.n_proj; ++p) n_dyn += a.p_rows_pb[p] != 0 ? 1 : 0;
+    if (n_dyn != 1)
+      return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual / with fp16 product rows / on segment-aligned tiles "
+                                         "needs exactly one per-sample projected table");
+  }
   // launch 1: layer 1 -> workspace tiles
   if (raw_e) {
     static DeviceOnce once_l1;
@@ -775,19 +799,9 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
   }
   // launch 2: the resident layers
-  static const int nw = GW_TUNE("GW_EDGE16_NW", 8);
   const bool rt = a.res_tiles != nullptr;
   const bool ga = !raw_e && fuse_gather;  // layer 1 gathered inside the resident kernel
-  static const int team = GW_TUNE("GW_EDGE16_TEAM", 1);
-  bool any_half = false;
-  for (int p = 0; p < a.n_proj; ++p) any_half = any_half || a.p_half[p];
-  // fp16 product rows are read by the layer-1 kernel (raw edge operand) and by the team kernel's gather - not by the lock-step
-  // kernels' gather
-  if (any_half && !raw_e && (nw == 4 || deterministic || team == 0 || !fuse_gather))
-    return set_error(GW_E_UNSUPPORTED, "edge16: fp16 product rows with all operands projected need the team-pipelined kernel (atomics mode)");
   int rc;
-  if (no_res && (nw == 4 || deterministic || team == 0))
-    return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual runs on the team-pipelined kernel only (atomics mode)");
   if (nw == 4 || deterministic) {  // the deterministic walk is a whole-tile walk per thread: the 4-wave form
     if (ga) rc = rt ? launch_resident(edge16_kernel<4, true, true>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, true>, 256, n_wg, a, stream);
     else rc = rt ? launch_resident(edge16_kernel<4, true, false>, 256, n_wg, a, stream) : launch_resident(edge16_kernel<4, false, false>, 256, n_wg, a, stream);
@@ -811,8 +825,6 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
       return edge16t_launch(&a, ga, n_wg, stream);
     }
   }
-  if (no_res) return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual needs exactly one per-sample projected table");
-  if (any_half && !raw_e) return set_error(GW_E_UNSUPPORTED, "edge16: fp16 product rows need exactly one per-sample projected table here");
   if (ga) return rt ? launch_resident(edge16_kernel<8, true, true>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, true>, 512, n_wg, a, stream);
   return rt ? launch_resident(edge16_kernel<8, true, false>, 512, n_wg, a, stream) : launch_resident(edge16_kernel<8, false, false>, 512, n_wg, a, stream);
 }

@@ -61,6 +61,9 @@ struct Edge16Args {
   float* agg;
   float* carry;  // deterministic segment sums: per-tile carry records (gw_internal.hpp), NULL = atomics; 4-wave kernel only
   char* h1g;  // workspace: layer-1 activations, [batch * neb tiles][4 groups][8 K-steps][64 lanes][8 bf16]
+  int seg_tiles;            // GW_EDGE_SEGMENT_TILES: src / dst are the padded arrays of segment-aligned tiles (dst < 0 = padding
+                            // column, no destination run crosses a multiple of 64): team kernel with the transposed output layer
+  int agg_bf16k;            // ... and agg is bf16 rows in MFMA K order (GW_LAYOUT_ROWS_BF16K) instead of fp32 rows
   int bc, nchunk;           // team kernel (gw_edge16t.hip): batch elements of one edge block a workgroup handles in a row (divides
                             // batch) and chunks per edge block (batch / bc): per-edge data shared by the batch is fetched once per chunk
   int tune;                 // tuning builds only (GW_EDGE16_TUNE): A/B switches of the team kernel
@@ -112,6 +115,26 @@ __device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* __restri
 // at the end), as in the round-1 kernel.
 __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+}
+// The transposed product: the activations fragment is the A operand (rows = the 16 edges of a group), the resident weight
+// fragment the B operand (columns = 16 output features) - the same registers, the operands swapped - so the accumulator comes
+// out as lane (feature, q) x 4 edges: D^T.  Used where the next contraction is over EDGES (segment sums on the matrix cores).
+__device__ __forceinline__ void mfma_t(f32x4& acc, const bf16x8& b, const bf16x8& w) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(b), "a"(w));
+}
+// x of the lane n places further round this lane's row of 16 (DPP row_ror: no LDS, no extra instruction once fused into the add)
+// x + (x of the lane N places further round this lane's row of 16): one VALU instruction with a DPP operand (no LDS; written as
+// asm because the builtin comes out as v_mov_b32_dpp into a zeroed register + the add).  A DPP operand must not have been written
+// by one of the two preceding VALU instructions (asm is opaque to the hazard recogniser): callers keep producer and use apart.
+template <int N>
+__device__ __forceinline__ float add_row_ror(float x) {
+  float y;
+  // (the first step reads sums the compiler's own VALU code produced - it may schedule that producer right in front: two wait states)
+  if constexpr (N == 8) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+  else if constexpr (N == 4) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+  else if constexpr (N == 2) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+  else asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+  return y;
 }
 __device__ __forceinline__ void layer_group(f32x4 (&acc)[4], const bf16x8 (&w)[4][8], const bf16x8 (&bf)[8]) {
   asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));

@@ -50,6 +50,14 @@ constexpr int kT_Par = kT_Ln + 4 * kTileCols * 8;           // b_mid, b_out, gam
 constexpr int kT_Zc = kT_Par + 5 * 256 * 4;                 // GATHER: cached batch-shared layer-1 part of column pass 1 (fp16), thread private
 constexpr int kT_Total = kT_Zc + 8 * 256 * 8;
 static_assert(kT_Total <= 160 * 1024, "LDS budget of one CU");
+// Segment-aligned form (SEGT): no staged tile - the area holds the slot tables of the 4 tiles in flight and small exchange buffers
+constexpr int kS_Dsl = kT_Stage;             // int[4][64]: destination row (global) of each destination slot of a tile
+constexpr int kS_Slot = kS_Dsl + 1024;       // uint8[4][64]: destination slot of each column (255 = padding column)
+constexpr int kS_Nsl = kS_Slot + 256;        // int[4]: number of destination slots of the tile
+constexpr int kS_Lnc = kT_Stage + 2048;      // float2[4 team-B waves][64 edges]: (rstd, -mean rstd), private to the wave
+constexpr int kS_ParT = kT_Stage + 4096;     // float4[4 waves][16 lanes][4 t]: b_out of a lane's feature of tile t, replicated x 4
+constexpr int kS_ParP = kT_Stage + 8192;     // float[2][256]: gamma, beta in the POSITION order of a destination row
+constexpr int kS_Cnt = kT_Stage + 10240;     // float[4][64]: edges of each destination slot
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
@@ -82,10 +90,14 @@ __device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (fmaxf adds 
 //  * slots 28..31: the bias of group g + 1 into its accumulator set (LDS reads straight into the accumulators).
 // Two accumulator sets alternate (a caller that keeps all groups passes 4).  The pieces of the last group run at the end.
 // bias(dst, t): accumulator of row tile t <- bias;  piece(g, m, acc): m = 0 .. 27.
-template <int NSETS, class Bias, class Piece>
+template <int NSETS, bool TR = false, class Bias, class Piece>
 __device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 (&w)[4][8], const char* __restrict__ hin, int lane,
                                            Bias bias, Piece piece) {
-  bf16x8 fr[2][4];
+  // TR: ONE ring of 4 fragment registers instead of two alternating sets - the fragment of K-step ks is requested again (for
+  // the next half-group) right behind the 4th MFMA that reads it (issued in order, its operands are read long before the LDS data
+  // returns) and is needed 13 MFMAs later; the transposed layer's filler state (8 running sums) takes the 16 registers
+  constexpr int NFR = TR ? 1 : 2;
+  bf16x8 fr[NFR][4];
   const char* const p0 = hin + fresh(lane) * 16;
 #pragma unroll
   for (int s = 0; s < 4; ++s) fr[0][s] = *(const bf16x8*)(p0 + s * 1024);
@@ -99,9 +111,14 @@ __device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 
 #pragma unroll
     for (int m16 = 0; m16 < 16; ++m16) {
       const int ks = m16 >> 2, t = m16 & 3, slot = 16 * hh + m16;
-      mfma_a(ac[t], w[t][4 * hh + ks], fr[h & 1][ks]);
-      if (m16 < 4 && h + 1 < 8)
-        fr[(h + 1) & 1][m16] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + m16 * 1024);
+      if constexpr (TR) {
+        mfma_t(ac[t], fr[0][ks], w[t][4 * hh + ks]);  // (the transposed product, see mfma_t)
+        if (t == 3 && h + 1 < 8) fr[0][ks] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + ks * 1024);
+      } else {
+        mfma_a(ac[t], w[t][4 * hh + ks], fr[h & 1][ks]);
+        if (m16 < 4 && h + 1 < 8)
+          fr[(h + 1) & 1][m16] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + m16 * 1024);
+      }
       if (g > 0 && slot >= 2 && slot < 30) piece(g - 1, slot - 2, acc[(g - 1) % NSETS]);
       if (slot >= 28 && g + 1 < 4) bias(acc[(g + 1) % NSETS][slot - 28], slot - 28);
       __builtin_amdgcn_sched_barrier(0);
@@ -124,8 +141,17 @@ struct TileId {
 // RES: the residual e of graph_net_block.py:135 is added from bf16 edge tiles (true), or not at all (false: callers that only
 // want the aggregate - the decoder - add the segment sums of their batch-shared e into the aggregate buffer beforehand:
 // sum(LN(.) + e) = sum(LN(.)) + sum(e), and sum(e) per destination is the same for every batch element).
-template <bool GATHER, bool PH, bool RES>
+// SEGT (GW_EDGE_SEGMENT_TILES; GATHER, no residual): the caller's edge list is padded so that no destination's run of edges
+// crosses a tile (dst < 0 marks padding columns; the decoder graph has 7 or 6 edges per grid node: 9 nodes = 63 columns per
+// tile).  Team B then runs its output layer TRANSPOSED (mfma_t: accumulators = lane (feature, q) x 4 edges), applies LayerNorm
+// in that layout (row sums over the 16 feature lanes on DPP rotations, parameters one float4 per lane) and computes the segment
+// sums as one more matrix product - y^T (bf16) . S, S[edge][slot] = 1 where the edge belongs to the tile's destination slot -
+// whose result, lane (slot, q) x 16 consecutive features, is stored straight to the destination rows: no staged tile in LDS, no
+// per-column walk, no atomics (every segment is complete inside its tile), and optionally as bf16 rows in the K order the node
+// update's matrix product reads them in (GW_LAYOUT_ROWS_BF16K: what it would round them to anyway).
+template <bool GATHER, bool PH, bool RES, bool SEGT = false>
 __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
+  static_assert(!SEGT || (GATHER && !RES), "the segment-aligned form gathers layer 1 and adds no residual");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -137,8 +163,39 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   const int s0 = 2 * tw;                // K-steps of the B layout the wave's 4 row tiles fill: s0, s0 + 1
 
   // ---- resident weights: rows 64 tw .. of the team's matrix, all 8 K-steps (packed stream: [s][16 tiles][lane][8]) ----
+  // SEGT, team B: output tile t of the wave, column m = lane & 15 (= row 4 q' + r of the segment-sum result) is the feature at
+  // POSITION 64 tw + 16 (m >> 2) + 4 t + (m & 3) of a destination row, so that a result lane holds 16 consecutive positions;
+  // position -> feature is the identity for fp32 rows and the K order of the packed streams for GW_LAYOUT_ROWS_BF16K
+  // (position 32 s + 8 q + i holds feature 32 s + 16 (i >> 2) + 4 q + (i & 3)).
+  auto feat_of = [&](int t) -> int {
+    const int pos = 64 * tw + 16 * (j >> 2) + 4 * t + (j & 3);
+    if (!a.agg_bf16k) return pos;
+    const int i = pos & 7;
+    return (pos & ~31) + 16 * (i >> 2) + 4 * ((pos >> 3) & 3) + (i & 3);
+  };
   bf16x8 wr[4][8];
-  {
+  if (SEGT && team_b) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int f = feat_of(t);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wr[t][s] = *(const bf16x8*)(a.w_out + ((size_t)(s * 16 + (f >> 4)) * 64 + 16 * q + (f & 15)) * 16);
+    }
+    if (q == 0) {
+      float* const parP = (float*)(lds + kS_ParP);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int f = feat_of(t);
+        const float b = a.b_out[f];
+        // (the accumulator of tile t starts as b for each of its 4 edges: stored replicated, so that the layer reads it with one
+        //  ds_read_b128 straight into the accumulator - a VALU move in front of an asm MFMA needs wait states nobody inserts)
+        ((f32x4*)(lds + kS_ParT))[(tw * 16 + j) * 4 + t] = f32x4{b, b, b, b};
+        const int pos = 64 * tw + 16 * (j >> 2) + 4 * t + (j & 3);
+        parP[pos] = a.gamma[f];
+        parP[256 + pos] = a.beta[f];
+      }
+    }
+  } else {
     const char* wsrc = team_b ? a.w_out : a.w_mid;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -230,6 +287,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         gidx[cp][p] = p < a.n_proj ? (a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k)) : 0;
+      if (SEGT) {  // (padding columns carry dst = -1: any valid row will do, their results are never summed)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gidx[cp][p] = gidx[cp][p] < 0 ? 0 : gidx[cp][p];
+      }
     }
 #pragma unroll
     for (int cp = 0; cp < 2; ++cp) {
@@ -362,7 +423,27 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   };
   auto publish_dst = [&](TileId t, int ring) {  // (wave 0) destination rows of the tile's 64 columns, for its segment sums
     const int kr = t.eb * kTileCols + lane;
-    gdl[ring * kTileCols + lane] = kr < a.n_edges ? t.b * a.n_dst + ldgi(a.dst + kr) : -1;
+    if constexpr (SEGT) {
+      // destination slots of the tile: a column starts a slot where its destination differs from its left neighbour's
+      // (runs are contiguous, padding columns sit at the end of the tile); slot of a column = slot starts up to it - 1
+      const int d = ldgi(a.dst + kr);
+      const int dp = lane > 0 ? ldgi(a.dst + kr - 1) : -2;
+      const bool valid = d >= 0;
+      const bool start = valid && d != dp;
+      const unsigned long long sm = __ballot(start);
+      const unsigned long long vm = __ballot(valid);
+      const int slot = __popcll(sm & ((2ull << lane) - 1ull)) - 1;
+      ((unsigned char*)(lds + kS_Slot))[ring * kTileCols + lane] = (unsigned char)(valid ? slot : 255);
+      if (start) {
+        const unsigned long long rest = (sm >> lane) >> 1;  // slot starts to the right of this one
+        const int len = rest != 0ull ? __builtin_ctzll(rest) + 1 : __popcll(vm >> lane);
+        ((int*)(lds + kS_Dsl))[ring * kTileCols + slot] = t.b * a.n_dst + d;
+        ((float*)(lds + kS_Cnt))[ring * kTileCols + slot] = (float)len;
+      }
+      if (lane == 0) ((int*)(lds + kS_Nsl))[ring] = __popcll(sm);
+    } else {
+      gdl[ring * kTileCols + lane] = kr < a.n_edges ? t.b * a.n_dst + ldgi(a.dst + kr) : -1;
+    }
   };
 
   // ===================================== both teams: segment sums of a staged tile ====================================
@@ -508,7 +589,9 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       }
       if (GATHER && has_next && !t_skip_a2) gather_part1(t_next, gx);
       GW_TS(9)
-      if (s >= 1 && !t_skip_a2) segment_sums(t_prev, (s - 1) & 3);
+      if constexpr (!SEGT) {
+        if (s >= 1 && !t_skip_a2) segment_sums(t_prev, (s - 1) & 3);
+      }
       GW_TS(8)
       if (has_next) {
         if (GATHER && !t_skip_a2) gather_part2(t_next, gx);
@@ -522,6 +605,174 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   } else {
     // ================================================ team B ========================================================
     __syncthreads();  // (pairs with team A's barrier before its first gather / DMA)
+    if constexpr (SEGT) {
+      // ---- segment-aligned form: transposed output layer, LayerNorm across lanes, segment sums on the matrix cores ----
+      f32x4 o[kGroups][4];  // o[g][t][r]: feature feat_of(t) (this lane's column of output tile t), edge 16 g + 4 q + r
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float* const ln1 = lnp;                     // [wave][edge]: sum over the wave's 64 features
+      float* const ln2 = lnp + 4 * kTileCols;     // [wave][edge]: sum of squares
+      float* const lnc = (float*)(lds + kS_Lnc);  // [wave][edge] (rstd, -mean rstd)
+      const f32x4* const parT = (const f32x4*)(lds + kS_ParT);   // b_out of the lane's features
+      const float* const parP = (const float*)(lds + kS_ParP);    // gamma, beta in position order
+      const float* const cntf = (const float*)(lds + kS_Cnt);
+      const unsigned* const slotw = (const unsigned*)(lds + kS_Slot);
+      const int* const dsl = (const int*)(lds + kS_Dsl);
+      const int* const nsl = (const int*)(lds + kS_Nsl);
+      TileId t_next = tile_at(0), t_cur = t_next, t_prev = t_next;
+#pragma unroll 1
+      for (int s = 0; s <= n; ++s) {
+        t_prev = t_cur;
+        t_cur = t_next;
+        if (s + 1 < n) t_next = tile_at(s + 1);
+        stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;
+        GW_TS(0)
+        team_barrier();  // (alpha) LayerNorm partial sums of tile s - 1 visible
+        GW_TS(1)
+        if (s >= 1 && !t_skip_ln) {
+          const int ring = (s - 1) & 3;
+          // LayerNorm statistics: lane (j, q) combines the four waves' partial sums of ONE edge, 16 (j >> 2) + 4 q + (j & 3),
+          // and parks (rstd, -mean rstd) in the wave's own slot; each lane then reads those of its 16 edges back (a wave's
+          // LDS accesses complete in order: no barrier)
+          {
+            const int e_mine = fresh(16 * (j >> 2) + 4 * q + (j & 3));
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              t1 += ln1[w * kTileCols + e_mine];
+              t2 += ln2[w * kTileCols + e_mine];
+            }
+            const float mean = t1 * (1.0f / 256.0f);
+            const float var = fmaxf(t2 * (1.0f / 256.0f) - mean * mean, 0.f);
+            const float ga = __builtin_amdgcn_rsqf(var + 1e-5f);
+            *(float2*)(lnc + (tw * kTileCols + e_mine) * 2) = float2{ga, -mean * ga};
+          }
+          // n = (o - mean) rstd, rounded to bf16 in the A-operand form of the segment-sum product: ypk[t][h] = the lane's feature of
+          // output tile t for the 8 edges 4 q + r of groups 2 h, 2 h + 1 (group by group: the accumulators die here).  gamma and
+          // beta wait until after the sums - sum_k (n_k gamma + beta) = gamma sum_k n_k + count beta - where they cost one fma per
+          // SUM instead of one per value and no registers in this phase.
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 ypk[4][2];
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g) {
+            const f32x4 gab0 = *(const f32x4*)(lnc + (tw * kTileCols + 16 * g + 4 * fresh(q)) * 2);      // (rstd, -mean rstd) x edges 4 q + 0, 1
+            const f32x4 gab1 = *(const f32x4*)(lnc + (tw * kTileCols + 16 * g + 4 * fresh(q) + 2) * 2);  // ... 4 q + 2, 3
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float n0 = fmaf(o[g][t][0], gab0[0], gab0[1]), n1 = fmaf(o[g][t][1], gab0[2], gab0[3]);
+              const float n2 = fmaf(o[g][t][2], gab1[0], gab1[1]), n3 = fmaf(o[g][t][3], gab1[2], gab1[3]);
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ypk[t][g >> 1][2 * (g & 1)]) : "v"(n0), "v"(n1));
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ypk[t][g >> 1][2 * (g & 1) + 1]) : "v"(n2), "v"(n3));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (group by group: the next group's statistics would only hold registers)
+          }
+          GW_TS(2)
+          const int nslots = __builtin_amdgcn_readfirstlane(nsl[ring]);
+#pragma unroll 1
+          for (int nt = 0; nt * 16 < nslots; ++nt) {
+            // S[edge][slot]: this lane's column = slot 16 nt + j, its 8 K entries of half h = edges 4 q + r of groups 2 h, 2 h + 1
+            const unsigned me = (unsigned)(16 * nt + j);
+            u32x4 sb[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const unsigned w0 = slotw[ring * 16 + 8 * h + fresh(q)];
+              const unsigned w1 = slotw[ring * 16 + 8 * h + 4 + fresh(q)];
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const unsigned lo0 = ((w0 >> (16 * i)) & 255u) == me ? 0x3F80u : 0u;
+                const unsigned hi0 = ((w0 >> (16 * i + 8)) & 255u) == me ? 0x3F800000u : 0u;
+                const unsigned lo1 = ((w1 >> (16 * i)) & 255u) == me ? 0x3F80u : 0u;
+                const unsigned hi1 = ((w1 >> (16 * i + 8)) & 255u) == me ? 0x3F800000u : 0u;
+                sb[h][i] = lo0 | hi0;
+                sb[h][2 + i] = lo1 | hi1;
+              }
+            }
+            // (asm MFMAs on plain vector registers: the builtin lets the allocator put these accumulators into the AGPR half
+            //  and rotate the resident weights out of their way; wait states as in layer_group - inline asm is opaque to the
+            //  hazard recogniser; an accumulator is touched by every 4th MFMA)
+            f32x4 dsum[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("s_nop 7" : "+v"(dsum[0]), "+v"(dsum[1]), "+v"(dsum[2]), "+v"(dsum[3]), "+v"(sb[0]), "+v"(sb[1]));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(dsum[t]) : "v"(ypk[t][h]), "v"(sb[h]));
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dsum[0]), "+v"(dsum[1]), "+v"(dsum[2]), "+v"(dsum[3]));
+            const int slot = 16 * nt + j;
+            if (slot < nslots && GW_SKIP(a) != 1) {
+              // agg[row][position p0 + 4 t + r] = gamma sum + count beta (parameters in position order: one float4 per t)
+              const size_t row = (size_t)dsl[ring * kTileCols + slot];
+              const float cnt = cntf[ring * kTileCols + slot];
+              const int p0 = fresh(64 * tw + 16 * q);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const f32x4 gm = *(const f32x4*)(parP + p0 + 4 * t);
+                const f32x4 bt = *(const f32x4*)(parP + 256 + p0 + 4 * t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsum[t][r] = fmaf(dsum[t][r], gm[r], cnt * bt[r]);
+              }
+              if (a.agg_bf16k) {
+                __bf16* dstp = (__bf16*)a.agg + row * 256 + p0;
+                *(GW_AS1 bf16x8*)dstp = to_bf16x8(dsum[0], dsum[1]);
+                *(GW_AS1 bf16x8*)(dstp + 8) = to_bf16x8(dsum[2], dsum[3]);
+              } else {
+                float* dstp = a.agg + row * 256 + p0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) stg4(dstp + 4 * t, dsum[t]);
+              }
+            }
+          }
+          GW_TS(3)
+        }
+        team_barrier();  // (beta) Hbuf2 of tile s complete
+        GW_TS(7)
+        if (s < n) {
+          // ---- output layer of tile s, transposed: Hbuf2 -> registers; per group (in the shadow of the next group's MFMAs) the
+          // sums and sums of squares over this wave's 64 features: 4 row tiles in registers, then the 16 feature lanes of the row ----
+          float s1[4], s2[4];
+          if (use_prio) __builtin_amdgcn_s_setprio(1);
+          team_layer<4, true>(
+              o, wr, h2, lane,
+              [&](f32x4& dst, int t) { dst = parT[(tw * 16 + fresh(j)) * 4 + t]; },  // b_out of the lane's feature of tile t x 4 edges
+              [&](int g, int mm, f32x4 (&ac)[4]) {
+                if (mm < 16) {  // one accumulator value into its edge's sums
+                  const int t = mm >> 2, r = mm & 3;
+                  const float x = ac[t][r];
+                  s1[r] = t == 0 ? x : s1[r] + x;
+                  s2[r] = t == 0 ? x * x : fmaf(x, x, s2[r]);
+                } else {  // 12 slots: 4 rotate-and-add steps for each of the 8 sums, then the partial sums of the 4 edges -> LDS
+                  const int lo = ((mm - 16) * 32) / 12, hi = ((mm - 15) * 32) / 12;
+#pragma unroll
+                  for (int op = lo; op < hi; ++op) {
+                    const int step = op >> 3, v = op & 7;
+                    float& x = v < 4 ? s1[v] : s2[v - 4];
+                    x = step == 0 ? add_row_ror<8>(x) : (step == 1 ? add_row_ror<4>(x) : (step == 2 ? add_row_ror<2>(x) : add_row_ror<1>(x)));
+                  }
+                  if (mm == 27 && j == 0) {
+                    *(f32x4*)(ln1 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+                    *(f32x4*)(ln2 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+                  }
+                }
+              });
+          __builtin_amdgcn_s_setprio(0);
+          GW_TS(9)
+        } else {
+          // (last iteration: no output layer.  The compiler cannot see that this path leaves the loop and would keep the 64
+          //  accumulators alive from their last use - the top of half 1 - across the segment sums, rotating resident weights
+          //  through scratch to make room: redefine them from nothing on this path, as the layer does on the other)
+#pragma unroll
+          for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(o[g][t]));
+        }
+        GW_TS(13)
+      }
+      return;
+    }
     f32x4 o[kGroups][4];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g)
@@ -658,6 +909,8 @@ int edge16t_launch(const void* edge16_args, bool gather, int n_wg, void* stream)
   //   layer-1 tiles by DMA + residual tiles     (processor blocks 1..: per-sample edge features)
   //   layer 1 gathered, no residual, the per-sample table as fp32 or fp16 rows   (decoder)
   const bool res = a.res_tiles != nullptr;
+  if (a.seg_tiles && (!gather || res))
+    return set_error(GW_E_UNSUPPORTED, "edge16t: segment-aligned tiles come with a gathered layer 1 and no residual");
   if (!gather) {
     if (!res) return set_error(GW_E_UNSUPPORTED, "edge16t: the form with a raw edge operand adds its residual from bf16 edge tiles");
     return launch_team(edge16t_kernel<false, false, true>, n_wg, a, stream);
@@ -671,6 +924,11 @@ int edge16t_launch(const void* edge16_args, bool gather, int n_wg, void* stream)
     }
   for (int p = 0; p < a.n_proj; ++p)
     if (a.p_half[p] && (p != dyn || n_dyn != 1)) return set_error(GW_E_UNSUPPORTED, "edge16t: only the per-sample projected table may be fp16 rows");
+  if (a.seg_tiles) {
+    if (n_dyn != 1) return set_error(GW_E_UNSUPPORTED, "edge16t: segment-aligned tiles take exactly one per-sample projected table");
+    return a.p_half[dyn] ? launch_team(edge16t_kernel<true, true, false, true>, n_wg, a, stream)
+                         : launch_team(edge16t_kernel<true, false, false, true>, n_wg, a, stream);
+  }
   if (n_dyn == 1)
     return a.p_half[dyn] ? launch_team(edge16t_kernel<true, true, false>, n_wg, a, stream) : launch_team(edge16t_kernel<true, false, false>, n_wg, a, stream);
   // (two per-sample tables - the first processor block - stay on the lock-step kernel: measured 0.43 ms there against 0.49 ms

@@ -27,6 +27,7 @@ struct ChainArgs {
   int seg_k[3];
   int seg_proj[3];     // operand is already multiplied by its layer-1 weight slice: rows are [hidden] wide
   int seg_half[3];     // ... and stored as fp16 rows (GW_LAYOUT_ROWS_F16; seg_ld counts halves): bf16 kernels only
+  int seg_bf16k[3];    // raw operand stored as bf16 rows in K order (GW_LAYOUT_ROWS_BF16K; seg_ld counts bf16 values): bf16 kernels
   // single-layer projection mode: blockIdx.y selects the weight slice / output table.
   // POST mode (node update): after LayerNorm + residual the new rows x' are multiplied, still in registers, by n_post packed
   // [256, 256] slices - the layer-1 products of the NEXT block's edge MLP (P_s = x' Ws^T, P_d = x' Wd^T) - and written to
@@ -143,7 +144,8 @@ bool edge16_eligible(const gw_operand* x_src, const gw_operand* x_dst, const gw_
 size_t edge16_workspace_bytes(int32_t batch, int32_t n_edges);
 int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst, const gw_operand* x_src,
                   const gw_operand* x_dst, const gw_operand* e_in, const gw_operand* e_res, const gw_mlp_weights* w,
-                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, bool deterministic, void* stream);
+                  float* e_out, void* e_out_tiles, float* agg, int32_t n_dst, void* workspace, int32_t flags /* GW_EDGE_* */,
+                  void* stream);
 size_t edge16_workspace_needed(int32_t batch, int32_t n_edges, const gw_operand* e_in, bool deterministic);  // layer-1 tiles (if a
                                                                                   // separate launch makes them) + carry records
 // team-pipelined form of the resident kernel (gw_edge16t.hip): residual as bf16 tiles, atomics mode; gather = layer 1 is a

@@ -811,6 +811,13 @@ void fill_operand(ChainArgs& a, int i, const gw_operand* op) {
   a.seg_k[i] = op->k;
   a.seg_proj[i] = op->projected;
   a.seg_half[i] = op->layout == GW_LAYOUT_ROWS_F16;
+  a.seg_bf16k[i] = op->layout == GW_LAYOUT_ROWS_BF16K;
+}
+// the aggregate operand of the node updates: fp32 rows, or (bf16 weights) bf16 rows in K order
+bool bad_agg(const gw_operand* op, bool bf16_weights) {
+  if (op->k != 256 || !op->ptr || op->projected) return true;
+  if (op->layout == GW_LAYOUT_ROWS_F32) return op->ld % 4 != 0;
+  return !(bf16_weights && op->layout == GW_LAYOUT_ROWS_BF16K && op->ld % 8 == 0 && !op->index);
 }
 
 void fill_residual(ChainArgs& a, const gw_operand* op) {
@@ -1109,6 +1116,16 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
                                   "resident weights: fp16 product rows)");
   float* e_out = tiles_out ? nullptr : (float*)e_out_any;
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
+  const bool seg = (flags & GW_EDGE_SEGMENT_TILES) != 0;
+  if ((flags & GW_EDGE_AGG_BF16K) && !seg) return fail(GW_E_BADARG, "gw_edge_update_forward: GW_EDGE_AGG_BF16K comes with GW_EDGE_SEGMENT_TILES");
+  if (seg) {
+    const bool all_proj = (x_src->k == 0 || x_src->projected) && (x_dst->k == 0 || x_dst->projected) && (e_in->k == 0 || e_in->projected);
+    if (!no_res || !all_proj || det || n_edges % 64 != 0 || !gw::edge16_eligible(x_src, x_dst, e_in, w))
+      return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: segment-aligned tiles (GW_EDGE_SEGMENT_TILES) are implemented for the bf16 "
+                                    "path with resident weights: every operand projected, no residual, atomics mode, n_edges a "
+                                    "multiple of 64");
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, nullptr, nullptr, agg, n_dst, workspace, flags, stream);
+  }
   const size_t ws16 = gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");
   if (tiles_in || tiles_out || no_res || half_nodes) {
@@ -1116,7 +1133,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
                                     "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");
     return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, tiles_out ? e_out_any : nullptr, agg,
-                             n_dst, workspace, det, stream);
+                             n_dst, workspace, det ? GW_EDGE_DETERMINISTIC : 0, stream);
   }
   if (w->weight_dtype == GW_DTYPE_F32 && (!save || w->n_mid == 1) && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) {
     if (save && (!save->hidden || !save->pre_norm || save->hidden_ld < 256 || save->hidden_ld % 4 != 0))
@@ -1127,7 +1144,8 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
                                 det ? (float*)workspace : nullptr, stream);
   }
   if (!save && gw::edge16_eligible(x_src, x_dst, e_in, w) && (ws16 == 0 || (workspace && workspace_bytes >= ws16)))
-    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace, det, stream);
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace,
+                             det ? GW_EDGE_DETERMINISTIC : 0, stream);
   if (det && (w->weight_dtype != GW_DTYPE_BF16 || !workspace || workspace_bytes < gw::edge_fast_carry_bytes(batch, n_edges)))
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums exist on the fast fp32 edge kernel (at most one "
                                   "raw operand, native 256 widths) and on the bf16 kernels, and need their workspace");
@@ -1168,7 +1186,9 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: only hidden=256, out=256");
   if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: at least 2 hidden layers (n_mid >= 1) are required");
-  if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide (raw)");
+  if (bad_agg(agg, w->weight_dtype == GW_DTYPE_BF16) || !w->w1[1])
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: agg must be 256 wide (raw fp32 rows; bf16 rows in K order with bf16 weights)");
+  if (agg->layout == GW_LAYOUT_ROWS_BF16K && save) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: bf16 aggregates are an inference format");
   if (x->k != 0 && (bad256(x, w->weight_dtype == GW_DTYPE_BF16) || (!x->projected && !w->w1[0])))
     return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x must be 256 wide (fp32 rows; fp16 product rows with bf16 weights) or zeros");
   if (x_res && x_res->k != 0 && bad256(x_res)) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: x_res must be 256 wide");
@@ -1218,7 +1238,7 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out || bad_layers(w) || w->n_mid != 1 || !w->ln_gamma ||
       (w->ln_width > 0 && w->ln_width != 256))
     return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: node MLP must be 512 -> 256 -> 256 -> 256 with LayerNorm");
-  if (bad256(agg) || agg->projected || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: agg must be 256 wide (raw)");
+  if (bad_agg(agg, true) || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: agg must be 256 wide (raw)");
   if (x->k != 0 && (bad256(x, true) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: x must be 256 wide or zeros");
   if (head->hidden != 128 || head->n_mid != 1 || head->n_out > 80 || head->n_out <= 0 || head->ln_gamma || !head->w1[0] || !head->b1 ||
       !head->w_mid || !head->b_mid || !head->w_out || !head->b_out)

@@ -74,9 +74,61 @@ class GraphPlan:
             self._ident_ptr = torch.arange(self.num_edges + 1, dtype=torch.int32, device=self.src.device)
         return self._ident_ptr
 
+    def seg_tiles(self):
+        """Segment-aligned tiles of the destination-sorted edge list (include/gw_amd.h: GW_EDGE_SEGMENT_TILES): the edges are
+        re-laid into tiles of 64 columns so that no destination's run of edges crosses a tile - runs are packed next-fit in
+        order, the rest of a tile is padding (the decoder graph, assimilator_decoder.py:92-103: 7 or 6 edges per grid node, 9
+        nodes = 63 columns per tile).  Returns ``SegTiles(src, dst, pos, n_pad, complete)`` - padded int32 ``src`` / ``dst``
+        (padding: src 0, dst -1), ``pos[i]`` = padded position of sorted edge i, ``complete`` = every destination row has an
+        edge - or None when some destination has more than 64 edges (the encoder's polar mesh cells)."""
+        if getattr(self, "_seg_tiles", None) is None:
+            dst = self.dst.cpu().numpy().astype(np.int64)
+            E = int(dst.size)
+            st = None
+            if E > 0:
+                starts = np.flatnonzero(np.concatenate([[True], dst[1:] != dst[:-1]]))
+                ends = np.concatenate([starts[1:], [E]])
+                if int((ends - starts).max()) <= 64:
+                    first, tile_of_seg = 0, np.empty(starts.size, dtype=np.int64)
+                    tile_start_edge = []
+                    t = 0
+                    while first < starts.size:  # next-fit: as many whole runs as fit into 64 columns
+                        nxt = int(np.searchsorted(ends, starts[first] + 64, side="right"))
+                        tile_of_seg[first:nxt] = t
+                        tile_start_edge.append(int(starts[first]))
+                        first, t = nxt, t + 1
+                    tile_start_edge = np.asarray(tile_start_edge, dtype=np.int64)
+                    tile_of_edge = np.repeat(tile_of_seg, ends - starts)
+                    pos = tile_of_edge * 64 + (np.arange(E, dtype=np.int64) - tile_start_edge[tile_of_edge])
+                    n_pad = 64 * t
+                    src_p = np.zeros(n_pad, dtype=np.int32)
+                    dst_p = np.full(n_pad, -1, dtype=np.int32)
+                    src_p[pos] = self.src.cpu().numpy()
+                    dst_p[pos] = dst
+                    dev = self.src.device
+                    st = SegTiles(torch.from_numpy(src_p).to(dev), torch.from_numpy(dst_p).to(dev), torch.from_numpy(pos).to(dev),
+                                  n_pad, bool(starts.size == self.n_dst))
+            self._seg_tiles = (st,)
+        return self._seg_tiles[0]
+
     def to(self, device) -> "GraphPlan":
         return GraphPlan(self.n_src, self.n_dst, self.src.to(device), self.dst.to(device), self.perm.to(device),
                          None if self.edge_attr is None else self.edge_attr.to(device))
+
+
+@dataclass
+class SegTiles:
+    src: torch.Tensor  # int32 [n_pad]: source row of each column (0 in padding columns)
+    dst: torch.Tensor  # int32 [n_pad]: destination row, -1 in padding columns
+    pos: torch.Tensor  # int64 [E]: padded position of destination-sorted edge i
+    n_pad: int
+    complete: bool  # every destination row has at least one edge
+
+    def pad_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """A per-edge table [E, w] in destination-sorted order -> [n_pad, w] in padded order (zero rows in padding columns)."""
+        out = rows.new_zeros((self.n_pad,) + tuple(rows.shape[1:]))
+        out[self.pos] = rows
+        return out
 
 
 def plan_from_coo(src: np.ndarray, dst: np.ndarray, n_src: int, n_dst: int,

@@ -97,6 +97,12 @@ class Operand:
             _require(self.tensor, "edge tiles", torch.uint8)
             # rows_per_batch: n_edges = one tile set per batch element, 0 = one set shared by the batch
             return GwOperand(self.tensor.data_ptr(), None, int(self.rows_per_batch), 256, 256, 0, _lib.LAYOUT_EDGE_TILES_BF16)
+        if self.tensor.dtype == torch.bfloat16:  # an aggregate as bf16 rows in K order (include/gw_amd.h: GW_LAYOUT_ROWS_BF16K)
+            if self.projected or self.index is not None or self.k != 256:
+                raise RuntimeError("graph_weather_amd: bf16 rows (K order) are a format of raw 256-wide aggregates only")
+            _require(self.tensor, "operand", torch.bfloat16)
+            return GwOperand(self.tensor.data_ptr(), None, int(self.rows_per_batch), int(self.tensor.stride(0)), 256, 0,
+                             _lib.LAYOUT_ROWS_BF16K)
         if self.tensor.dtype == torch.float16:  # layer-1 node products as fp16 rows (include/gw_amd.h: GW_LAYOUT_ROWS_F16)
             if not self.projected or self.index is not None:
                 raise RuntimeError("graph_weather_amd: fp16 rows are a format of projected (layer-1 product) operands only")
@@ -327,13 +333,20 @@ def edge_rows_to_tiles(rows: torch.Tensor, batch: int, n_edges: int, rows_per_ba
 
 def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
                         e_in: Operand, e_res: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
-                        tag: Optional[str] = None, save: Optional[SavedActivations] = None, deterministic: bool = False) -> None:
+                        tag: Optional[str] = None, save: Optional[SavedActivations] = None, deterministic: bool = False,
+                        segment_tiles: bool = False) -> None:
     """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed.
     ``e_out``: None, fp32 rows [batch * n_edges, 256], or a uint8 buffer of ``edge_tiles_bytes`` (bf16 edge tiles).
-    ``deterministic``: bitwise reproducible segment sums (carry records + a fix-up launch instead of atomics)."""
+    ``deterministic``: bitwise reproducible segment sums (carry records + a fix-up launch instead of atomics).
+    ``segment_tiles``: ``src`` / ``dst`` are the padded arrays of segment-aligned tiles (include/gw_amd.h:
+    GW_EDGE_SEGMENT_TILES; ``GraphPlan.seg_tiles()``): ``agg`` rows are written with plain stores and need no zero fill when every
+    destination has an edge; a bfloat16 ``agg`` is written as bf16 rows in K order (GW_EDGE_AGG_BF16K)."""
     _require(src, "src", torch.int32)
     _require(dst, "dst", torch.int32)
-    _require(agg, "agg")
+    agg_bf16 = agg.dtype == torch.bfloat16
+    if agg_bf16 and not segment_tiles:
+        raise RuntimeError("graph_weather_amd: a bf16 aggregate comes with segment-aligned tiles")
+    _require(agg, "agg", torch.bfloat16 if agg_bf16 else torch.float32)
     e_out_layout = _lib.LAYOUT_ROWS_F32
     if e_out is not None:
         if e_out.dtype == torch.uint8:
@@ -345,6 +358,8 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
     wc = pm.c((x_src.k > 0 and not x_src.projected, x_dst.k > 0 and not x_dst.projected, e_in.k > 0 and not e_in.projected))
     xs, xd, ei = x_src.c(), x_dst.c(), e_in.c()
     flags = _lib.EDGE_DETERMINISTIC if deterministic else 0
+    if segment_tiles:
+        flags |= _lib.EDGE_SEGMENT_TILES | (_lib.EDGE_AGG_BF16K if agg_bf16 else 0)
     ws, ws_bytes = None, 0
     if save is None:  # scratch for the kernel the library would like to use (the library never allocates)
         ws_bytes = int(_lib.lib().gw_edge_update_workspace_bytes(batch, n_edges, xs, xd, ei, wc, flags))

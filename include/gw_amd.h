@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 13
+#define GW_ABI_VERSION 14
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -57,6 +57,15 @@ extern "C" {
  * most of what an edge update reads; fp16 keeps 11 significant bits in front of the bf16 rounding of the layer-1 activation.
  * Accepted as a projected x_src / x_dst operand by the bf16 edge update with resident weights (csrc/gw_edge16*.hip). */
 #define GW_LAYOUT_ROWS_F16 2
+/* GW_LAYOUT_ROWS_BF16K (v14): an AGGREGATE table (the scatter_sum of graph_net_block.py:188) as bf16 rows of 256 values in the K
+ * order of the packed weight streams - position 32 s + 8 q + i of a row holds feature 32 s + 16 (i >> 2) + 4 q + (i & 3)
+ * (s < 8, q < 4, i < 8; ld counts bf16 values) - i.e. exactly the 16 bytes lane q loads as its B-operand fragment of K-step s.
+ * bf16 mode only: the node update rounds the aggregate to bf16 for its layer-1 product anyway (graph_net_block.py:189-190 on
+ * v_mfma_f32_16x16x32_bf16), so the producer (gw_edge_update_forward with GW_EDGE_AGG_BF16K) stores what the consumer would
+ * compute from fp32 rows - a quarter of the bytes written and read back (1.06 GB -> 0.27 GB per direction for the 1 degree
+ * decoder at batch 16) and no conversion in the consumer.  Accepted as the raw `agg` operand of gw_node_update_forward /
+ * gw_node_update_head_forward with bf16 weights. */
+#define GW_LAYOUT_ROWS_BF16K 3
 
 /* flags of gw_edge_update_forward.  GW_EDGE_DETERMINISTIC: the segment sums (scatter_sum, graph_net_block.py:188) are
  * bitwise reproducible from run to run - partial sums of segments that cross a 64-edge tile are parked in per-tile carry
@@ -64,6 +73,15 @@ extern "C" {
  * (torch_scatter's scatter_add_ on a GPU is order-nondeterministic too; this is an extra).  Needs the workspace of
  * gw_edge_update_workspace_bytes(..., flags). */
 #define GW_EDGE_DETERMINISTIC 1
+/* GW_EDGE_SEGMENT_TILES (v14; bf16 weights with resident kernels, every operand projected, e_res.k == 0, no e_out): `src` / `dst`
+ * are a PADDED edge list of n_edges = 64 T entries in which no destination's run of edges crosses a multiple of 64 ("segment-
+ * aligned tiles": assimilator_decoder.py:92-103 gives every grid node 7 or 6 consecutive edges, so 9 nodes = 63 columns fill a
+ * tile).  dst[k] < 0 marks a padding column (src[k] must still be a valid row; rows of batch-shared per-edge tables are indexed by
+ * the padded position k).  Every destination segment is then complete inside one tile: agg rows of destinations that have edges
+ * are WRITTEN (=, plain stores - no atomics, bitwise reproducible), rows of destinations without edges are not touched.
+ * GW_EDGE_AGG_BF16K (with GW_EDGE_SEGMENT_TILES): `agg` points to bf16 rows in K order (GW_LAYOUT_ROWS_BF16K) instead of fp32. */
+#define GW_EDGE_SEGMENT_TILES 2
+#define GW_EDGE_AGG_BF16K 4
 
 /* Library / ABI version and last error text (thread local). */
 int gw_version(void);
@@ -208,7 +226,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w,
                            void* e_out /* NULL, or fp32 rows [batch*n_edges,256], or bf16 edge tiles (e_out_layout) */,
-                           int32_t e_out_layout /* GW_LAYOUT_* of e_out */, float* agg /* [batch*n_dst,256] */,
+                           int32_t e_out_layout /* GW_LAYOUT_* of e_out */, float* agg /* [batch*n_dst,256] (GW_EDGE_AGG_BF16K: bf16) */,
                            int32_t n_dst, const struct gw_activation_save* save /* may be NULL */,
                            void* workspace /* may be NULL */, size_t workspace_bytes, int32_t flags /* GW_EDGE_* */, void* stream);
 /* Edge tiles (GW_LAYOUT_EDGE_TILES_BF16) are consumed and produced by the bf16 path with register-resident weights only:
@@ -230,7 +248,8 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
  * x may be raw, pre-projected or zeros (k == 0: the decoder's lat/lon rows are zeros, assimilator_decoder.py:84,
  * 190 - the x-slice of layer 1 is skipped); x_res = raw node rows for the residual (NULL or k == 0: none).  With bf16
  * weights a pre-projected x may be fp16 product rows (GW_LAYOUT_ROWS_F16, ld in halves); every other operand of the row-wise
- * entry points is fp32 rows - any other layout is rejected. */
+ * entry points is fp32 rows - any other layout is rejected; agg may also be bf16 rows in K order (GW_LAYOUT_ROWS_BF16K, bf16
+ * weights, ld in bf16 values, no index). */
 int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* x_res,
                            const gw_operand* agg, const gw_mlp_weights* w, float* x_out, int32_t out_ld,
                            const struct gw_activation_save* save /* may be NULL */,
@@ -247,7 +266,9 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
  * AssimilatorDecoder.forward after its edge update (assimilator_decoder.py:195-200) + the Decoder residual (decoder.py:93):
  *   x_new[j] = LN(MLP_node(cat[x[j], agg[j]]))            (graph_net_block.py:189-191; the decoder's rows are zeros: no x_res)
  *   out[j, :n] = MLP_head(x_new[j]) + residual[j, :n]     (node_decoder 256 -> 128 -> 128 -> n <= 80 features, no norm)
- * x_new stays in registers: the [rows, 256] table between the two MLPs is neither written nor read. */
+ * x_new stays in registers: the [rows, 256] table between the two MLPs is neither written nor read.
+ * Packed sizes the kernel streams unconditionally (the caller guarantees them; gw_pack_many with these shapes):
+ * head->w1[0] = [128, 256] slice (8 K-steps x 8 row tiles), head->w_mid = [128, 128], head->w_out / b_out packed with rows = 80. */
 int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
                                 const gw_mlp_weights* w, const gw_mlp_weights* head, const gw_operand* residual /* may be NULL */,
                                 float* out, int32_t out_ld, void* stream);

@@ -36,17 +36,18 @@ with torch.no_grad():
         L.gw_debug_timestamps(None, 0, -1)
 rec = buf.cpu().numpy().reshape(cap, 32)
 rec = rec[rec[:, 0] != 0]
-NA = ["wait at alpha", "mid group 0", "mid group 1", "mid group 2", "mid group 3", "issue gather pass 0", "wait at beta", "segment sums",
-      "gather: pass 0 done", "gather: pass 1 done", "dst ids / DMA wait"]
-NB = ["wait at alpha", "LN: mean / rstd", "LN: tile 0 (needs residual)", "LN: tile 1 (+ residual request)", "LN: tile 2", "LN: tile 3",
-      "wait at beta", "segment sums", "out group 0", "out group 1", "out group 2", "out group 3", "residual request"]
 print(WHICH, "batch", B, "workgroups", rec.shape[0], "env", {k: v for k, v in os.environ.items() if k.startswith("GW_")}, "(ticks = shader cycles)")
-for team, off, names in (("A", 0, NA), ("B", 16, NB)):
-    r = rec[:, off:off + len(names) + 1].astype(np.int64)
-    if WHICH == "processor" and team == "A":  # (DMA form: no gather stamps 9 - their slots stay 0)
-        r = r.copy(); r[:, 9] = r[:, 8]
-    d = np.diff(r, axis=1)
+# stamps are GW_TS(i) of csrc/gw_edge16t.hip, written on each workgroup's 4th pipeline step; offsets from the team's stamp 0
+LA = {0: "step start", 1: "after alpha", 2: "middle layer done", 6: "gather of the next tile issued", 7: "after beta", 9: "gather pass 0 stored",
+      8: "segment sums done (lock-step forms)", 10: "gather pass 1 stored", 11: "step end (dst slots published / DMA landed)"}
+LB = {0: "step start", 1: "after alpha", 2: "LayerNorm statistics + normalised bf16 operands", 3: "segment sums (MFMA) + stores / LN tile 0", 4: "LN tile 1", 5: "LN tile 2",
+      6: "LN tile 3", 7: "after beta", 8: "segment sums done (lock-step forms)", 9: "output layer done", 13: "step end"}
+for team, off, lab in (("A", 0, LA), ("B", 16, LB)):
+    r = rec[:, off:off + 16].astype(np.int64)
     print("team", team)
-    for i, n in enumerate(names):
-        print(f"  {n:32s} median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
-    print(f"  step total                       median {np.median(r[:, len(names)] - r[:, 0]):8.0f}")
+    order = sorted((i for i in lab if np.median(r[:, i]) != 0), key=lambda i: np.median(r[:, i] - r[:, 0]))
+    prev = 0.0
+    for i in order:
+        t = np.median(r[:, i] - r[:, 0])
+        print(f"  [{i:2d}] {lab[i]:56s} at {t:8.0f}  (+{t - prev:7.0f})  p90 {np.percentile(r[:, i] - r[:, 0], 90):8.0f}")
+        prev = t

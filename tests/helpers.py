@@ -141,3 +141,26 @@ def edge_rows_from_tiles(tiles: torch.Tensor, E: int) -> torch.Tensor:
     rows = torch.empty_like(t)
     rows[..., f] = t
     return rows.reshape(B, neb * 64, 256)[:, :E]
+
+
+def bf16k_feature_of_position() -> np.ndarray:
+    """GW_LAYOUT_ROWS_BF16K (include/gw_amd.h): position 32 s + 8 q + i of a row holds feature k16_of(s, q, i)."""
+    f = np.empty(256, dtype=np.int64)
+    for s in range(8):
+        for q in range(4):
+            for i in range(8):
+                f[32 * s + 8 * q + i] = k16_of(s, q, i)
+    assert sorted(f.tolist()) == list(range(256))
+    return f
+
+
+def rows_to_bf16k(rows: torch.Tensor) -> torch.Tensor:
+    """fp32 rows [n, 256] -> bf16 rows in K order (round to nearest even)."""
+    return rows[:, torch.from_numpy(bf16k_feature_of_position())].to(torch.bfloat16).contiguous()
+
+
+def rows_from_bf16k(rows_k: torch.Tensor) -> torch.Tensor:
+    """bf16 rows in K order -> fp32 rows [n, 256] in feature order."""
+    out = torch.empty(rows_k.shape, dtype=torch.float32)
+    out[:, torch.from_numpy(bf16k_feature_of_position())] = rows_k.float().cpu()
+    return out

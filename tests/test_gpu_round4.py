@@ -1,0 +1,163 @@
+"""Round 4: the segment-aligned form of the bf16 edge update (csrc/gw_edge16t.hip, SEGT: transposed output layer, LayerNorm
+across lanes, segment sums on the matrix cores, aggregate as bf16 rows in K order) and its consumers."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from graph_weather_amd import ops  # noqa: E402
+from graph_weather_amd.graphs import plan_from_coo  # noqa: E402
+from graph_weather_amd.ops import Operand, PackedMLP  # noqa: E402
+
+from .helpers import rows_from_bf16k, rows_to_bf16k  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _graph(rs, n_src, n_dst, degrees):
+    deg = rs.choice(degrees, size=n_dst)
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rs.randint(0, n_src, size=dst.size)
+    order = rs.permutation(dst.size)  # the plan sorts by destination itself
+    return src[order], dst[order]
+
+
+@pytest.mark.parametrize("case,degrees,B,n_dst", [
+    ("decoder-like", [7, 7, 7, 6], 3, 100),       # 9 destinations per tile, one padding column
+    ("many-slots", [1, 2, 3], 2, 300),            # more than 16 destination slots per tile: several slot groups
+    ("long-runs", [0, 1, 30, 64, 40], 2, 37),     # runs up to a whole tile, destinations without edges, much padding
+    ("tiny", [2], 1, 3),
+])
+@pytest.mark.parametrize("half", [True, False])
+def test_segment_tiles_edge_update_against_emulation_and_oracle(case, degrees, B, n_dst, half):
+    """gw_edge_update_forward(GW_EDGE_SEGMENT_TILES) - the GATHER / no-residual / segment-aligned form of the team kernel -
+    DIRECTLY against (a) a float64 emulation of its arithmetic (bf16-rounded operands of the two resident layers, exact
+    products; what remains is the bf16 rounding of the normalised values in front of the segment-sum product and summation
+    order) and (b) the oracle on the raw rows (oracle/reference_math.py: EdgeProcessor.forward + scatter_sum, minus the
+    residual sums the callers of this form add elsewhere), with fp32 and bf16 (K order) aggregates."""
+    from graph_weather_amd.utils import deterministic_fill_
+    from oracle import reference_math as om
+    import graph_weather_amd as gw
+
+    rs = np.random.RandomState(len(case) + 7 * B)
+    n_src = 50
+    src, dst = _graph(rs, n_src, n_dst, degrees)
+    plan = plan_from_coo(src, dst, n_src, n_dst)
+    seg = plan.seg_tiles()
+    assert seg is not None and seg.n_pad % 64 == 0
+    E = plan.num_edges
+    ep = gw.EdgeProcessor(256, 256, 256, 2, "LayerNorm")
+    deterministic_fill_(ep, seed=23)
+    p = {"blk.edge_model." + k: v.clone() for k, v in ep.state_dict().items()}
+    x_src = torch.from_numpy(rs.standard_normal((B, n_src, 256)).astype(np.float32))
+    e = torch.from_numpy(rs.standard_normal((E, 256)).astype(np.float32))  # batch-shared edge features, destination-sorted
+    st, dt = plan.src.long(), plan.dst.long()
+    lin = [m for m in ep.edge_mlp.model if isinstance(m, torch.nn.Linear)]
+    norm = ep.edge_mlp.model[-1]
+    W0 = lin[0].weight.detach().double()
+    ps = (x_src.double().reshape(B * n_src, 256) @ W0[:, :256].t()).float()
+    pe = (e.double() @ W0[:, 512:].t()).float()
+    ps_dev = ps.to(DEV).half() if half else ps.to(DEV)
+    # (a) emulation: layer 1 in fp32-like sums, bf16 operands of the resident layers, LayerNorm in float64, no residual
+    ps_e = ps_dev.float().cpu().double().reshape(B, n_src, 256)
+    z1 = lin[0].bias.detach().double() + ps_e[:, st] + pe.double()[None]
+    h1 = _bf(torch.relu(z1).float())
+    h2 = _bf(torch.relu(h1 @ _bf(lin[1].weight.detach()).t() + lin[1].bias.detach().double()).float())
+    o = h2 @ _bf(lin[2].weight.detach()).t() + lin[2].bias.detach().double()
+    y = torch.nn.functional.layer_norm(o, (256,), norm.weight.detach().double(), norm.bias.detach().double(), 1e-5)
+    agg_emu = torch.zeros(B, n_dst, 256, dtype=torch.float64)
+    agg_emu.index_add_(1, dt, y)
+    # (b) oracle on the raw rows; the kernel leaves the residual sums to its caller
+    agg_orc = []
+    for b in range(B):
+        en = om.edge_processor(p, "blk.edge_model", x_src[b][st], torch.zeros(E, 256), e)
+        agg_orc.append(om.scatter_sum(en - e, dt, n_dst))
+    agg_orc = torch.stack(agg_orc).double()
+
+    pm = PackedMLP([l.weight.detach().to(DEV) for l in lin], [l.bias.detach().to(DEV) for l in lin],
+                   (norm.weight.detach().to(DEV), norm.bias.detach().to(DEV)), ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+    pe_pad = seg.pad_rows(pe).to(DEV)
+    s_dev, d_dev = seg.src.to(DEV), seg.dst.to(DEV)
+    got = {}
+    for kind in ("fp32", "bf16k"):
+        canary = 768.0  # (representable in bf16)
+        agg = torch.full((B * n_dst, 256), canary, device=DEV, dtype=torch.float32 if kind == "fp32" else torch.bfloat16)
+        ops.edge_update_forward(pm, B, s_dev, d_dev, Operand(ps_dev, n_src, 256, projected=True), ops.ZERO,
+                                Operand(pe_pad, 0, 256, projected=True), ops.ZERO, n_dst, agg, None, segment_tiles=True)
+        torch.cuda.synchronize()
+        a = (agg.cpu() if kind == "fp32" else rows_from_bf16k(agg)).double().reshape(B, n_dst, 256)
+        has = torch.zeros(n_dst, dtype=torch.bool)
+        has[dt] = True
+        assert torch.all(a[:, ~has] == canary), "rows of destinations without edges must not be touched"
+        got[kind] = a[:, has]
+    ref_e, ref_o = agg_emu[:, has], agg_orc[:, has]
+    scale = ref_e.abs().max().item()
+    err_e = (got["fp32"] - ref_e).abs().max().item() / scale
+    err_o = (got["fp32"] - ref_o).abs().max().item() / ref_o.abs().max().item()
+    err_k = (got["bf16k"] - got["fp32"]).abs().max().item() / scale
+    print(f"[segment tiles {case} half={half}] vs emulation {err_e:.2e}, vs oracle {err_o:.2e}, bf16 rows vs fp32 rows {err_k:.2e}")
+    # bf16(n_k) in front of the sums: 2^-9 relative per value; a flipped bf16 rounding of one hidden activation ~1e-3
+    assert err_e <= 6e-3, err_e
+    assert 1e-6 < err_o <= 2e-2, err_o
+    assert err_k <= 2 ** -8 + 1e-3, err_k  # one bf16 rounding of the same sums (different lane order of the partial statistics)
+
+
+def test_node_updates_take_the_aggregate_as_bf16_rows_in_k_order():
+    """gw_node_update_forward / gw_node_update_head_forward with the aggregate as GW_LAYOUT_ROWS_BF16K: bitwise the result of
+    the fp32-row form on the bf16-rounded values (the kernel rounds fp32 rows to bf16 with the same rule on the fly)."""
+    from graph_weather_amd.utils import deterministic_fill_
+    import graph_weather_amd as gw
+
+    rs = np.random.RandomState(5)
+    n = 333
+    npr = gw.NodeProcessor(256, 256, 256, 2, "LayerNorm")
+    head = gw.MLP(256, 78, 128, 2, None)
+    deterministic_fill_(npr, seed=3)
+    deterministic_fill_(head, seed=4)
+    npr, head = npr.to(DEV), head.to(DEV)
+    for m in (npr.node_mlp, head):
+        m.compute_dtype = torch.bfloat16
+    agg = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
+    agg_r = agg.to(torch.bfloat16).float()  # what the kernel makes of fp32 rows
+    x = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    res = torch.from_numpy(rs.standard_normal((n, 78)).astype(np.float32)).to(DEV)
+    pm, ph = npr.node_mlp.packed(), head.packed()
+    a32, a16 = Operand(agg_r.to(DEV), n, 256), Operand(rows_to_bf16k(agg).to(DEV), n, 256)
+    y32 = ops.node_update_forward(pm, n, n, Operand(x, n, 256), Operand(x, n, 256), a32)
+    y16 = ops.node_update_forward(pm, n, n, Operand(x, n, 256), Operand(x, n, 256), a16)
+    assert torch.equal(y32, y16)
+    h32 = ops.node_update_head_forward(pm, ph, n, n, ops.ZERO, a32, Operand(res, n, 78))
+    h16 = ops.node_update_head_forward(pm, ph, n, n, ops.ZERO, a16, Operand(res, n, 78))
+    assert torch.equal(h32, h16)
+    assert torch.isfinite(h16).all() and h16.abs().max().item() > 0
+
+
+def test_decoder_runs_on_segment_aligned_tiles_and_matches_the_fp32_path():
+    """AssimilatorDecoder in bf16 mode takes the segment-aligned route (every grid node has 7 or 6 consecutive edges) and stays
+    inside the bf16 budget of the fp32 kernels on the same weights (2e-2 of the output scale)."""
+    import graph_weather_amd as gw
+    from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons
+
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=2)
+    model = model.to(DEV).eval()
+    assert model.decoder._plan(torch.device(DEV)).seg_tiles() is not None
+    x = torch.randn(3, model.decoder.num_h3, 256, device=DEV).reshape(-1, 256)
+    start = torch.randn(3, len(lat_lons), 78, device=DEV)
+    with torch.no_grad():
+        ref = model.decoder(x, start)
+        model.set_compute_dtype(torch.bfloat16)
+        assert model.decoder.team_path()
+        out = model.decoder(x, start)
+        out2 = model.decoder(x, start)
+    assert torch.equal(out, out2), "plain stores, no atomics: bitwise reproducible"
+    scale = (ref - start).abs().max().item()
+    err = (out - ref).abs().max().item() / scale
+    print(f"[decoder on segment tiles] max-rel vs fp32 kernels {err:.2e}")
+    assert err <= 2e-2

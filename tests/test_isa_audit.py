@@ -123,9 +123,12 @@ def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "e.o", "-save-temps"]
     subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
     text = (tmp_path / "gw_edge16t-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
-    names = re.findall(r"^(_Z\w*edge16t_kernelILb[01]ELb[01]ELb[01]E\w*):", text, re.M)
-    assert len(names) == 3, names  # layer-1 tiles by DMA + residual tiles | gathered from fp32 rows | from fp16 rows (no residual)
+    names = re.findall(r"^(_Z\w*edge16t_kernelILb[01]ELb[01]ELb[01]ELb[01]E\w*):", text, re.M)
+    # layer-1 tiles by DMA + residual tiles | gathered from fp32 rows | from fp16 rows (no residual) | the last two on segment-
+    # aligned tiles (round 4: transposed output layer - the weight is then the B operand - and 8 segment-sum MFMAs on plain VGPRs)
+    assert len(names) == 5, names
     for name in names:
+        segt = "ELb1EEEv" in name  # edge16t_kernel<GATHER, PH, RES, SEGT = true>
         meta = text[text.index(".amdhsa_kernel " + name):]
         meta = meta[:meta.index(".end_amdhsa_kernel")]
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
@@ -136,15 +139,22 @@ def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path
         body = body[:body.index(".end_amdhsa_kernel")]
         lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
         mfma = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma_f32_16x16x32_bf16")]
-        assert len(mfma) == 256, (name, len(mfma))
+        assert len(mfma) == (264 if segt else 256), (name, len(mfma))
+        layers = []
         for i in mfma:
             ops = [o.strip() for o in lines[i].split(None, 1)[1].split(",")]
-            assert ops[1].startswith("a["), f"weight operand not in an AGPR: {lines[i]}"
+            if ops[1].startswith("a[") or ops[2].startswith("a["):
+                layers.append(i)
+        assert len(layers) == 256, f"{name}: {len(layers)} MFMAs take their weight operand from an AGPR"
+        if segt:  # team B's layer: activations as A (VGPR), weights as B (AGPR)
+            assert sum(1 for i in layers if lines[i].split(None, 1)[1].split(",")[2].strip().startswith("a[")) == 128, name
+            assert sum(1 for ln in lines if ln.startswith("v_add_f32_dpp") and "row_ror" in ln) == 4 * 32, name
         first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
-        assert not any(ln.startswith(("v_accvgpr_read", "v_accvgpr_write")) for ln in lines[first_barrier:]), name
+        assert not any(ln.startswith("v_accvgpr") for ln in lines[first_barrier:]), name
+        mfma = layers
         for phase in (mfma[:128], mfma[128:]):
             gaps = [b_ - a_ - 1 for a_, b_ in zip(phase, phase[1:])]
-            assert max(gaps) <= 12, (name, max(gaps))
+            assert max(gaps) <= (20 if segt else 12), (name, max(gaps))
 
 
 @pytest.mark.timeout(600)
