@@ -116,6 +116,11 @@ __device__ __forceinline__ void load_frags(bf16x8 (&bf)[8], const char* __restri
 __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
 }
+// The same instruction on fp16 operands (same rate, 11-bit significands): the middle layer of the segment-aligned team kernel,
+// whose B operand - relu of a sum of fp16 product rows - is then made with packed fp16 arithmetic and no conversion.
+__device__ __forceinline__ void mfma_a_f16(f32x4& acc, const bf16x8& w, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+}
 // The transposed product: the activations fragment is the A operand (rows = the 16 edges of a group), the resident weight
 // fragment the B operand (columns = 16 output features) - the same registers, the operands swapped - so the accumulator comes
 // out as lane (feature, q) x 4 edges: D^T.  Used where the next contraction is over EDGES (segment sums on the matrix cores).

@@ -90,7 +90,7 @@ __device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (fmaxf adds 
 //  * slots 28..31: the bias of group g + 1 into its accumulator set (LDS reads straight into the accumulators).
 // Two accumulator sets alternate (a caller that keeps all groups passes 4).  The pieces of the last group run at the end.
 // bias(dst, t): accumulator of row tile t <- bias;  piece(g, m, acc): m = 0 .. 27.
-template <int NSETS, bool TR = false, class Bias, class Piece>
+template <int NSETS, bool TR = false, bool F16 = false, class Bias, class Piece>
 __device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 (&w)[4][8], const char* __restrict__ hin, int lane,
                                            Bias bias, Piece piece) {
   // TR: ONE ring of 4 fragment registers instead of two alternating sets - the fragment of K-step ks is requested again (for
@@ -115,7 +115,8 @@ __device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 
         mfma_t(ac[t], fr[0][ks], w[t][4 * hh + ks]);  // (the transposed product, see mfma_t)
         if (t == 3 && h + 1 < 8) fr[0][ks] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + ks * 1024);
       } else {
-        mfma_a(ac[t], w[t][4 * hh + ks], fr[h & 1][ks]);
+        if constexpr (F16) mfma_a_f16(ac[t], w[t][4 * hh + ks], fr[h & 1][ks]);
+        else mfma_a(ac[t], w[t][4 * hh + ks], fr[h & 1][ks]);
         if (m16 < 4 && h + 1 < 8)
           fr[(h + 1) & 1][m16] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + m16 * 1024);
       }
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     const int i = pos & 7;
     return (pos & ~31) + 16 * (i >> 2) + 4 * ((pos >> 3) & 3) + (i & 3);
   };
+  // F16MID (segment-aligned form with the per-sample products as fp16 rows): layer 1 = relu(fp16 row + cached fp16 part) stays in
+  // packed fp16 arithmetic (a third of the instructions of widen / add / relu / round-to-bf16: the gather is team A's critical
+  // phase) and the middle layer runs on fp16 operands - W_mid's bf16 values are exact in fp16 (|w| >= 6e-5), converted once here
+  constexpr bool F16MID = SEGT && PH;
   bf16x8 wr[4][8];
   if (SEGT && team_b) {
 #pragma unroll
@@ -200,7 +205,21 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) wr[t][s] = *(const bf16x8*)(wsrc + ((size_t)(s * 16 + 4 * tw + t) * 64 + lane) * 16);
+      for (int s = 0; s < 8; ++s) {
+        wr[t][s] = *(const bf16x8*)(wsrc + ((size_t)(s * 16 + 4 * tw + t) * 64 + lane) * 16);
+        if (F16MID && !team_b) {  // (fragment by fragment: converting all 128 registers at once spills)
+          typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+          f16x8 h;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h[i] = (_Float16)(float)wr[t][s][i];
+          // (a value made by vector instructions is born in the VGPR class, and the allocator would then keep the weights there
+          //  and copy them in front of every MFMA: re-define it as an AGPR-class value here, once)
+          bf16x8 conv = __builtin_bit_cast(bf16x8, h), pinned;
+          asm volatile("" : "=a"(pinned) : "0"(conv));
+          wr[t][s] = pinned;
+          if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
   }
   if (threadIdx.x < 256) {
     float* par_w = (float*)(lds + kT_Par);
@@ -373,6 +392,24 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       x[2 * i + 1] = f32x4{(float)xh[i][4], (float)xh[i][5], (float)xh[i][6], (float)xh[i][7]};
     }
   };
+  // F16MID: one column pass of layer 1 in packed fp16 arithmetic: relu(row + cached part), capped at the largest fp16 (an
+  // overflowed sum would be +inf, then NaN under the matrix product), 8 bytes per unit straight into the B-operand slots
+  auto gather_finish_h = [&](const half8_t (&xh)[4], int cp) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    char* out = h1 + pslot(32 * cp + gcol);
+    const h4_t zero = h4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const h4_t cap = h4_t{(_Float16)65504.f, (_Float16)65504.f, (_Float16)65504.f, (_Float16)65504.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = u >> 1, e = u & 1;
+      const h4_t x4 = h4_t{xh[i][4 * e], xh[i][4 * e + 1], xh[i][4 * e + 2], xh[i][4 * e + 3]};
+      h4_t c4;
+      if (cp == 0) c4 = h4_t{zc[u][0][0], zc[u][0][1], zc[u][1][0], zc[u][1][1]};
+      else c4 = zc1[256 * u];
+      const h4_t hsum = __builtin_elementwise_min(__builtin_elementwise_max(x4 + c4, zero), cap);
+      *(h4_t*)(out + uslot(u)) = hsum;
+    }
+  };
   // gx: 32 registers of gathered rows in flight (fp32: pass 0 as 8 x f32x4; fp16: pass 0 in gx[0..3], pass 1 in gx[4..7])
   auto gather_issue0 = [&](TileId t, f32x4 (&gx)[8]) {
     if (t.eb != cached_eb) prep_chunk(t.eb);
@@ -386,7 +423,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   };
   auto gather_part1 = [&](TileId t, f32x4 (&gx)[8]) {
     const bool v0 = t.eb * kTileCols + gcol < a.n_edges;
-    if constexpr (PH) {
+    if constexpr (F16MID) {
+      half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
+      gather_finish_h(reinterpret_cast<half8_t(&)[4]>(gh[0]), 0);
+    } else if constexpr (PH) {
       half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
       f32x4 x[8];
       widen(x, reinterpret_cast<half8_t(&)[4]>(gh[0]));
@@ -400,7 +440,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   };
   auto gather_part2 = [&](TileId t, f32x4 (&gx)[8]) {
     const bool v1 = t.eb * kTileCols + 32 + gcol < a.n_edges;
-    if constexpr (PH) {
+    if constexpr (F16MID) {
+      half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
+      gather_finish_h(reinterpret_cast<half8_t(&)[4]>(gh[4]), 1);
+    } else if constexpr (PH) {
       half8_t(&gh)[8] = reinterpret_cast<half8_t(&)[8]>(gx);
       f32x4 x[8];
       widen(x, reinterpret_cast<half8_t(&)[4]>(gh[4]));
@@ -437,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       if (start) {
         const unsigned long long rest = (sm >> lane) >> 1;  // slot starts to the right of this one
         const int len = rest != 0ull ? __builtin_ctzll(rest) + 1 : __popcll(vm >> lane);
-        ((int*)(lds + kS_Dsl))[ring * kTileCols + slot] = t.b * a.n_dst + d;
+        ((int*)(lds + kS_Dsl))[ring * kTileCols + slot] = d;  // (row within a batch element: the table serves the whole chunk)
         ((float*)(lds + kS_Cnt))[ring * kTileCols + slot] = (float)len;
       }
       if (lane == 0) ((int*)(lds + kS_Nsl))[ring] = __popcll(sm);
@@ -538,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       prep_dma_issue(t_next);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // (SEGT: the slot tables depend on the edge block only - one table per unit of bc tiles, in ring entry (tile / bc) & 3)
     if (tw == 0) publish_dst(t_next, 0);
     TileId t_cur = t_next, t_prev = t_next;
 #pragma unroll 1
@@ -556,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         f32x4 acc[2][4];
         unsigned pk[8];  // bf16 pairs of the group being packed: row tile t -> pk[2 t], pk[2 t + 1]
         if (use_prio) __builtin_amdgcn_s_setprio(1);
-        team_layer<2>(
+        team_layer<2, false, F16MID>(
             acc, wr, h1, lane,
             [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + 16 * t); },  // b_mid
             [&](int g, int m, f32x4 (&ac)[4]) {
@@ -596,7 +640,11 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       if (has_next) {
         if (GATHER && !t_skip_a2) gather_part2(t_next, gx);
         GW_TS(10)
-        if (tw == 0) publish_dst(t_next, (s + 1) & 3);
+        if constexpr (SEGT) {
+          if (tw == 0 && (s + 1) % a.bc == 0) publish_dst(t_next, ((s + 1) / a.bc) & 3);
+        } else {
+          if (tw == 0) publish_dst(t_next, (s + 1) & 3);
+        }
         if (!GATHER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       GW_TS(11)
@@ -632,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         team_barrier();  // (alpha) LayerNorm partial sums of tile s - 1 visible
         GW_TS(1)
         if (s >= 1 && !t_skip_ln) {
-          const int ring = (s - 1) & 3;
+          const int ring = ((s - 1) / a.bc) & 3;  // slot tables of the unit (edge block) tile s - 1 belongs to
           // LayerNorm statistics: lane (j, q) combines the four waves' partial sums of ONE edge, 16 (j >> 2) + 4 q + (j & 3),
           // and parks (rstd, -mean rstd) in the wave's own slot; each lane then reads those of its 16 edges back (a wave's
           // LDS accesses complete in order: no barrier)
@@ -705,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
             const int slot = 16 * nt + j;
             if (slot < nslots && GW_SKIP(a) != 1) {
               // agg[row][position p0 + 4 t + r] = gamma sum + count beta (parameters in position order: one float4 per t)
-              const size_t row = (size_t)dsl[ring * kTileCols + slot];
+              const size_t row = (size_t)(t_prev.b * a.n_dst + dsl[ring * kTileCols + slot]);
               const float cnt = cntf[ring * kTileCols + slot];
               const int p0 = fresh(64 * tw + 16 * q);
 #pragma unroll
