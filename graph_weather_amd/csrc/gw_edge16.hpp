@@ -131,11 +131,12 @@ __device__ __forceinline__ void mfma_t(f32x4& acc, const bf16x8& b, const bf16x8
 // x + (x of the lane N places further round this lane's row of 16): one VALU instruction with a DPP operand (no LDS; written as
 // asm because the builtin comes out as v_mov_b32_dpp into a zeroed register + the add).  A DPP operand must not have been written
 // by one of the two preceding VALU instructions (asm is opaque to the hazard recogniser): callers keep producer and use apart.
-template <int N>
+template <int N, bool WAIT = false>
 __device__ __forceinline__ float add_row_ror(float x) {
   float y;
-  // (the first step reads sums the compiler's own VALU code produced - it may schedule that producer right in front: two wait states)
-  if constexpr (N == 8) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+  // (WAIT: the operand may have been produced by the instruction right in front - two wait states)
+  if constexpr (N == 8 && WAIT) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+  else if constexpr (N == 8) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
   else if constexpr (N == 4) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
   else if constexpr (N == 2) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
   else asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));

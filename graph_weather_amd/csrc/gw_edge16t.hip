@@ -58,6 +58,8 @@ constexpr int kS_Lnc = kT_Stage + 2048;      // float2[4 team-B waves][64 edges]
 constexpr int kS_ParT = kT_Stage + 4096;     // float4[4 waves][16 lanes][4 t]: b_out of a lane's feature of tile t, replicated x 4
 constexpr int kS_ParP = kT_Stage + 8192;     // float[2][256]: gamma, beta in the POSITION order of a destination row
 constexpr int kS_Cnt = kT_Stage + 10240;     // float[4][64]: edges of each destination slot
+constexpr int kS_Smat = kT_Stage + 12288;    // uint4[4 ring][4 slot groups][2 halves][64 lanes]: the B operand S of the segment sums
+static_assert(kS_Smat + 4 * 4 * 2 * 64 * 16 <= kT_Stage + kTileCols * kStageLd * 4, "the slot tables fit the staging area");
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
@@ -90,7 +92,11 @@ __device__ __forceinline__ float relu1(float x) {  // one v_max_f32 (fmaxf adds 
 //  * slots 28..31: the bias of group g + 1 into its accumulator set (LDS reads straight into the accumulators).
 // Two accumulator sets alternate (a caller that keeps all groups passes 4).  The pieces of the last group run at the end.
 // bias(dst, t): accumulator of row tile t <- bias;  piece(g, m, acc): m = 0 .. 27.
-template <int NSETS, bool TR = false, bool F16 = false, class Bias, class Piece>
+// BIAS_SLOT: first of the 4 consecutive filler slots of group g in which the bias of group g + 1 is read from LDS into its
+// accumulator set.  The default 28 leaves 4 MFMAs (~70 cycles) to the first use - less than an LDS round trip under load, i.e.
+// a stall per group (measured with the partner team parked: 128 MFMAs took 3.1 k cycles instead of 2.2 k); callers whose
+// epilogue pieces are done with that set earlier (or that keep all 4 sets) name an earlier slot.
+template <int NSETS, bool TR = false, bool F16 = false, int BIAS_SLOT = 28, class Bias, class Piece>
 __device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 (&w)[4][8], const char* __restrict__ hin, int lane,
                                            Bias bias, Piece piece) {
   // TR: ONE ring of 4 fragment registers instead of two alternating sets - the fragment of K-step ks is requested again (for
@@ -121,7 +127,7 @@ __device__ __forceinline__ void team_layer(f32x4 (&acc)[NSETS][4], const bf16x8 
           fr[(h + 1) & 1][m16] = *(const bf16x8*)(p0 + ((h + 1) >> 1) * 8192 + ((h + 1) & 1) * 4096 + m16 * 1024);
       }
       if (g > 0 && slot >= 2 && slot < 30) piece(g - 1, slot - 2, acc[(g - 1) % NSETS]);
-      if (slot >= 28 && g + 1 < 4) bias(acc[(g + 1) % NSETS][slot - 28], slot - 28);
+      if (slot >= BIAS_SLOT && slot < BIAS_SLOT + 4 && g + 1 < 4) bias(acc[(g + 1) % NSETS][slot - BIAS_SLOT], slot - BIAS_SLOT);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -483,7 +489,31 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         ((int*)(lds + kS_Dsl))[ring * kTileCols + slot] = d;  // (row within a batch element: the table serves the whole chunk)
         ((float*)(lds + kS_Cnt))[ring * kTileCols + slot] = (float)len;
       }
-      if (lane == 0) ((int*)(lds + kS_Nsl))[ring] = __popcll(sm);
+      const int nsl_ = __popcll(sm);
+      if (lane == 0) ((int*)(lds + kS_Nsl))[ring] = nsl_;
+      // S[edge][slot] as the B operand of the segment-sum product, once per edge block for all four team-B waves and all tiles
+      // of the unit: lane (n, qq) of slot group nt, half h: 8 K entries = edges 4 qq + r of groups 2 h, 2 h + 1 -> 1.0 (bf16)
+      // where the edge's slot is 16 nt + n.  (The slot bytes were written by this wave just above: LDS keeps a wave's order.)
+      {
+        const unsigned* const sw = (const unsigned*)(lds + kS_Slot) + ring * 16;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* const sm_out = (u32x4*)(lds + kS_Smat) + ring * (4 * 2 * 64);
+        const int n_ = lane & 15, qq = lane >> 4;
+        for (int nt = 0; nt * 16 < nsl_; ++nt) {
+          const unsigned me = (unsigned)(16 * nt + n_);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const unsigned w0 = sw[8 * h + qq], w1 = sw[8 * h + 4 + qq];
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              pk[i] = ((((w0 >> (16 * i)) & 255u) == me) ? 0x3F80u : 0u) | ((((w0 >> (16 * i + 8)) & 255u) == me) ? 0x3F800000u : 0u);
+              pk[2 + i] = ((((w1 >> (16 * i)) & 255u) == me) ? 0x3F80u : 0u) | ((((w1 >> (16 * i + 8)) & 255u) == me) ? 0x3F800000u : 0u);
+            }
+            sm_out[(nt * 2 + h) * 64 + lane] = pk;
+          }
+        }
+      }
     } else {
       gdl[ring * kTileCols + lane] = kr < a.n_edges ? t.b * a.n_dst + ldgi(a.dst + kr) : -1;
     }
@@ -595,23 +625,40 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       GW_TS(0)
       team_barrier();  // (alpha) Hbuf1 of tile s complete; staged tile s - 2 free
       GW_TS(1)
+      const bool has_next = s + 1 < n;
+      // F16MID: both column passes of the next tile's rows are 32 registers - requested HERE, in front of the middle layer, they
+      // have the whole MFMA phase to arrive (requested behind it, the first pass was still under way 1.5 k cycles into half 2)
+      if (F16MID && has_next) gather_issue0(t_next, gx);
       if (s < n) {
         // ---- middle layer of tile s: Hbuf1 -> Hbuf2 ----
         f32x4 acc[2][4];
         unsigned pk[8];  // bf16 pairs of the group being packed: row tile t -> pk[2 t], pk[2 t + 1]
         if (use_prio) __builtin_amdgcn_s_setprio(1);
-        team_layer<2, false, F16MID>(
+        team_layer<2, false, F16MID, 18>(  // (the pieces read the accumulators in slots 2..17 only)
             acc, wr, h1, lane,
             [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + 16 * t); },  // b_mid
             [&](int g, int m, f32x4 (&ac)[4]) {
               // m = 0..15: relu of one accumulator value; 16..23: bf16 pack of a pair; 24 / 25: the 16-byte store of K-step s0 / s0 + 1
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-              if (m < 16) {
+              if constexpr (true) {
+                // relu on the PACKED pairs: a negative bf16 is a negative 16-bit integer, so max(., 0) per half clears it and leaves
+                // the others as they are - 8 instead of 16 instructions per group
+                if (m < 16) {
+                  if ((m & 1) == 0) {
+                    const int pi = m >> 1;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[pi]) : "v"(ac[pi >> 1][2 * (pi & 1)]), "v"(ac[pi >> 1][2 * (pi & 1) + 1]));
+                  } else {
+                    const int pi = m >> 1;
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[pi]) : "v"(pk[pi]));
+                  }
+                }
+              } else if (m < 16) {
                 ac[m >> 2][m & 3] = relu1(ac[m >> 2][m & 3]);
               } else if (m < 24) {
                 const int pi = m - 16;
                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[pi]) : "v"(ac[pi >> 1][2 * (pi & 1)]), "v"(ac[pi >> 1][2 * (pi & 1) + 1]));
-              } else if (m == 24) {
+              }
+              if (m == 24) {
                 *(u32x4*)(h2 + ((g * 8 + s0) * 64 + fresh(lane)) * 16) = u32x4{pk[0], pk[1], pk[2], pk[3]};
               } else if (m == 25) {
                 *(u32x4*)(h2 + ((g * 8 + s0 + 1) * 64 + fresh(lane)) * 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
@@ -620,8 +667,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         __builtin_amdgcn_s_setprio(0);
         GW_TS(2)
       }
-      const bool has_next = s + 1 < n;
-      if (GATHER && has_next) gather_issue0(t_next, gx);  // (registers only: Hbuf1 is still being read by the other waves)
+      if (GATHER && !F16MID && has_next) gather_issue0(t_next, gx);  // (registers only: Hbuf1 is still being read by the other waves)
       GW_TS(6)
       team_barrier();  // (beta) Hbuf2 of tile s and the staged tile s - 1 complete; Hbuf1 free
       GW_TS(7)
@@ -666,7 +712,8 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       const f32x4* const parT = (const f32x4*)(lds + kS_ParT);   // b_out of the lane's features
       const float* const parP = (const float*)(lds + kS_ParP);    // gamma, beta in position order
       const float* const cntf = (const float*)(lds + kS_Cnt);
-      const unsigned* const slotw = (const unsigned*)(lds + kS_Slot);
+      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+      const u32x4s* const smat = (const u32x4s*)(lds + kS_Smat);
       const int* const dsl = (const int*)(lds + kS_Dsl);
       const int* const nsl = (const int*)(lds + kS_Nsl);
       TileId t_next = tile_at(0), t_cur = t_next, t_prev = t_next;
@@ -703,10 +750,17 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
           // SUM instead of one per value and no registers in this phase.
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           u32x4 ypk[4][2];
+          // ((rstd, -mean rstd) of the next group requested before this group's arithmetic: one LDS latency, not four)
+          f32x4 gnx0 = *(const f32x4*)(lnc + (tw * kTileCols + 4 * fresh(q)) * 2);
+          f32x4 gnx1 = *(const f32x4*)(lnc + (tw * kTileCols + 4 * fresh(q) + 2) * 2);
 #pragma unroll
           for (int g = 0; g < kGroups; ++g) {
-            const f32x4 gab0 = *(const f32x4*)(lnc + (tw * kTileCols + 16 * g + 4 * fresh(q)) * 2);      // (rstd, -mean rstd) x edges 4 q + 0, 1
-            const f32x4 gab1 = *(const f32x4*)(lnc + (tw * kTileCols + 16 * g + 4 * fresh(q) + 2) * 2);  // ... 4 q + 2, 3
+            const f32x4 gab0 = gnx0;  // (rstd, -mean rstd) x edges 4 q + 0, 1
+            const f32x4 gab1 = gnx1;  // ... 4 q + 2, 3
+            if (g + 1 < kGroups) {
+              gnx0 = *(const f32x4*)(lnc + (tw * kTileCols + 16 * (g + 1) + 4 * fresh(q)) * 2);
+              gnx1 = *(const f32x4*)(lnc + (tw * kTileCols + 16 * (g + 1) + 4 * fresh(q) + 2) * 2);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const float n0 = fmaf(o[g][t][0], gab0[0], gab0[1]), n1 = fmaf(o[g][t][1], gab0[2], gab0[3]);
@@ -720,23 +774,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
           const int nslots = __builtin_amdgcn_readfirstlane(nsl[ring]);
 #pragma unroll 1
           for (int nt = 0; nt * 16 < nslots; ++nt) {
-            // S[edge][slot]: this lane's column = slot 16 nt + j, its 8 K entries of half h = edges 4 q + r of groups 2 h, 2 h + 1
-            const unsigned me = (unsigned)(16 * nt + j);
+            // S[edge][slot] of slot group nt (made once per edge block by the publishing wave of team A)
             u32x4 sb[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const unsigned w0 = slotw[ring * 16 + 8 * h + fresh(q)];
-              const unsigned w1 = slotw[ring * 16 + 8 * h + 4 + fresh(q)];
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const unsigned lo0 = ((w0 >> (16 * i)) & 255u) == me ? 0x3F80u : 0u;
-                const unsigned hi0 = ((w0 >> (16 * i + 8)) & 255u) == me ? 0x3F800000u : 0u;
-                const unsigned lo1 = ((w1 >> (16 * i)) & 255u) == me ? 0x3F80u : 0u;
-                const unsigned hi1 = ((w1 >> (16 * i + 8)) & 255u) == me ? 0x3F800000u : 0u;
-                sb[h][i] = lo0 | hi0;
-                sb[h][2 + i] = lo1 | hi1;
-              }
-            }
+            sb[0] = smat[((ring * 4 + nt) * 2 + 0) * 64 + fresh(lane)];
+            sb[1] = smat[((ring * 4 + nt) * 2 + 1) * 64 + fresh(lane)];
             // (asm MFMAs on plain vector registers: the builtin lets the allocator put these accumulators into the AGPR half
             //  and rotate the resident weights out of their way; wait states as in layer_group - inline asm is opaque to the
             //  hazard recogniser; an accumulator is touched by every 4th MFMA)
@@ -783,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
           // sums and sums of squares over this wave's 64 features: 4 row tiles in registers, then the 16 feature lanes of the row ----
           float s1[4], s2[4];
           if (use_prio) __builtin_amdgcn_s_setprio(1);
-          team_layer<4, true>(
+          team_layer<4, true, false, 4>(  // (four accumulator sets: the next group's is free - its bias is read 28 MFMAs ahead)
               o, wr, h2, lane,
               [&](f32x4& dst, int t) { dst = parT[(tw * 16 + fresh(j)) * 4 + t]; },  // b_out of the lane's feature of tile t x 4 edges
               [&](int g, int mm, f32x4 (&ac)[4]) {
@@ -798,7 +839,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
                   for (int op = lo; op < hi; ++op) {
                     const int step = op >> 3, v = op & 7;
                     float& x = v < 4 ? s1[v] : s2[v - 4];
-                    x = step == 0 ? add_row_ror<8>(x) : (step == 1 ? add_row_ror<4>(x) : (step == 2 ? add_row_ror<2>(x) : add_row_ror<1>(x)));
+                    // (first step: the sums come from the compiler's own VALU code.  Inside the layer a whole filler slot lies
+                    //  between producer and use; in the tail after the last MFMA - group 3 - nothing does: wait states there)
+                    x = step == 0 ? (g == 3 ? add_row_ror<8, true>(x) : add_row_ror<8>(x))
+                                  : (step == 1 ? add_row_ror<4>(x) : (step == 2 ? add_row_ror<2>(x) : add_row_ror<1>(x)));
                   }
                   if (mm == 27 && j == 0) {
                     *(f32x4*)(ln1 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s1[0], s1[1], s1[2], s1[3]};
@@ -907,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         // ---- output layer of tile s: Hbuf2 -> registers, LayerNorm partial sums (per group, in the shadow of the next group) ----
         float s1 = 0.f, s2 = 0.f;
         if (use_prio) __builtin_amdgcn_s_setprio(1);
-        team_layer<4>(
+        team_layer<4, false, false, 4>(  // (four accumulator sets: the next group's bias is read 28 MFMAs ahead of its first use)
             o, wr, h2, lane,
             [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + 256 + 16 * t); },  // b_out
             [&](int g, int m, f32x4 (&ac)[4]) {
