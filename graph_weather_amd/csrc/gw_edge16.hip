@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
 #pragma unroll
     for (int p = 0; p < 2; ++p)
       if (p < a.n_proj) {
-        const int r = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
+        int r = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
+        r = r < 0 ? 0 : r;  // (segment-aligned tiles: padding columns carry dst = -1; their results are never summed)
         const size_t ro = ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
         if (a.p_half[p]) {  // node products as fp16 rows (GW_LAYOUT_ROWS_F16): 8 bytes per row tile and lane
           typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         gidx[cp][p] = p < a.n_proj ? (a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k)) : 0;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) gidx[cp][p] = gidx[cp][p] < 0 ? 0 : gidx[cp][p];  // (padding columns of segment-aligned tiles: dst = -1)
     }
   };
   // GATHER: layer 1 of a tile = relu(b1 + sum_p P_p[row_p]) -> bf16 -> Hbuf1[buffer], at the top of the tile.  The rows it
@@ -404,7 +407,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void edge16_kernel(const Edge16Arg
     int gd_mine = -1;  // wave 0: destination row of column `lane` (written to LDS with the staged tile)
     if (wave == 0) {
       const int kr = k0 + lane;
-      gd_mine = kr < a.n_edges ? b * a.n_dst + ldgi(a.dst + kr) : -1;
+      const int dk = kr < a.n_edges ? ldgi(a.dst + kr) : -1;
+      gd_mine = dk >= 0 ? b * a.n_dst + dk : -1;  // (dst < 0: a padding column of segment-aligned tiles - never summed)
     }
 
     // ---- residual: requested here, used after barrier (3) - its latency passes under the middle layer, and it is back
@@ -779,9 +783,15 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     return set_error(GW_E_UNSUPPORTED, "edge16: fp16 product rows with all operands projected need the team-pipelined kernel (atomics mode)");
   if (no_res && team_only)
     return set_error(GW_E_UNSUPPORTED, "edge16: an edge update without residual runs on the team-pipelined kernel only (atomics mode)");
-  if (a.seg_tiles && (team_only || raw_e || !fuse_gather || !no_res))
-    return set_error(GW_E_UNSUPPORTED, "edge16: segment-aligned tiles run on the team-pipelined kernel (gathered layer 1, no residual)");
-  if (no_res || (any_half && !raw_e) || a.seg_tiles) {
+  // segment-aligned tiles: (a) every operand projected, no residual, no e' -> the gather form of the team kernel (agg rows WRITTEN);
+  // (b) raw edge tiles + per-sample residual tiles -> layer-1 kernel + edge16p_kernel (agg rows += in place: the running sum of
+  // the processor stack); (c) every operand projected with a (batch-shared) residual - the first processor block - runs on
+  // the lock-step kernel, which only has to skip the padding columns (agg += by atomics on the caller's zero fill)
+  if (a.seg_tiles && (team_only || !fuse_gather || a.res_ptr != nullptr || e_out != nullptr || (raw_e && (no_res || a.res_tiles_shared)) ||
+                      (a.agg_bf16k && (raw_e || !no_res))))
+    return set_error(GW_E_UNSUPPORTED, "edge16: segment-aligned tiles take projected operands without residual, or bf16 edge tiles "
+                                       "(operand and residual), atomics mode, e' as tiles or dropped");
+  if (no_res || (any_half && !raw_e)) {
     int n_dyn = 0;
     for (int p = 0; p < a.n_proj; ++p) n_dyn += a.p_rows_pb[p] != 0 ? 1 : 0;
     if (n_dyn != 1)
@@ -798,6 +808,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
     hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)a.neb), dim3(256), 0, (hipStream_t)stream, a);  // one workgroup per edge block
     if (int rc = check_launch("edge16_gather_kernel launch")) return rc;
   }
+  if (a.seg_tiles && raw_e) return edge16p_launch(&a, n_wg, stream);  // (b): the processor form on segment-aligned tiles
   // launch 2: the resident layers
   const bool rt = a.res_tiles != nullptr;
   const bool ga = !raw_e && fuse_gather;  // layer 1 gathered inside the resident kernel

@@ -151,6 +151,8 @@ size_t edge16_workspace_needed(int32_t batch, int32_t n_edges, const gw_operand*
 // team-pipelined form of the resident kernel (gw_edge16t.hip): residual as bf16 tiles, atomics mode; gather = layer 1 is a
 // gather-add done inside the kernel (every operand projected), else the layer-1 tiles come from the workspace
 int edge16t_launch(const void* edge16_args /* gw16::Edge16Args */, bool gather, int n_wg, void* stream);
+// processor-block form on segment-aligned tiles (gw_edge16p.hip): layer-1 tiles from the workspace, residual tiles, agg += in place
+int edge16p_launch(const void* edge16_args /* gw16::Edge16Args */, int n_wg, void* stream);
 int edge16_rows_to_tiles(int32_t batch, int32_t n_edges, const float* rows, int32_t rows_per_batch, int32_t ld, void* tiles,
                          void* stream);
 

@@ -1119,12 +1119,15 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   const bool seg = (flags & GW_EDGE_SEGMENT_TILES) != 0;
   if ((flags & GW_EDGE_AGG_BF16K) && !seg) return fail(GW_E_BADARG, "gw_edge_update_forward: GW_EDGE_AGG_BF16K comes with GW_EDGE_SEGMENT_TILES");
   if (seg) {
-    const bool all_proj = (x_src->k == 0 || x_src->projected) && (x_dst->k == 0 || x_dst->projected) && (e_in->k == 0 || e_in->projected);
-    if (!no_res || !all_proj || det || n_edges % 64 != 0 || !gw::edge16_eligible(x_src, x_dst, e_in, w))
+    const size_t ws_seg = gw::edge16_eligible(x_src, x_dst, e_in, w) ? gw::edge16_workspace_needed(batch, n_edges, e_in, false) : 0;
+    if (det || save || n_edges % 64 != 0 || !gw::edge16_eligible(x_src, x_dst, e_in, w) || (e_out_any && !tiles_out) ||
+        (!no_res && e_res->layout != GW_LAYOUT_EDGE_TILES_BF16) || (ws_seg > 0 && (!workspace || workspace_bytes < ws_seg)))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: segment-aligned tiles (GW_EDGE_SEGMENT_TILES) are implemented for the bf16 "
-                                    "path with resident weights: every operand projected, no residual, atomics mode, n_edges a "
-                                    "multiple of 64");
-    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, nullptr, nullptr, agg, n_dst, workspace, flags, stream);
+                                    "path with resident weights: projected node operands, residual none or bf16 edge tiles, e' none "
+                                    "or bf16 edge tiles, atomics mode, n_edges a multiple of 64, the workspace of "
+                                    "gw_edge_update_workspace_bytes");
+    return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, nullptr, tiles_out ? e_out_any : nullptr, agg, n_dst,
+                             workspace, flags, stream);
   }
   const size_t ws16 = gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");

@@ -107,7 +107,7 @@ class GraphPlan:
                     dst_p[pos] = dst
                     dev = self.src.device
                     st = SegTiles(torch.from_numpy(src_p).to(dev), torch.from_numpy(dst_p).to(dev), torch.from_numpy(pos).to(dev),
-                                  n_pad, bool(starts.size == self.n_dst))
+                                  n_pad, bool(starts.size == self.n_dst), int(np.bincount(tile_of_seg).max()))
             self._seg_tiles = (st,)
         return self._seg_tiles[0]
 
@@ -123,12 +123,20 @@ class SegTiles:
     pos: torch.Tensor  # int64 [E]: padded position of destination-sorted edge i
     n_pad: int
     complete: bool  # every destination row has at least one edge
+    max_slots: int = 64  # most destinations in one tile (the processor form of the kernels takes up to 16)
 
     def pad_rows(self, rows: torch.Tensor) -> torch.Tensor:
         """A per-edge table [E, w] in destination-sorted order -> [n_pad, w] in padded order (zero rows in padding columns)."""
         out = rows.new_zeros((self.n_pad,) + tuple(rows.shape[1:]))
         out[self.pos] = rows
         return out
+
+    def pad_batched_rows(self, rows: torch.Tensor, batch: int) -> torch.Tensor:
+        """Per-sample tables [batch * E, w] -> [batch * n_pad, w]."""
+        e = rows.shape[0] // batch
+        out = rows.new_zeros((batch, self.n_pad) + tuple(rows.shape[1:]))
+        out[:, self.pos] = rows.reshape((batch, e) + tuple(rows.shape[1:]))
+        return out.reshape((batch * self.n_pad,) + tuple(rows.shape[1:]))
 
 
 def plan_from_coo(src: np.ndarray, dst: np.ndarray, n_src: int, n_dst: int,

@@ -112,6 +112,7 @@ def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
                 getattr(m, attr).clear()
         if hasattr(m, "_e0_cache"):
             m._e0_cache = None
+            m._e0_seg_cache = None
     return module
 
 
@@ -312,7 +313,7 @@ class GraphNetBlock(nn.Module):
     def run(self, batch: int, plan: GraphPlan, x_src: Feed, x_dst: Feed, e_in: Feed, e_res: torch.Tensor, e_res_rows_pb: int,
             x_node: Feed, x_res: Optional[torch.Tensor], x_res_rows_pb: int, want_edges: bool, device,
             tag: Optional[str] = None, agg_zeroed: Optional[torch.Tensor] = None, post_w=None, post_zero: bool = False,
-            post_half: bool = False, head=None, seg=None):
+            post_half: bool = False, head=None, seg=None, agg_acc: Optional[torch.Tensor] = None):
         """One message-passing block on a shared graph: e' (optional), x' for all ``batch * plan.n_dst`` rows.
         Inputs may be raw rows, rows pre-multiplied by their layer-1 weight slice, or zeros (see ``Feed``).
         ``agg_zeroed``: an aggregate buffer the caller has already had zero-filled (by the projection launch).
@@ -323,7 +324,9 @@ class GraphNetBlock(nn.Module):
         ``seg`` (bf16 inference, no residual, no e'): the plan's segment-aligned tiles (``GraphPlan.seg_tiles()``) - the edge update
         runs on the padded edge list (batch-shared per-edge operands must be in padded order, ``SegTiles.pad_rows``), writes the
         aggregate with plain stores as bf16 rows in the K order the node update's matrix product reads (a quarter of the bytes
-        of the fp32 round trip; no zero fill when every destination has an edge)."""
+        of the fp32 round trip; no zero fill when every destination has an edge).  ``seg`` with ``agg_acc`` (a processor block): the
+        edge update adds its segment sums onto ``agg_acc`` in place - the previous block's aggregate (include/gw_amd.h:
+        GW_EDGE_SEGMENT_TILES); edge tiles then cover the padded list, and no next aggregate is zero-filled."""
         n_dst, n_edges = plan.n_dst, plan.num_edges
         if _autograd_on(self, x_src.tensor, x_dst.tensor, e_in.tensor, e_res, x_node.tensor, x_res):
             agg, e_out = ag.edge_update(self.edge_model.edge_mlp, plan, batch, (x_src.spec(), x_dst.spec(), e_in.spec()),
@@ -331,7 +334,12 @@ class GraphNetBlock(nn.Module):
             x_new = ag.node_update(self.node_model.node_mlp, batch * n_dst, n_dst, x_node.spec(), x_node.tensor, x_res,
                                    x_res_rows_pb, agg)
             return x_new, e_out
-        if seg is not None:
+        if seg is not None and agg_acc is not None:
+            if want_edges not in (False, "tiles"):
+                raise RuntimeError("graph_weather_amd: a processor block on segment-aligned tiles hands e' over as edge tiles")
+            agg = agg_acc
+            n_edges = seg.n_pad  # (the tile buffers cover the padded list)
+        elif seg is not None:
             if want_edges or e_res is not None:
                 raise RuntimeError("graph_weather_amd: segment-aligned tiles come without residual and without e'")
             agg = (torch.empty if seg.complete else torch.zeros)((batch * n_dst, 256), dtype=torch.bfloat16, device=device)
@@ -357,6 +365,8 @@ class GraphNetBlock(nn.Module):
             return y, e_out
         if post_w is not None:
             next_agg = torch.empty((batch * n_dst, 256), dtype=torch.float32, device=device) if post_zero else None
+            if seg is not None and agg_acc is not None and not post_zero:
+                next_agg = None
             x_new, posts = ops.node_update_forward(self.node_model.node_mlp.packed(), batch * n_dst, n_dst, x_node.operand(), res_x,
                                                    Operand(agg, n_dst, 256), post_w=post_w, zero_rows=next_agg, post_half=post_half)
             return x_new, e_out, posts, next_agg
@@ -410,6 +420,7 @@ class GraphProcessor(nn.Module):
         self.streams = 0  # HIP streams of the fused inference forward: 0 = automatic (see forward_streams), 1 = one stream
         self._plan_cache = None
         self._e0_cache = None
+        self._e0_seg_cache = None
         self._side_streams = {}
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
@@ -486,6 +497,32 @@ class GraphProcessor(nn.Module):
         if len(self.blocks):
             self._shared_e0(self.blocks[0], e, plan.num_edges)
 
+    def _seg_for(self, plan: GraphPlan):
+        """The plan's segment-aligned tiles when the whole stack can run on them (bf16 inference with the resident kernels in
+        every block, atomics mode, at most 16 destinations per tile: csrc/gw_edge16p.hip), else None."""
+        if len(self.blocks) == 0 or plan.num_edges == 0:
+            return None
+        for blk in self.blocks:
+            m = blk.edge_model.edge_mlp
+            if m.compute_dtype != torch.bfloat16 or blk.node_model.node_mlp.compute_dtype != torch.bfloat16 or blk.deterministic:
+                return None
+            pm = m.packed()
+            if pm.n_mid != 1 or pm.ln_width != 0 or pm.gamma is None:
+                return None
+        seg = plan.seg_tiles()
+        return seg if (seg is not None and seg.max_slots <= 16) else None
+
+    def _shared_e0_seg(self, blk, e_cur: torch.Tensor, seg):
+        """(We . e in padded order, e as one shared set of bf16 edge tiles over the padded list) of batch-independent edge
+        features on segment-aligned tiles, cached per (e, weights)."""
+        key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key(), seg.n_pad)
+        hit = getattr(self, "_e0_seg_cache", None)
+        if hit is None or hit[0] != key or hit[3] is not e_cur:
+            pe = self._shared_e0(blk, e_cur, int(e_cur.shape[0]))[1]
+            e_pad = seg.pad_rows(e_cur)
+            self._e0_seg_cache = (key, seg.pad_rows(pe), ops.edge_rows_to_tiles(e_pad, 1, seg.n_pad, seg.n_pad), e_cur)
+        return self._e0_seg_cache[1], self._e0_seg_cache[2]
+
     def _shared_e0(self, blk, e_cur: torch.Tensor, n_edges: int):
         """(We . e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights)."""
         mlp_e = blk.edge_model.edge_mlp
@@ -509,6 +546,9 @@ class GraphProcessor(nn.Module):
         train = _autograd_on(self, x, e)
         carried = None if train else pre_proj  # (P_s, P_d, zeroed aggregate) made by the previous node update
         tail = None
+        seg = None if (train or want_edges or lo != 0) else self._seg_for(plan)
+        if seg is not None and not shared and e_cur.dtype != torch.uint8:
+            e_cur = ops.edge_rows_to_tiles(seg.pad_batched_rows(e_cur.contiguous(), batch), batch, seg.n_pad, seg.n_pad)
         for i in range(lo, hi):
             blk = self.blocks[i]
             last = i == hi - 1
@@ -533,6 +573,8 @@ class GraphProcessor(nn.Module):
             if shared:
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
+                elif seg is not None:
+                    pe = self._shared_e0_seg(blk, e_cur, seg)[0]
                 else:
                     pe = self._shared_e0(blk, e_cur, n_edges)[1]
                 e_in = Feed(pe, 0, "proj")
@@ -553,6 +595,8 @@ class GraphProcessor(nn.Module):
                              and npk.gamma is not None)
             out_kind = "tiles" if (tiled and need_e and nxt_tiled) else need_e
             e_res = self._e0_cache[3] if (shared and tiled) else e_cur
+            if seg is not None and shared:
+                e_res = self._shared_e0_seg(blk, e_cur, seg)[1]
             # what the node update of this block also produces (inference): the next block's layer-1 node products
             post_w, post_zero, post_half = None, False, False
             if not train:
@@ -561,7 +605,8 @@ class GraphProcessor(nn.Module):
                     nxt_mlp = self.blocks[i + 1].edge_model.edge_mlp
                     nxt = nxt_mlp.packed()
                     if nxt.weight_dtype == pm_n.weight_dtype and i + 1 < hi:
-                        post_w, post_zero = [nxt.w1[0], nxt.w1[1]], True
+                        # (segment-aligned stack: the next block adds onto this block's aggregate - nothing to zero-fill)
+                        post_w, post_zero = [nxt.w1[0], nxt.w1[1]], seg is None
                         # block i + 1 >= 1 reads per-sample edge tiles, i.e. runs its layer 1 in the bf16 layer-1 kernel, which
                         # gathers these products once per edge: hand them over as fp16 rows
                         post_half = (nxt_mlp.compute_dtype == torch.bfloat16 and nxt.n_mid == 1 and nxt.ln_width == 0
@@ -569,13 +614,17 @@ class GraphProcessor(nn.Module):
                 elif tail_w is not None and all(w_.dtype == pm_n.w_out.dtype for w_ in tail_w):
                     post_w = list(tail_w)
                     post_half = bool(tail_half)
+            if seg is not None and agg_buf is None:
+                agg_buf = torch.zeros((batch * n, 256), dtype=torch.float32, device=x.device)
             res = blk.run(batch, plan, Feed(ps, n, "proj"), Feed(pd, n, "proj"), e_in, e_res, 0 if shared else n_edges,
                           Feed(x, n, "raw"), x, n, out_kind, x.device, tag="processor_edge", agg_zeroed=agg_buf,
-                          post_w=post_w, post_zero=post_zero, post_half=post_half)
+                          post_w=post_w, post_zero=post_zero, post_half=post_half, seg=seg, agg_acc=agg_buf if seg is not None else None)
             x, e_new = res[0], res[1]
             if post_w is not None:
                 if post_zero:
                     carried = (res[2][0], res[2][1], res[3])
+                elif seg is not None and i + 1 < hi:
+                    carried = (res[2][0], res[2][1], agg_buf)  # the running aggregate goes on to the next block
                 else:
                     tail = res[2]
             if e_new is not None:

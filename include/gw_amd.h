@@ -77,9 +77,16 @@ extern "C" {
  * are a PADDED edge list of n_edges = 64 T entries in which no destination's run of edges crosses a multiple of 64 ("segment-
  * aligned tiles": assimilator_decoder.py:92-103 gives every grid node 7 or 6 consecutive edges, so 9 nodes = 63 columns fill a
  * tile).  dst[k] < 0 marks a padding column (src[k] must still be a valid row; rows of batch-shared per-edge tables are indexed by
- * the padded position k).  Every destination segment is then complete inside one tile: agg rows of destinations that have edges
- * are WRITTEN (=, plain stores - no atomics, bitwise reproducible), rows of destinations without edges are not touched.
- * GW_EDGE_AGG_BF16K (with GW_EDGE_SEGMENT_TILES): `agg` points to bf16 rows in K order (GW_LAYOUT_ROWS_BF16K) instead of fp32. */
+ * the padded position k; edge tiles cover the padded list).  Every destination segment is then complete inside one tile:
+ *   - e_res.k == 0 (no residual, no e_out; decoder): agg rows of destinations that have edges are WRITTEN (=, plain stores - no
+ *     atomics, bitwise reproducible), rows of destinations without edges are not touched;
+ *   - e_in = per-sample bf16 edge tiles (raw) with e_res = the same tiles (a processor block, graph_net_block.py:293-301): agg rows
+ *     are UPDATED in place, agg[dst] += sum of LayerNorm(.) over the destination's edges WITHOUT the residual - the caller hands
+ *     over the previous block's aggregate, whose rows are the segment sums of this block's residual (e of block n = e' of block
+ *     n - 1), so the buffer always holds sum(e') (plain load / add / store; at most 16 destinations per tile);
+ *   - every operand projected with a batch-shared residual (first processor block): as without the flag (agg += by atomics on a
+ *     zero fill), the padding columns are skipped.
+ * GW_EDGE_AGG_BF16K (with GW_EDGE_SEGMENT_TILES, no residual): `agg` points to bf16 rows in K order (GW_LAYOUT_ROWS_BF16K). */
 #define GW_EDGE_SEGMENT_TILES 2
 #define GW_EDGE_AGG_BF16K 4
 

@@ -161,3 +161,108 @@ def test_decoder_runs_on_segment_aligned_tiles_and_matches_the_fp32_path():
     err = (out - ref).abs().max().item() / scale
     print(f"[decoder on segment tiles] max-rel vs fp32 kernels {err:.2e}")
     assert err <= 2e-2
+
+
+@pytest.mark.parametrize("want_e,half", [(True, True), (False, True), (True, False)])
+def test_processor_block_on_segment_tiles_against_emulation_and_oracle(want_e, half):
+    """The processor-block form on segment-aligned tiles (csrc/gw_edge16p.hip behind gw_edge_update_forward with
+    GW_EDGE_SEGMENT_TILES: raw edge tiles + residual tiles, aggregate accumulated onto the caller's rows) DIRECTLY against the
+    oracle on the raw rows (oracle/reference_math.py EdgeProcessor.forward + scatter_sum) and a float64 emulation of the bf16
+    operands: e' tiles, and agg_out = agg_in + segment sums of LayerNorm(.) - with agg_in = the segment sums of e, that is the
+    reference's scatter_sum(e')."""
+    from graph_weather_amd.utils import deterministic_fill_
+    from oracle import reference_math as om
+    import graph_weather_amd as gw
+    from .helpers import edge_rows_from_tiles, edge_tiles_from_rows
+
+    rs = np.random.RandomState(31 + int(want_e))
+    B, N = 3, 90
+    src, dst = _graph(rs, N, N, [7, 7, 7, 6])
+    plan = plan_from_coo(src, dst, N, N)
+    seg = plan.seg_tiles()
+    assert seg is not None and seg.max_slots <= 16
+    E, P = plan.num_edges, seg.n_pad
+    ep = gw.EdgeProcessor(256, 256, 256, 2, "LayerNorm")
+    deterministic_fill_(ep, seed=29)
+    p = {"blk.edge_model." + k: v.clone() for k, v in ep.state_dict().items()}
+    x = torch.from_numpy(rs.standard_normal((B, N, 256)).astype(np.float32))
+    e = torch.from_numpy(rs.standard_normal((B, E, 256)).astype(np.float32)).to(torch.bfloat16).float()  # what the tiles hold
+    st, dt = plan.src.long(), plan.dst.long()
+    lin = [m for m in ep.edge_mlp.model if isinstance(m, torch.nn.Linear)]
+    norm = ep.edge_mlp.model[-1]
+    W0 = lin[0].weight.detach().double()
+    ps = (x.double().reshape(B * N, 256) @ W0[:, :256].t()).float()
+    pd = (x.double().reshape(B * N, 256) @ W0[:, 256:512].t()).float()
+    # oracle
+    e_orc, agg_orc = [], []
+    for b in range(B):
+        en = om.edge_processor(p, "blk.edge_model", x[b][st], x[b][dt], e[b])
+        e_orc.append(en)
+        agg_orc.append(om.scatter_sum(en, dt, N))
+    e_orc, agg_orc = torch.stack(e_orc).double(), torch.stack(agg_orc).double()
+    # emulation of the bf16 operands (layer 1: W_e in bf16 on the bf16 tiles, node products as handed over)
+    ps_h = ps.half().float() if half else ps
+    pd_h = pd.half().float() if half else pd
+    z1 = (lin[0].bias.detach().double() + ps_h.double().reshape(B, N, 256)[:, st] + pd_h.double().reshape(B, N, 256)[:, dt]
+          + e.double() @ _bf(lin[0].weight.detach()[:, 512:]).t())
+    h1 = _bf(torch.relu(z1).float())
+    h2 = _bf(torch.relu(h1 @ _bf(lin[1].weight.detach()).t() + lin[1].bias.detach().double()).float())
+    o = h2 @ _bf(lin[2].weight.detach()).t() + lin[2].bias.detach().double()
+    y = torch.nn.functional.layer_norm(o, (256,), norm.weight.detach().double(), norm.bias.detach().double(), 1e-5)
+    e_emu = y + e.double()
+    agg_in = torch.zeros(B, N, 256, dtype=torch.float64)
+    agg_in.index_add_(1, dt, e.double())          # the previous block's aggregate = segment sums of this block's residual
+    agg_emu = agg_in.clone()
+    agg_emu.index_add_(1, dt, y)
+    # kernel
+    pm = PackedMLP([l.weight.detach().to(DEV) for l in lin], [l.bias.detach().to(DEV) for l in lin],
+                   (norm.weight.detach().to(DEV), norm.bias.detach().to(DEV)), ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+    e_pad = seg.pad_batched_rows(e.reshape(B * E, 256), B).reshape(B, P, 256)
+    tiles = edge_tiles_from_rows(e_pad).view(torch.uint8).reshape(-1).to(DEV)
+    assert tiles.numel() == ops.edge_tiles_bytes(B, P)
+    agg = agg_in.float().reshape(B * N, 256).to(DEV).contiguous()
+    e_out = torch.empty(ops.edge_tiles_bytes(B, P), dtype=torch.uint8, device=DEV) if want_e else None
+    ps_d = ps.to(DEV).half() if half else ps.to(DEV)
+    pd_d = pd.to(DEV).half() if half else pd.to(DEV)
+    et = Operand(tiles, P, 256, tiles=True)
+    ops.edge_update_forward(pm, B, seg.src.to(DEV), seg.dst.to(DEV), Operand(ps_d, N, 256, projected=True),
+                            Operand(pd_d, N, 256, projected=True), et, et, N, agg, e_out, segment_tiles=True)
+    torch.cuda.synchronize()
+    got_a = agg.cpu().double().reshape(B, N, 256)
+    sc = agg_emu.abs().max().item()
+    err_ae = (got_a - agg_emu).abs().max().item() / sc
+    err_ao = (got_a - agg_orc).abs().max().item() / agg_orc.abs().max().item()
+    msg = f"[processor block on segment tiles e'={want_e} half={half}] aggregate vs emulation {err_ae:.2e}, vs oracle {err_ao:.2e}"
+    assert err_ae <= 6e-3 and 1e-6 < err_ao <= 2e-2, msg
+    if want_e:
+        got_t = e_out.cpu().view(torch.bfloat16).reshape(B, P // 64, 4, 8, 64, 8)
+        got_e = edge_rows_from_tiles(got_t, P)[:, seg.pos.cpu()].double()
+        err_ee = (got_e - e_emu).abs().max().item() / e_emu.abs().max().item()
+        err_eo = (got_e - e_orc).abs().max().item() / e_orc.abs().max().item()
+        msg += f"; e' vs emulation {err_ee:.2e}, vs oracle {err_eo:.2e}"
+        assert err_ee <= 8e-3 and err_eo <= 2e-2, msg  # (e' is stored as bf16: 2^-9 of its own magnitude on top)
+    print(msg)
+
+
+def test_processor_stack_on_segment_tiles_matches_the_fp32_kernels():
+    """GraphProcessor (9 blocks) in bf16 mode takes the segment-aligned route on the latent mesh graph (running aggregate,
+    e' as tiles between blocks) and stays inside the bf16 budget of the fp32 kernels on the same weights; bitwise reproducible
+    from the second block on (the first block's sums still meet in atomics)."""
+    import graph_weather_amd as gw
+    from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons
+
+    model = gw.GraphWeatherForecaster(regular_lat_lons(30.0))
+    deterministic_fill_(model, seed=5)
+    model = model.to(DEV).eval()
+    feats = torch.randn(2, 72, 102, device=DEV)
+    with torch.no_grad():
+        ref = model(feats)
+        model.set_compute_dtype(torch.bfloat16)
+        gp = model.processor.graph_processor
+        _, lat_plan = model.encoder._plans(torch.device(DEV))
+        assert gp._seg_for(lat_plan) is not None
+        out = model(feats)
+    scale = (ref - feats[..., :78]).abs().max().item()
+    err = (out - ref).abs().max().item() / scale
+    print(f"[forecaster with the processor stack on segment tiles] max-rel vs fp32 kernels {err:.2e}")
+    assert err <= 2e-2
