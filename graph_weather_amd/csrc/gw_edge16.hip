@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void edge16_gather_kernel(const Edge16Args a) 
 //   H1[s] = bf16(relu(acc[2 s]), relu(acc[2 s + 1]))   (one coalesced 16-byte store per K-step)
 // No inter-wave synchronisation after the weight copy: the gathers of one wave overlap the MFMAs of its neighbours.
 constexpr int kL1Waves = 8;
+constexpr int kL1Lds = 128 * 1024 + 1024;  // W_e + b1
+// Round 4: a group is worked off in two halves of 8 output row tiles (32 accumulator registers instead of 64), which leaves room
+// to request the NEXT group's edge-tile fragments (8 KiB per group: the only bytes of this kernel that come from HBM) and its row
+// indices while the current group is on the matrix cores - the dependent chain index -> gather -> MFMA -> store of a group no
+// longer starts with an HBM round trip.  b1 lives in LDS beside W_e (it was 16 global loads per group).
 __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
     for (int p = wave; p < 128; p += kL1Waves)
       glds16_asm_s((const float*)(a.w_raw + (size_t)p * 1024), (unsigned)lane * 16u,
                    __builtin_amdgcn_readfirstlane(lds0 + (unsigned)p * 1024u));
+    if (threadIdx.x < 256) ((float*)(lds + 128 * 1024))[threadIdx.x] = a.b1[threadIdx.x];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -140,65 +146,105 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
   const int g_lo = (int)((long long)n_groups * xcd / 8), g_hi = (int)((long long)n_groups * (xcd + 1) / 8);
   const int stride = nslot * kL1Waves;
-#pragma unroll 1
-  for (int u = g_lo + slot * kL1Waves + wave; u < g_hi; u += stride) {
+  const float* const b1l = (const float*)(lds + 128 * 1024) + 4 * q;
+  const char* const wl = lds + lane * 16;
+
+  struct Grp {
+    size_t goff, eoff;
+    int b, k;
+    bool valid;
+  };
+  auto locate = [&](int u) -> Grp {
     const int tile = u >> 2, g = u & 3;
     const int b = tile / a.neb;
     const int eb = tile - b * a.neb;
     const int kr = eb * kTileCols + 16 * g + j;
-    const bool valid = kr < a.n_edges;
-    const int k = valid ? kr : a.n_edges - 1;
-    const size_t goff = ((size_t)tile * kGroups + g) * 8192 + (size_t)lane * 16;
-    const size_t eoff = a.e_tiles_shared ? ((size_t)eb * kGroups + g) * 8192 + (size_t)lane * 16 : goff;
-    bf16x8 bf[8];
+    Grp r;
+    r.valid = kr < a.n_edges;
+    r.k = r.valid ? kr : a.n_edges - 1;
+    r.b = b;
+    r.goff = ((size_t)tile * kGroups + g) * 8192 + (size_t)lane * 16;
+    r.eoff = a.e_tiles_shared ? ((size_t)eb * kGroups + g) * 8192 + (size_t)lane * 16 : r.goff;
+    return r;
+  };
+  int u = g_lo + slot * kL1Waves + wave;
+  if (u >= g_hi) return;
+  Grp cur = locate(u);
+  bf16x8 bf[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bf[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + eoff + s * 1024);
-    f32x4 acc[16];
+  for (int s = 0; s < 8; ++s) bf[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + cur.eoff + s * 1024);
+  int ridx[2] = {0, 0};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = ldg4(a.b1 + 16 * t + 4 * q);
+  for (int p = 0; p < 2; ++p)
+    if (p < a.n_proj) ridx[p] = a.p_kind[p] == 0 ? ldgi(a.src + cur.k) : (a.p_kind[p] == 1 ? ldgi(a.dst + cur.k) : cur.k);
+#pragma unroll 1
+  for (;;) {
+    const int un = u + stride;
+    const bool more = un < g_hi;
+    Grp nxt = cur;
+    bf16x8 bfn[8];
+    int ridn[2] = {0, 0};
+    if (more) {  // the next group's fragments and row indices: in flight under this group's 128 MFMAs
+      nxt = locate(un);
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-      if (p < a.n_proj) {
-        int r = a.p_kind[p] == 0 ? ldgi(a.src + k) : (a.p_kind[p] == 1 ? ldgi(a.dst + k) : k);
-        r = r < 0 ? 0 : r;  // (segment-aligned tiles: padding columns carry dst = -1; their results are never summed)
-        const size_t ro = ((size_t)b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q;
-        if (a.p_half[p]) {  // node products as fp16 rows (GW_LAYOUT_ROWS_F16): 8 bytes per row tile and lane
-          typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-          const _Float16* row = (const _Float16*)a.p_ptr[p] + ro;
+      for (int s = 0; s < 8; ++s) bfn[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + nxt.eoff + s * 1024);
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const half4_t h = *(const GW_AS1 half4_t*)(row + 16 * t);
-            acc[t] += f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-          }
-        } else {
-          const float* row = a.p_ptr[p] + ro;
+      for (int p = 0; p < 2; ++p)
+        if (p < a.n_proj) ridn[p] = a.p_kind[p] == 0 ? ldgi(a.src + nxt.k) : (a.p_kind[p] == 1 ? ldgi(a.dst + nxt.k) : nxt.k);
+    }
+    char* out = a.h1g + cur.goff;
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            acc[t] += ldg4(row + 16 * t);
-            if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // at most 8 row pieces in flight: registers
+    for (int half = 0; half < 2; ++half) {
+      // acc[t] = b1 + P_s[src] + P_d[dst] for the row tiles 8 half + t   (lane (j, q): features 16 T + 4 q .. + 3 of column j)
+      f32x4 acc[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = *(const f32x4*)(b1l + 16 * (8 * half + t));
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        if (p < a.n_proj) {
+          int r = ridx[p];
+          r = r < 0 ? 0 : r;  // (segment-aligned tiles: padding columns carry dst = -1; their results are never summed)
+          const size_t ro = ((size_t)cur.b * (size_t)a.p_rows_pb[p] + (size_t)r) * (size_t)a.p_ld[p] + 4 * q + 128 * half;
+          if (a.p_half[p]) {  // node products as fp16 rows (GW_LAYOUT_ROWS_F16): 8 bytes per row tile and lane
+            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+            const _Float16* row = (const _Float16*)a.p_ptr[p] + ro;
+            half4_t h[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) h[t] = *(const GW_AS1 half4_t*)(row + 16 * t);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += f32x4{(float)h[t][0], (float)h[t][1], (float)h[t][2], (float)h[t][3]};
+          } else {
+            const float* row = a.p_ptr[p] + ro;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += ldg4(row + 16 * t);
           }
         }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int t4 = 0; t4 < 2; ++t4) {  // A fragments four at a time (16 registers)
+          bf16x8 af[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(wl + (s * 16 + 8 * half + 4 * t4 + t) * 1024);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[4 * t4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf[s], acc[4 * t4 + t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    const char* wl = lds + lane * 16;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {  // A fragments four at a time (16 registers), read one quartet ahead by the scheduler
-        bf16x8 af[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(wl + (s * 16 + 4 * t4 + t) * 1024);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * t4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf[s], acc[4 * t4 + t], 0, 0, 0);
-        if (t4 & 1) __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < 4; ++s) {  // output K-steps 4 half + s <- row tiles 2 s, 2 s + 1 of this half
+        bf16x8 v = to_bf16x8(relu4(acc[2 * s]), relu4(acc[2 * s + 1]));
+        if (!cur.valid) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *(GW_AS1 bf16x8*)(out + (4 * half + s) * 1024) = v;
       }
     }
-    char* out = a.h1g + goff;
+    if (!more) break;
+    u = un;
+    cur = nxt;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      bf16x8 v = to_bf16x8(relu4(acc[2 * s]), relu4(acc[2 * s + 1]));
-      if (!valid) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      *(GW_AS1 bf16x8*)(out + s * 1024) = v;
-    }
+    for (int s = 0; s < 8; ++s) bf[s] = bfn[s];
+    ridx[0] = ridn[0];
+    ridx[1] = ridn[1];
   }
 }
 
@@ -801,8 +847,8 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   // launch 1: layer 1 -> workspace tiles
   if (raw_e) {
     static DeviceOnce once_l1;
-    if (once_l1.first()) (void)hipFuncSetAttribute((const void*)edge16_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(edge16_l1_kernel, dim3((unsigned)n_wg), dim3(64 * kL1Waves), 128 * 1024, (hipStream_t)stream, a);
+    if (once_l1.first()) (void)hipFuncSetAttribute((const void*)edge16_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kL1Lds);
+    hipLaunchKernelGGL(edge16_l1_kernel, dim3((unsigned)n_wg), dim3(64 * kL1Waves), kL1Lds, (hipStream_t)stream, a);
     if (int rc = check_launch("edge16_l1_kernel launch")) return rc;
   } else if (!fuse_gather) {
     hipLaunchKernelGGL(edge16_gather_kernel, dim3((unsigned)a.neb), dim3(256), 0, (hipStream_t)stream, a);  // one workgroup per edge block

@@ -259,6 +259,11 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
     const u32x4* const smat = (const u32x4*)(lds + kP_Smat);
     const int* const dsl = (const int*)(lds + kP_Dsl);
     const int* const nsl = (const int*)(lds + kP_Nsl);
+    // the rows of the running aggregate this lane will add to (tile s: requested at the end of step s, behind the output layer -
+    // the slot tables of tile s were published a step earlier - and added in half 1 of step s + 1: an HBM round trip under cover)
+    f32x4 old[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) old[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int s = 0; s <= n; ++s) {
       stamp = a.dbg != nullptr && s == 3 && (int)blockIdx.x < a.dbg_cap;
@@ -321,11 +326,6 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
         const int nslots = __builtin_amdgcn_readfirstlane(nsl[ring]);
         const bool mine = j < nslots && GW_SKIP(a) != 1;
         float* const dstp = a.agg + (size_t)(mine ? dsl[ring * kTileCols + fresh(j)] : 0) * 256 + fresh(64 * tw + 16 * q);
-        f32x4 old[4];
-        if (mine) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) old[t] = ldg4(dstp + 4 * t);
-        }
         u32x4 sb[2];
         sb[0] = smat[(ring * 2 + 0) * 64 + fresh(lane)];
         sb[1] = smat[(ring * 2 + 1) * 64 + fresh(lane)];
@@ -375,6 +375,15 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
               }
             });
         __builtin_amdgcn_s_setprio(0);
+        {
+          const int ring_s = s & 3;
+          const bool mine_s = j < __builtin_amdgcn_readfirstlane(nsl[ring_s]) && GW_SKIP(a) != 1;
+          if (mine_s) {
+            const float* src = a.agg + (size_t)dsl[ring_s * kTileCols + fresh(j)] * 256 + fresh(64 * tw + 16 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) old[t] = ldg4(src + 4 * t);
+          }
+        }
         GW_TS(9)
       } else {
         // (last iteration: redefine the accumulators from nothing - see gw_edge16t.hip)
