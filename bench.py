@@ -169,8 +169,8 @@ def pmc_traffic(name="pmc_decoder_edge.json"):
 
 def pmc_c3_traffic():
     """Counter traffic (bytes per launch) of the bf16 kernels at C3 from the tracked per-kernel PMC summary: the newest of
-    profiles/r03_pmc_c3.json / r02_pmc_c3_edge16_v2.json.  Returns ({"processor_block": bytes, "decoder": bytes}, file)."""
-    for name in ("r03_pmc_c3.json", "r02_pmc_c3_edge16_v2.json"):
+    profiles/r04_pmc_c3.json / r03_pmc_c3.json / r02_pmc_c3_edge16_v2.json.  Returns ({"processor_block": bytes, "decoder": bytes}, file)."""
+    for name in ("r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3_edge16_v2.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -181,7 +181,9 @@ def pmc_c3_traffic():
             w = next((v for k, v in entry.items() if k.startswith("hbm_write_bytes")), None)
             return None if r is None or w is None else r + w
 
-        proc = [rw(v) for k, v in d.items() if "blocks1-8" in k]
+        # one processor block = the layer-1 kernel + the resident-weight kernel that writes e' (the last block's variant, which
+        # drops e', is a separate instantiation and not part of the per-block figure)
+        proc = [rw(v) for k, v in d.items() if "blocks1-8" in k and "edge16p_kernel<false>" not in k]
         dec = [rw(v) for k, v in d.items() if "[decoder]" in k]
         if proc and all(x is not None for x in proc):
             return {"processor_block": sum(proc), "decoder": sum(x for x in dec if x is not None) or None}, name
@@ -252,11 +254,16 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
     # algorithmic HBM bytes of one decoder edge launch: per (sample, edge) the cached product row and the residual edge-feature
     # row (2 x 1 KiB), per destination row one 1 KiB sum written; indices 8 B per edge
     alg_bytes = dec_b * e_dec * (2 * 1024 + 8) + dec_b * graphs.num_grid * 1024
+    if precision != "fp32":
+        # bf16 path: per (sample, edge) the fp16 product row of the source node (512 B), the batch-shared cached product row once
+        # per edge (1 KiB), no residual row (its sums enter the node update as a cached table); per destination one bf16 sum (512 B)
+        alg_bytes = dec_b * e_dec * (512 + 8) + e_dec * 1024 + dec_b * graphs.num_grid * 512
     # gather / scatter stage of one processor block: 2 E D s + 2 M D 4 bytes per sample, s = bytes per stored
     # edge-feature element between blocks (4: fp32 rows; 2: bf16 edge tiles - "halve for bf16 storage")
     e_bytes = 4 if precision == "fp32" else 2
     gs_bytes = proc_b * (2 * e_lat * D * e_bytes + 2 * graphs.num_mesh * D * 4)
     gs_bytes_fp32 = proc_b * (2 * e_lat * D * 4 + 2 * graphs.num_mesh * D * 4)
+    gs_bytes_halved = proc_b * (2 * e_lat * D * 2 + 2 * graphs.num_mesh * D * 2)  # SURVEY 8(d) "halve for bf16 storage", node tables too
     ach = executed / (dec_ms * 1e-3) / 1e12
     gs_traffic, gs_traffic_file = (None, None)
     if precision != "fp32" and proc_b == 16 and graphs.num_grid == 64800:
@@ -282,6 +289,10 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
                            "achieved_tbs": gs_bytes / (proc_ms * 1e-3) / 1e12, "peak_tbs": PEAK_HBM_TBS,
                            "frac": gs_bytes / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                            "frac_fp32_basis": gs_bytes_fp32 / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                           "frac_fully_halved_basis": None if precision == "fp32" else gs_bytes_halved / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                           "basis_note": "frac = storage basis (edge features as stored: bf16 tiles in bf16 mode; node tables fp32); "
+                                         "frac_fully_halved_basis = SURVEY 8(d) bytes with every table halved; frac_fp32_basis = the "
+                                         "reference's fp32 bytes",
                            "traffic": gs_traffic, "traffic_file": gs_traffic_file,
                            "traffic_tbs": None if gs_traffic is None else gs_traffic / (proc_ms * 1e-3) / 1e12,
                            "executed_tflops": 3 * LAYER * e_lat * proc_b / (proc_ms * 1e-3) / 1e12},

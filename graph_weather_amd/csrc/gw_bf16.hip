@@ -659,6 +659,27 @@ int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
         break;
     }
   }
+  if (nw == 12 || nw == 16) {  // one workgroup of 12 / 16 waves per CU: 192 / 256 columns share one weight stream
+    const int th = nw * 64, cl = nw * 16;
+    switch (kind) {
+      case 2:
+        return nw == 12 ? launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, false, 12, 1>, a, stream, 1, kLdsWeights, th, cl)
+                        : launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, false, 16, 1>, a, stream, 1, kLdsWeights, th, cl);
+      case 4:
+        return nw == 12 ? launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true, false, 12, 1>, a, stream, 1, kLdsWeights, th, cl)
+                        : launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, true, false, 16, 1>, a, stream, 1, kLdsWeights, th, cl);
+      case 6:
+        return nw == 12 ? launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true, 12, 1>, a, stream, 1, kLdsWeights, th, cl)
+                        : launch16(chain16_kernel<8, true, 2, 16, 16, EPI_ROWS, false, false, true, 16, 1>, a, stream, 1, kLdsWeights, th, cl);
+      case 5:
+        if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32)
+          return nw == 12 ? launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true, false, 12, 1>, a, stream, 1, kLdsWeights, th, cl)
+                          : launch16(chain16_kernel<4, false, 1, 16, 16, EPI_ROWS, false, true, false, 16, 1>, a, stream, 1, kLdsWeights, th, cl);
+        break;
+      default:
+        break;
+    }
+  }
   if (nw == 4) {
     switch (kind) {
       case 2:

@@ -34,16 +34,20 @@ for name in ("fetch", "write", "sq", "grbm"):
     for d in sorted(by_disp):
         rs = by_disp[d]
         k = rs[0]["Kernel_Name"]
-        m = re.search(r"(edge16t_kernel<[^>]*>|edge16_kernel<[^>]*>|edge16_l1_kernel|chain16_kernel<[^>]*>)", k)
+        m = re.search(r"(edge16t_kernel<[^>]*>|edge16p_kernel<[^>]*>|edge16_kernel<[^>]*>|edge16_l1_kernel|chain16_kernel<[^>]*>)", k)
         if not m: continue
         kind = m.group(1)
         i = pos[kind]; pos[kind] += 1
         # per forward (round 3): the team kernel's gather form runs twice (encoder edge update, then decoder), its DMA form and
         # the layer-1 kernel once per processor block 1..8, the lock-step kernel once (first processor block); the chain16
         # kernels (node-side MLPs) are averaged per instantiation
-        if kind.startswith("edge16t_kernel<true"):
-            label = "encoder" if i % 2 == 0 else "decoder"
-        elif kind.startswith("edge16t_kernel") or kind == "edge16_l1_kernel":
+        # (round 4: the decoder runs edge16t_kernel<true, true, false, true> - segment-aligned tiles - the encoder the form
+        #  without them, processor blocks 1..8 the layer-1 kernel + edge16p_kernel<e' out>)
+        if kind.startswith("edge16t_kernel<true") and kind.rstrip(">").endswith("true"):
+            label = "decoder"
+        elif kind.startswith("edge16t_kernel<true"):
+            label = "encoder"
+        elif kind.startswith(("edge16t_kernel", "edge16p_kernel")) or kind == "edge16_l1_kernel":
             label = "blocks1-8"
         elif kind.startswith("edge16_kernel"):
             label = "block0"
