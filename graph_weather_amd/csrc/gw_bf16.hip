@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kerne
   }
 
   // ---- residual ----
-  if (!SINGLE && !HEAD && a.res_ptr != nullptr) {
+  if (!SINGLE && !HEAD && a.res_ptr != nullptr && !(GW_TUNE16(a) & 16)) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const float* rrow = operand_row16(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kerne
 
   // ---- store ----
   float* outp = SINGLE ? a.proj_out[blockIdx.y] : a.out;
-  if (!HEAD && outp != nullptr) {
+  if (!HEAD && outp != nullptr && !(GW_TUNE16(a) & 8)) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (valid[g]) {
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chain16_kerne
       pass16<NW, NG, 8, BKS, HT, HTP>(acc, bin, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, lds16, parity, lane, wave, GW_TUNE16(a));
 #pragma unroll
       for (int g = 0; g < NG; ++g)
-        if (valid[g]) {
+        if (valid[g] && !(GW_TUNE16(a) & 32)) {
           if (a.proj_half) {
             _Float16* prow = (_Float16*)a.proj_out[sl] + (size_t)cc[g] * 256;
 #pragma unroll
