@@ -18,7 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomic
 ABI_VERSION = 14
 DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16, LAYOUT_ROWS_BF16K = 0, 1, 2, 3
-EDGE_DETERMINISTIC, EDGE_SEGMENT_TILES, EDGE_AGG_BF16K = 1, 2, 4
+EDGE_DETERMINISTIC, EDGE_SEGMENT_TILES, EDGE_AGG_BF16K, EDGE_SEGMENT_SPLIT = 1, 2, 4, 8
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",

@@ -759,6 +759,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   memset(&a, 0, sizeof(a));
   a.seg_tiles = (flags & GW_EDGE_SEGMENT_TILES) != 0;
   a.agg_bf16k = (flags & GW_EDGE_AGG_BF16K) != 0;
+  a.seg_split = (flags & GW_EDGE_SEGMENT_SPLIT) != 0;
   a.batch = batch;
   a.n_edges = n_edges;
   a.n_dst = n_dst;
@@ -834,7 +835,7 @@ int edge16_launch(int32_t batch, int32_t n_edges, const int32_t* src, const int3
   // the processor stack); (c) every operand projected with a (batch-shared) residual - the first processor block - runs on
   // the lock-step kernel, which only has to skip the padding columns (agg += by atomics on the caller's zero fill)
   if (a.seg_tiles && (team_only || !fuse_gather || a.res_ptr != nullptr || e_out != nullptr || (raw_e && (no_res || a.res_tiles_shared)) ||
-                      (a.agg_bf16k && (raw_e || !no_res))))
+                      (a.agg_bf16k && (raw_e || !no_res || a.seg_split)) || (a.seg_split && (raw_e || !no_res))))
     return set_error(GW_E_UNSUPPORTED, "edge16: segment-aligned tiles take projected operands without residual, or bf16 edge tiles "
                                        "(operand and residual), atomics mode, e' as tiles or dropped");
   if (no_res || (any_half && !raw_e)) {

@@ -64,6 +64,8 @@ struct Edge16Args {
   int seg_tiles;            // GW_EDGE_SEGMENT_TILES: src / dst are the padded arrays of segment-aligned tiles (dst < 0 = padding
                             // column, no destination run crosses a multiple of 64): team kernel with the transposed output layer
   int agg_bf16k;            // ... and agg is bf16 rows in MFMA K order (GW_LAYOUT_ROWS_BF16K) instead of fp32 rows
+  int seg_split;            // GW_EDGE_SEGMENT_SPLIT: a run longer than a tile continues over whole tiles - the first / last slot of a tile
+                            // may be a PIECE of such a run: its sums are added with fp32 atomics (agg zero-filled by the caller)
   int bc, nchunk;           // team kernel (gw_edge16t.hip): batch elements of one edge block a workgroup handles in a row (divides
                             // batch) and chunks per edge block (batch / bc): per-edge data shared by the batch is fetched once per chunk
   int tune;                 // tuning builds only (GW_EDGE16_TUNE): A/B switches of the team kernel

@@ -60,6 +60,7 @@ constexpr int kS_Lnc = kT_Stage + 2048;      // float2[4 team-B waves][64 edges]
 constexpr int kS_ParT = kT_Stage + 4096;     // float4[4 waves][16 lanes][4 t]: b_out of a lane's feature of tile t, replicated x 4
 constexpr int kS_ParP = kT_Stage + 8192;     // float[2][256]: gamma, beta in the POSITION order of a destination row
 constexpr int kS_Cnt = kT_Stage + 10240;     // float[4][64]: edges of each destination slot
+constexpr int kS_Part = kT_Stage + 11264;    // int[4][64]: 1 = the slot is a piece of a run that continues in a neighbouring tile
 constexpr int kS_Smat = kT_Stage + 12288;    // uint4[4 ring][4 slot groups][2 halves][64 lanes]: the B operand S of the segment sums
 static_assert(kS_Smat + 4 * 4 * 2 * 64 * 16 <= kT_Stage + kTileCols * kStageLd * 4, "the slot tables fit the staging area");
 
@@ -408,6 +409,12 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         const int len = rest != 0ull ? __builtin_ctzll(rest) + 1 : __popcll(vm >> lane);
         ((int*)(lds + kS_Dsl))[ring * kTileCols + slot] = d;  // (row within a batch element: the table serves the whole chunk)
         ((float*)(lds + kS_Cnt))[ring * kTileCols + slot] = (float)len;
+        int part = 0;
+        if (a.seg_split) {  // does the run go on before column 0 / behind column 63 of this tile?
+          if (lane == 0 && t.eb > 0 && ldgi(a.dst + kr - 1) == d) part = 1;
+          if (lane + len == kTileCols && t.eb + 1 < a.neb && ldgi(a.dst + kr + len) == d) part = 1;
+        }
+        ((int*)(lds + kS_Part))[ring * kTileCols + slot] = part;
       }
       const int nsl_ = __popcll(sm);
       if (lane == 0) ((int*)(lds + kS_Nsl))[ring] = nsl_;
@@ -728,6 +735,13 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
                 __bf16* dstp = (__bf16*)a.agg + row * 256 + p0;
                 *(GW_AS1 bf16x8*)dstp = to_bf16x8(dsum[0], dsum[1]);
                 *(GW_AS1 bf16x8*)(dstp + 8) = to_bf16x8(dsum[2], dsum[3]);
+              } else if (a.seg_split && ((const int*)(lds + kS_Part))[ring * kTileCols + slot] != 0) {
+                float* dstp = a.agg + row * 256 + p0;  // a piece of a run that spans tiles: partial sums meet in atomics
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    __hip_atomic_fetch_add((GW_AS1 float*)(dstp + 4 * t + r), dsum[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               } else {
                 float* dstp = a.agg + row * 256 + p0;
 #pragma unroll

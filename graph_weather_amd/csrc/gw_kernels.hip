@@ -1117,7 +1117,8 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   float* e_out = tiles_out ? nullptr : (float*)e_out_any;
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
   const bool seg = (flags & GW_EDGE_SEGMENT_TILES) != 0;
-  if ((flags & GW_EDGE_AGG_BF16K) && !seg) return fail(GW_E_BADARG, "gw_edge_update_forward: GW_EDGE_AGG_BF16K comes with GW_EDGE_SEGMENT_TILES");
+  if ((flags & (GW_EDGE_AGG_BF16K | GW_EDGE_SEGMENT_SPLIT)) && !seg)
+    return fail(GW_E_BADARG, "gw_edge_update_forward: GW_EDGE_AGG_BF16K / GW_EDGE_SEGMENT_SPLIT come with GW_EDGE_SEGMENT_TILES");
   if (seg) {
     const size_t ws_seg = gw::edge16_eligible(x_src, x_dst, e_in, w) ? gw::edge16_workspace_needed(batch, n_edges, e_in, false) : 0;
     if (det || save || n_edges % 64 != 0 || !gw::edge16_eligible(x_src, x_dst, e_in, w) || (e_out_any && !tiles_out) ||

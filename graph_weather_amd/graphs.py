@@ -74,25 +74,39 @@ class GraphPlan:
             self._ident_ptr = torch.arange(self.num_edges + 1, dtype=torch.int32, device=self.src.device)
         return self._ident_ptr
 
-    def seg_tiles(self):
+    def seg_tiles(self, split: bool = False):
         """Segment-aligned tiles of the destination-sorted edge list (include/gw_amd.h: GW_EDGE_SEGMENT_TILES): the edges are
         re-laid into tiles of 64 columns so that no destination's run of edges crosses a tile - runs are packed next-fit in
         order, the rest of a tile is padding (the decoder graph, assimilator_decoder.py:92-103: 7 or 6 edges per grid node, 9
-        nodes = 63 columns per tile).  Returns ``SegTiles(src, dst, pos, n_pad, complete)`` - padded int32 ``src`` / ``dst``
-        (padding: src 0, dst -1), ``pos[i]`` = padded position of sorted edge i, ``complete`` = every destination row has an
-        edge - or None when some destination has more than 64 edges (the encoder's polar mesh cells)."""
-        if getattr(self, "_seg_tiles", None) is None:
+        nodes = 63 columns per tile).  Returns ``SegTiles`` - padded int32 ``src`` / ``dst`` (padding: src 0, dst -1), ``pos[i]``
+        = padded position of sorted edge i, ``complete`` = every destination row has an edge.  A destination with more than 64
+        edges (the encoder's polar mesh cells, encoder.py:75-104) makes this None - unless ``split``: such a run then starts a
+        fresh tile and continues over whole tiles (``SegTiles.split``: its pieces are partial sums that meet in atomics,
+        GW_EDGE_SEGMENT_SPLIT)."""
+        cache = getattr(self, "_seg_tiles", None)
+        if cache is None:
+            cache = self._seg_tiles = {}
+        if split not in cache:
             dst = self.dst.cpu().numpy().astype(np.int64)
             E = int(dst.size)
             st = None
             if E > 0:
                 starts = np.flatnonzero(np.concatenate([[True], dst[1:] != dst[:-1]]))
                 ends = np.concatenate([starts[1:], [E]])
-                if int((ends - starts).max()) <= 64:
+                n_runs = int(starts.size)
+                longest = int((ends - starts).max())
+                has_split = longest > 64
+                if has_split and split:  # pieces of 64 (the last one shorter) stand for the long runs in the packing below
+                    nparts = (ends - starts + 63) // 64
+                    run_of = np.repeat(np.arange(n_runs), nparts)
+                    part_ix = np.arange(run_of.size) - np.repeat(np.cumsum(nparts) - nparts, nparts)
+                    starts = starts[run_of] + 64 * part_ix
+                    ends = np.minimum(starts + 64, ends[run_of])
+                if not has_split or split:
                     first, tile_of_seg = 0, np.empty(starts.size, dtype=np.int64)
                     tile_start_edge = []
                     t = 0
-                    while first < starts.size:  # next-fit: as many whole runs as fit into 64 columns
+                    while first < starts.size:  # next-fit: as many whole runs (pieces) as fit into 64 columns
                         nxt = int(np.searchsorted(ends, starts[first] + 64, side="right"))
                         tile_of_seg[first:nxt] = t
                         tile_start_edge.append(int(starts[first]))
@@ -107,9 +121,9 @@ class GraphPlan:
                     dst_p[pos] = dst
                     dev = self.src.device
                     st = SegTiles(torch.from_numpy(src_p).to(dev), torch.from_numpy(dst_p).to(dev), torch.from_numpy(pos).to(dev),
-                                  n_pad, bool(starts.size == self.n_dst), int(np.bincount(tile_of_seg).max()))
-            self._seg_tiles = (st,)
-        return self._seg_tiles[0]
+                                  n_pad, bool(n_runs == self.n_dst), int(np.bincount(tile_of_seg).max()), bool(has_split))
+            cache[split] = st
+        return cache[split]
 
     def to(self, device) -> "GraphPlan":
         return GraphPlan(self.n_src, self.n_dst, self.src.to(device), self.dst.to(device), self.perm.to(device),
@@ -124,6 +138,7 @@ class SegTiles:
     n_pad: int
     complete: bool  # every destination row has at least one edge
     max_slots: int = 64  # most destinations in one tile (the processor form of the kernels takes up to 16)
+    split: bool = False  # some destination's run spans several tiles: its pieces are partial sums (atomics; zero-filled fp32 aggregate)
 
     def pad_rows(self, rows: torch.Tensor) -> torch.Tensor:
         """A per-edge table [E, w] in destination-sorted order -> [n_pad, w] in padded order (zero rows in padding columns)."""

@@ -342,7 +342,10 @@ class GraphNetBlock(nn.Module):
         elif seg is not None:
             if want_edges or e_res is not None:
                 raise RuntimeError("graph_weather_amd: segment-aligned tiles come without residual and without e'")
-            agg = (torch.empty if seg.complete else torch.zeros)((batch * n_dst, 256), dtype=torch.bfloat16, device=device)
+            if seg.split:  # pieces of long runs meet in fp32 atomics
+                agg = agg_zeroed if agg_zeroed is not None else torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
+            else:
+                agg = (torch.empty if seg.complete else torch.zeros)((batch * n_dst, 256), dtype=torch.bfloat16, device=device)
         else:
             agg = agg_zeroed if agg_zeroed is not None else torch.zeros((batch * n_dst, 256), dtype=torch.float32, device=device)
         if want_edges == "tiles":  # e' stays in the kernels' own bf16 tile format for the next block
@@ -353,7 +356,7 @@ class GraphNetBlock(nn.Module):
         ops.edge_update_forward(self.edge_model.edge_mlp.packed(), batch, plan.src if seg is None else seg.src,
                                 plan.dst if seg is None else seg.dst, x_src.operand(), x_dst.operand(),
                                 e_in.operand(), res_op, n_dst, agg, e_out, tag=tag, deterministic=self.deterministic,
-                                segment_tiles=seg is not None)
+                                segment_tiles=seg is not None, segment_split=seg is not None and seg.split and agg_acc is None)
         res_x = ops.ZERO if x_res is None else Operand(x_res, x_res_rows_pb, 256)
         if head is not None:
             # (bf16 inference, decoder) the node update and the output head that follows it in one launch: ``head`` = (packed
@@ -750,6 +753,7 @@ class Encoder(nn.Module):
         _check_native_dims(*self.graph_processor._dims)
         pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
         x_src, e_res = Feed(xg, G, "raw"), e
+        seg = None
         if team:
             # bf16 inference on the team-pipelined edge kernel (csrc/gw_edge16t.hip): every operand of the edge MLP's layer 1
             # enters as a product - Ws.xg is made once per grid node here (one edge per grid node: the same matrix work the raw
@@ -762,13 +766,16 @@ class Encoder(nn.Module):
             x_src = Feed(fused_ps, G, "proj")
             px_xm = self._team_node_product(blk, enc_plan, e, px_xm)
             e_res = None
+            seg = enc_plan.seg_tiles(split=True)  # (a polar mesh cell collects hundreds of grid nodes: runs split over tiles)
+            if seg is not None:
+                pe = self._cached("enc_pe_pad", list(self.parameters()), lambda: seg.pad_rows(pe))
         if post_w is not None:
             x, _, posts, agg0 = blk.run(B, enc_plan, x_src, Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e_res, 0,
                                         Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge",
-                                        post_w=post_w, post_zero=True)
+                                        post_w=post_w, post_zero=True, seg=seg)
             return x, posts, agg0
         x, _ = blk.run(B, enc_plan, x_src, Feed(pd_xm, 0, "proj"), Feed(pe, 0, "proj"), e_res, 0,
-                       Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge")
+                       Feed(px_xm, 0, "proj"), xm, 0, False, features.device, tag="encoder_edge", seg=seg)
         return x
 
     def team_path(self, features: Optional[torch.Tensor] = None) -> bool:

@@ -334,13 +334,14 @@ def edge_rows_to_tiles(rows: torch.Tensor, batch: int, n_edges: int, rows_per_ba
 def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch.Tensor, x_src: Operand, x_dst: Operand,
                         e_in: Operand, e_res: Operand, n_dst: int, agg: torch.Tensor, e_out: Optional[torch.Tensor],
                         tag: Optional[str] = None, save: Optional[SavedActivations] = None, deterministic: bool = False,
-                        segment_tiles: bool = False) -> None:
+                        segment_tiles: bool = False, segment_split: bool = False) -> None:
     """graph_net_block.py:131-137 (EdgeProcessor) fused with the scatter_sum of :188.  ``agg`` must be zeroed.
     ``e_out``: None, fp32 rows [batch * n_edges, 256], or a uint8 buffer of ``edge_tiles_bytes`` (bf16 edge tiles).
     ``deterministic``: bitwise reproducible segment sums (carry records + a fix-up launch instead of atomics).
     ``segment_tiles``: ``src`` / ``dst`` are the padded arrays of segment-aligned tiles (include/gw_amd.h:
     GW_EDGE_SEGMENT_TILES; ``GraphPlan.seg_tiles()``): ``agg`` rows are written with plain stores and need no zero fill when every
-    destination has an edge; a bfloat16 ``agg`` is written as bf16 rows in K order (GW_EDGE_AGG_BF16K)."""
+    destination has an edge; a bfloat16 ``agg`` is written as bf16 rows in K order (GW_EDGE_AGG_BF16K).  ``segment_split``: the
+    padded list splits runs longer than a tile over several tiles (``SegTiles.split``; zero-filled fp32 ``agg``)."""
     _require(src, "src", torch.int32)
     _require(dst, "dst", torch.int32)
     agg_bf16 = agg.dtype == torch.bfloat16
@@ -359,7 +360,7 @@ def edge_update_forward(pm: PackedMLP, batch: int, src: torch.Tensor, dst: torch
     xs, xd, ei = x_src.c(), x_dst.c(), e_in.c()
     flags = _lib.EDGE_DETERMINISTIC if deterministic else 0
     if segment_tiles:
-        flags |= _lib.EDGE_SEGMENT_TILES | (_lib.EDGE_AGG_BF16K if agg_bf16 else 0)
+        flags |= _lib.EDGE_SEGMENT_TILES | (_lib.EDGE_AGG_BF16K if agg_bf16 else 0) | (_lib.EDGE_SEGMENT_SPLIT if segment_split else 0)
     ws, ws_bytes = None, 0
     if save is None:  # scratch for the kernel the library would like to use (the library never allocates)
         ws_bytes = int(_lib.lib().gw_edge_update_workspace_bytes(batch, n_edges, xs, xd, ei, wc, flags))

@@ -86,9 +86,13 @@ extern "C" {
  *     n - 1), so the buffer always holds sum(e') (plain load / add / store; at most 16 destinations per tile);
  *   - every operand projected with a batch-shared residual (first processor block): as without the flag (agg += by atomics on a
  *     zero fill), the padding columns are skipped.
- * GW_EDGE_AGG_BF16K (with GW_EDGE_SEGMENT_TILES, no residual): `agg` points to bf16 rows in K order (GW_LAYOUT_ROWS_BF16K). */
+ * GW_EDGE_AGG_BF16K (with GW_EDGE_SEGMENT_TILES, no residual): `agg` points to bf16 rows in K order (GW_LAYOUT_ROWS_BF16K).
+ * GW_EDGE_SEGMENT_SPLIT (with GW_EDGE_SEGMENT_TILES, no residual, fp32 agg): a destination with more than 64 edges (a polar
+ * mesh cell of the encoder graph, encoder.py:75-104) is allowed: its run starts a fresh tile and continues over whole tiles; the
+ * pieces are partial sums that are ADDED with fp32 atomics, all other rows are written - agg must be zero-filled by the caller. */
 #define GW_EDGE_SEGMENT_TILES 2
 #define GW_EDGE_AGG_BF16K 4
+#define GW_EDGE_SEGMENT_SPLIT 8
 
 /* Library / ABI version and last error text (thread local). */
 int gw_version(void);

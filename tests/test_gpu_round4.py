@@ -32,6 +32,7 @@ def _graph(rs, n_src, n_dst, degrees):
     ("many-slots", [1, 2, 3], 2, 300),            # more than 16 destination slots per tile: several slot groups
     ("long-runs", [0, 1, 30, 64, 40], 2, 37),     # runs up to a whole tile, destinations without edges, much padding
     ("tiny", [2], 1, 3),
+    ("split-runs", [1, 5, 11, 150, 64, 65, 300], 2, 40),   # runs longer than a tile: pieces over whole tiles, summed by atomics
 ])
 @pytest.mark.parametrize("half", [True, False])
 def test_segment_tiles_edge_update_against_emulation_and_oracle(case, degrees, B, n_dst, half):
@@ -48,8 +49,8 @@ def test_segment_tiles_edge_update_against_emulation_and_oracle(case, degrees, B
     n_src = 50
     src, dst = _graph(rs, n_src, n_dst, degrees)
     plan = plan_from_coo(src, dst, n_src, n_dst)
-    seg = plan.seg_tiles()
-    assert seg is not None and seg.n_pad % 64 == 0
+    seg = plan.seg_tiles(split=True)
+    assert seg is not None and seg.n_pad % 64 == 0 and seg.split == (case == "split-runs")
     E = plan.num_edges
     ep = gw.EdgeProcessor(256, 256, 256, 2, "LayerNorm")
     deterministic_fill_(ep, seed=23)
@@ -85,10 +86,14 @@ def test_segment_tiles_edge_update_against_emulation_and_oracle(case, degrees, B
     s_dev, d_dev = seg.src.to(DEV), seg.dst.to(DEV)
     got = {}
     for kind in ("fp32", "bf16k"):
-        canary = 768.0  # (representable in bf16)
+        canary = 0.0 if seg.split else 768.0  # (representable in bf16; split runs: the caller's zero fill)
+        if seg.split and kind == "bf16k":
+            got[kind] = got["fp32"]  # (pieces meet in fp32 atomics: fp32 rows only)
+            continue
         agg = torch.full((B * n_dst, 256), canary, device=DEV, dtype=torch.float32 if kind == "fp32" else torch.bfloat16)
         ops.edge_update_forward(pm, B, s_dev, d_dev, Operand(ps_dev, n_src, 256, projected=True), ops.ZERO,
-                                Operand(pe_pad, 0, 256, projected=True), ops.ZERO, n_dst, agg, None, segment_tiles=True)
+                                Operand(pe_pad, 0, 256, projected=True), ops.ZERO, n_dst, agg, None, segment_tiles=True,
+                                segment_split=seg.split)
         torch.cuda.synchronize()
         a = (agg.cpu() if kind == "fp32" else rows_from_bf16k(agg)).double().reshape(B, n_dst, 256)
         has = torch.zeros(n_dst, dtype=torch.bool)

@@ -79,3 +79,73 @@ def test_plan_from_coo_rejects_bad_indices_and_handles_empty():
         plan_from_coo(np.array([0, 5]), np.array([0, 1]), 5, 2)
     p = plan_from_coo(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 3, 3)
     assert p.num_edges == 0 and p.dst_ptr().tolist() == [0, 0, 0, 0]
+
+
+def _check_seg_tiles(plan, st):
+    """Invariants the segment-aligned kernels rely on (include/gw_amd.h: GW_EDGE_SEGMENT_TILES / _SPLIT)."""
+    assert st.n_pad % 64 == 0 and st.src.shape[0] == st.dst.shape[0] == st.n_pad
+    d = st.dst.numpy().reshape(-1, 64)
+    valid = d >= 0
+    assert (valid[:, :-1] >= valid[:, 1:]).all(), "padding columns sit at the end of a tile"
+    assert valid[:, 0].all(), "no empty tile"
+    assert (st.src.numpy()[~valid.reshape(-1)] == 0).all()
+    # the padded list is the sorted list with gaps
+    assert torch.equal(st.dst[st.pos], plan.dst) and torch.equal(st.src[st.pos], plan.src)
+    assert (np.diff(st.pos.numpy()) > 0).all()
+    # runs inside a tile are contiguous and destinations ascend through the padded list
+    flat = d.reshape(-1)
+    seen = flat[flat >= 0]
+    assert (np.diff(seen) >= 0).all()
+    slots = [len(np.unique(row[row >= 0])) for row in d]
+    assert max(slots) == st.max_slots
+    # a destination appears in more than one tile only as a split run: whole tiles, then the head of one more
+    tiles_of = {}
+    for t, row in enumerate(d):
+        for v in np.unique(row[row >= 0]):
+            tiles_of.setdefault(int(v), []).append(t)
+    multi = {v: ts for v, ts in tiles_of.items() if len(ts) > 1}
+    assert bool(multi) == st.split
+    for v, ts in multi.items():
+        assert ts == list(range(ts[0], ts[-1] + 1))
+        for t in ts[:-1]:
+            assert (d[t] == v).all()
+        assert d[ts[-1]][0] == v
+    assert st.complete == (len(tiles_of) == plan.n_dst)
+
+
+def test_segment_aligned_tiles_of_the_forecaster_graphs():
+    """GraphPlan.seg_tiles(): decoder (7 or 6 edges per grid node: 9 nodes per tile) and latent graph pack without splits; the
+    encoder graph (polar mesh cells collect hundreds of grid nodes) only with split runs."""
+    g = build_forecast_graphs(regular_lat_lons(2.0), 2)
+    for plan in (g.dec_plan, g.lat_plan):
+        st = plan.seg_tiles()
+        assert st is not None and not st.split and st.complete and st.max_slots <= 16
+        assert st.n_pad <= 1.05 * plan.num_edges + 64
+        _check_seg_tiles(plan, st)
+        assert plan.seg_tiles(split=True).n_pad == st.n_pad
+    assert g.enc_plan.seg_tiles() is None
+    st = g.enc_plan.seg_tiles(split=True)
+    assert st is not None and st.split
+    _check_seg_tiles(g.enc_plan, st)
+    rows = torch.arange(g.enc_plan.num_edges, dtype=torch.float32)[:, None].expand(-1, 3).contiguous()
+    padded = st.pad_rows(rows)
+    assert torch.equal(padded[st.pos], rows) and padded.shape[0] == st.n_pad
+    pb = st.pad_batched_rows(torch.cat([rows, rows + 0.5]), 2)
+    assert torch.equal(pb.reshape(2, st.n_pad, 3)[1][st.pos], rows + 0.5)
+
+
+def test_segment_aligned_tiles_of_random_graphs():
+    rs = np.random.RandomState(3)
+    for degrees in ([1, 2, 3], [0, 7, 6], [64, 1, 63], [0, 0, 200, 65, 2]):
+        n_dst = 57
+        deg = rs.choice(degrees, size=n_dst)
+        deg[0] = max(deg[0], 1)
+        dst = np.repeat(np.arange(n_dst), deg)
+        src = rs.randint(0, 9, size=dst.size)
+        plan = plan_from_coo(src, dst, 9, n_dst)
+        long_run = int(deg.max()) > 64
+        assert (plan.seg_tiles() is None) == long_run
+        st = plan.seg_tiles(split=True)
+        assert st.split == long_run
+        _check_seg_tiles(plan, st)
+    assert plan_from_coo(np.zeros(0, int), np.zeros(0, int), 3, 3).seg_tiles() is None

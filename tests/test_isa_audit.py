@@ -138,7 +138,8 @@ def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path
         body = text[text.index(name + ":"):]
         body = body[:body.index(".end_amdhsa_kernel")]
         lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
-        mfma = [i for i, ln in enumerate(lines) if ln.startswith("v_mfma_f32_16x16x32_bf16")]
+        # (the segment-aligned form with fp16 product rows runs its middle layer on fp16 operands: v_mfma_f32_16x16x32_f16)
+        mfma = [i for i, ln in enumerate(lines) if ln.startswith(("v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_f16"))]
         assert len(mfma) == (264 if segt else 256), (name, len(mfma))
         layers = []
         for i in mfma:
@@ -155,6 +156,40 @@ def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path
         for phase in (mfma[:128], mfma[128:]):
             gaps = [b_ - a_ - 1 for a_, b_ in zip(phase, phase[1:])]
             assert max(gaps) <= (20 if segt else 12), (name, max(gaps))
+
+
+@pytest.mark.timeout(600)
+def test_processor_form_on_segment_tiles_keeps_weights_resident_and_has_no_scratch(tmp_path):
+    """csrc/gw_edge16p.hip (processor block on segment-aligned tiles): both instantiations (e' written / dropped) fit two waves
+    per SIMD without scratch, keep their matrix in the AGPR half (256 layer MFMAs read a weight operand from an AGPR - team A as
+    the A operand, team B's transposed layer as the B operand - plus 8 segment-sum MFMAs on plain VGPRs), make no AGPR <-> VGPR
+    copies after the prologue, reduce the LayerNorm statistics on DPP row rotations (4 steps x 8 sums x 4 groups) and stay
+    within the LDS of one CU."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graph_weather_amd", "csrc", "gw_edge16p.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "e.o", "-save-temps"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+    text = (tmp_path / "gw_edge16p-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    names = re.findall(r"^(_Z\w*edge16p_kernelILb[01]E\w*):", text, re.M)
+    assert len(names) == 2, names
+    for name in names:
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1)) == 0, name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 256, name
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        mfma = [ln for ln in lines if ln.startswith("v_mfma_f32_16x16x32_bf16")]
+        assert len(mfma) == 264, (name, len(mfma))
+        ops = [[o.strip() for o in ln.split(None, 1)[1].split(",")] for ln in mfma]
+        assert sum(1 for o in ops if o[1].startswith("a[")) == 128, name   # middle layer: weight = A operand
+        assert sum(1 for o in ops if o[2].startswith("a[")) == 128, name   # transposed output layer: weight = B operand
+        first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
+        assert not any(ln.startswith("v_accvgpr") for ln in lines[first_barrier:]), name
+        assert sum(1 for ln in lines if ln.startswith("v_add_f32_dpp") and "row_ror" in ln) == 128, name
 
 
 @pytest.mark.timeout(600)
