@@ -43,10 +43,10 @@ for name in ("fetch", "write", "sq", "grbm"):
         # kernels (node-side MLPs) are averaged per instantiation
         # (round 4: the decoder runs edge16t_kernel<true, true, false, true> - segment-aligned tiles - the encoder the form
         #  without them, processor blocks 1..8 the layer-1 kernel + edge16p_kernel<e' out>)
-        if kind.startswith("edge16t_kernel<true") and kind.rstrip(">").endswith("true"):
-            label = "decoder"
-        elif kind.startswith("edge16t_kernel<true"):
-            label = "encoder"
+        # (both run the gather form on segment-aligned tiles since the encoder's split runs: launch 0, 2, 4, ... of that
+        #  instantiation is the encoder's edge update, the odd ones are the decoder's)
+        if kind.startswith("edge16t_kernel<true"):
+            label = "encoder" if i % 2 == 0 else "decoder"
         elif kind.startswith(("edge16t_kernel", "edge16p_kernel")) or kind == "edge16_l1_kernel":
             label = "blocks1-8"
         elif kind.startswith("edge16_kernel"):
