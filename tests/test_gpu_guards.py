@@ -357,3 +357,78 @@ def test_chain_backward_stays_inside_its_buffers(rows, n_chain, n_fan):
         return {f"o{i}": o for i, o in enumerate(outs)}
 
     _both(run)
+
+
+def _seg_graph(rs, n_src, n_dst, degrees):
+    from graph_weather_amd.graphs import plan_from_coo
+
+    deg = rs.choice(degrees, size=n_dst)
+    deg[-1] = max(int(deg[-1]), 1)  # the last destination row is written
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rs.randint(0, n_src, size=dst.size)
+    src[0] = n_src - 1           # ... and the last source row is read
+    return plan_from_coo(src, dst, n_src, n_dst)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("B,n_src,n_dst,degrees,kind", [(2, 50, 41, [7, 7, 6], "bf16k"), (1, 7, 3, [2], "fp32"), (3, 19, 77, [1, 2, 3], "bf16k"),
+                                                        (16, 20, 25, [0, 5, 40, 64], "fp32"), (2, 33, 9, [3, 70, 150, 64], "split")])
+def test_segment_tile_edge_update_stays_inside_its_buffers(half, B, n_src, n_dst, degrees, kind):
+    """Round-4 gather form on segment-aligned tiles (GW_EDGE_SEGMENT_TILES; aggregate written as fp32 rows, as bf16 rows in K
+    order, or - runs longer than a tile - added by atomics): padded index arrays, padded per-edge rows, a destination table whose
+    rows without edges are never touched."""
+    rs = np.random.RandomState(n_dst + 5)
+    mlp = _mlp(rs, 768, 256, 256, True, torch.bfloat16)
+    plan = _seg_graph(rs, n_src, n_dst, degrees)
+    seg = plan.seg_tiles(split=(kind == "split"))
+    assert seg is not None and seg.split == (kind == "split")
+    ps = torch.from_numpy(rs.standard_normal((B * n_src, 256)).astype(np.float32))
+    pe = seg.pad_rows(torch.from_numpy(rs.standard_normal((plan.num_edges, 256)).astype(np.float32)))
+
+    def run(g):
+        pm = _packed(g, mlp, ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+        agg = g.wrap(torch.zeros(B * n_dst, 256, dtype=torch.bfloat16 if kind == "bf16k" else torch.float32))
+        tab = g.wrap(ps.half() if half else ps)
+        ops.edge_update_forward(pm, B, g.wrap(seg.src), g.wrap(seg.dst), Operand(tab, n_src, 256, projected=True), ops.ZERO,
+                                Operand(g.wrap(pe), 0, 256, projected=True), ops.ZERO, n_dst, agg, None, segment_tiles=True,
+                                segment_split=seg.split)
+        return {"agg": agg}
+
+    _both(run)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("B,n,degrees,want_e", [(2, 41, [7, 7, 6], True), (1, 3, [2], False), (3, 77, [4, 5, 6, 7], True), (16, 25, [7], False)])
+def test_processor_form_on_segment_tiles_stays_inside_its_buffers(half, B, n, degrees, want_e):
+    """Round-4 processor-block form (edge16_l1_kernel + csrc/gw_edge16p.hip): padded per-sample edge tiles as operand and
+    residual, both node products gathered, e' tiles written or dropped, the aggregate accumulated in place."""
+    from .helpers import edge_tiles_from_rows
+
+    rs = np.random.RandomState(n + 11)
+    mlp = _mlp(rs, 768, 256, 256, True, torch.bfloat16)
+    plan = _seg_graph(rs, n, n, degrees)
+    seg = plan.seg_tiles()
+    assert seg is not None and seg.max_slots <= 16
+    E, P = plan.num_edges, seg.n_pad
+    ps = torch.from_numpy(rs.standard_normal((B * n, 256)).astype(np.float32))
+    pd = torch.from_numpy(rs.standard_normal((B * n, 256)).astype(np.float32))
+    e = torch.from_numpy(rs.standard_normal((B * E, 256)).astype(np.float32))
+    e_pad = seg.pad_batched_rows(e, B).reshape(B, P, 256)
+    tiles_host = edge_tiles_from_rows(e_pad).view(torch.uint8).reshape(-1)
+    agg0 = torch.from_numpy(rs.standard_normal((B * n, 256)).astype(np.float32))
+
+    def run(g):
+        pm = _packed(g, mlp, ((0, 256), (256, 512), (512, 768)), torch.bfloat16)
+        tiles = g.wrap(tiles_host)
+        agg = g.wrap(agg0)
+        e_out = g.wrap(torch.zeros(ops.edge_tiles_bytes(B, P), dtype=torch.uint8)) if want_e else None
+        et = Operand(tiles, P, 256, tiles=True)
+        ops.edge_update_forward(pm, B, g.wrap(seg.src), g.wrap(seg.dst), Operand(g.wrap(ps.half() if half else ps), n, 256, projected=True),
+                                Operand(g.wrap(pd.half() if half else pd), n, 256, projected=True), et, et, n, agg, e_out,
+                                segment_tiles=True)
+        out = {"agg": agg}
+        if e_out is not None:
+            out["e_out"] = e_out.view(torch.bfloat16)
+        return out
+
+    _both(run)
