@@ -68,7 +68,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # GW_TUNING=1 builds the A/B knobs in (env-selected kernel variants, skip switches that give wrong results - used by
     # scripts/gpu_tune.sh / gpu_ab.sh only); the shipped library is built without them.  The flag set is recorded beside
     # the library so that switching modes rebuilds.
-    flags = HIPCC_FLAGS + (["-DGW_TUNING"] if os.environ.get("GW_TUNING") == "1" else [])
+    flags = HIPCC_FLAGS + (["-DGW_TUNING"] + os.environ.get("GW_HIPCC_EXTRA", "").split() if os.environ.get("GW_TUNING") == "1" else [])
     stamp = LIB_PATH + ".flags"
     want = " ".join(flags)
     try:

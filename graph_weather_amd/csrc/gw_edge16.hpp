@@ -120,6 +120,18 @@ __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8
 }
 // The same instruction on fp16 operands (same rate, 11-bit significands): the middle layer of the segment-aligned team kernel,
 // whose B operand - relu of a sum of fp16 product rows - is then made with packed fp16 arithmetic and no conversion.
+// The first product of an accumulator chain with the bias as its C operand (acc = w . b + c): the accumulator is DEFINED here -
+// no bias read from LDS per group, nothing to keep alive before its first MFMA (early clobber: the product reads its sources
+// over several passes).
+__device__ __forceinline__ void mfma_a_c(f32x4& acc, const bf16x8& w, const bf16x8& b, const f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma_t_c(f32x4& acc, const bf16x8& b, const bf16x8& w, const f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(b), "a"(w), "v"(c));
+}
+__device__ __forceinline__ void mfma_a_f16_c(f32x4& acc, const bf16x8& w, const bf16x8& b, const f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(c));
+}
 __device__ __forceinline__ void mfma_a_f16(f32x4& acc, const bf16x8& w, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
 }
@@ -133,6 +145,37 @@ __device__ __forceinline__ void mfma_t(f32x4& acc, const bf16x8& b, const bf16x8
 // x + (x of the lane N places further round this lane's row of 16): one VALU instruction with a DPP operand (no LDS; written as
 // asm because the builtin comes out as v_mov_b32_dpp into a zeroed register + the add).  A DPP operand must not have been written
 // by one of the two preceding VALU instructions (asm is opaque to the hazard recogniser): callers keep producer and use apart.
+// Reduce-scatter of 8 per-lane sums over the 16 lanes of a DPP row in 16 instructions (an all-reduce of each takes 4 x 8):
+//   step A  row_mirror       (l <-> 15 - l): lanes 0-7 keep v[0..3], lanes 8-15 keep v[4..7]        8 ops -> 4 registers
+//   step B  row_half_mirror  (l <-> 7 - l within 8): banks 0 / 2 keep the first two, banks 1 / 3 the other two   4 ops -> 2
+//   steps C, D  quad_perm [2,3,0,1], [1,0,3,2] on both                                                 4 ops
+// bank_mask picks the 4-lane banks an instruction writes, so no select is needed.  Afterwards every lane of bank b holds the
+// complete sums (v[2 (b & 1)], v[2 (b & 1) + 1]) of the first (b < 2) or second (b >= 2) four inputs.
+// OP = 0 .. 15 in issue order; WAIT: two wait states in front (no instruction lies between producer and DPP use).
+#define GW_DPP_ADD(ctrl, bank, dstc, dst, src)                                                                           \
+  do {                                                                                                                   \
+    if constexpr (WAIT) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:" bank : dstc(dst) : "v"(src)); \
+    else asm volatile("v_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:" bank : dstc(dst) : "v"(src));          \
+  } while (0)
+template <int OP, bool WAIT>
+__device__ __forceinline__ void row_reduce_scatter_op(const float (&lo)[4], const float (&hi)[4], float (&a)[4], float (&b)[2],
+                                                      float (&c)[2], float (&d)[2]) {
+  if constexpr (OP < 8) {  // step A: a[k] <- lo[k] (lanes 0-7), hi[k] (lanes 8-15)
+    constexpr int k = OP >> 1;
+    if constexpr ((OP & 1) == 0) GW_DPP_ADD("row_mirror", "0x3", "=v", a[k], lo[k]);
+    else GW_DPP_ADD("row_mirror", "0xc", "+v", a[k], hi[k]);
+  } else if constexpr (OP < 12) {  // step B: b[k] <- a[k] (banks 0, 2), a[k + 2] (banks 1, 3)
+    constexpr int k = (OP - 8) >> 1;
+    if constexpr ((OP & 1) == 0) GW_DPP_ADD("row_half_mirror", "0x5", "=v", b[k], a[k]);
+    else GW_DPP_ADD("row_half_mirror", "0xa", "+v", b[k], a[k + 2]);
+  } else if constexpr (OP < 14) {
+    GW_DPP_ADD("quad_perm:[2,3,0,1]", "0xf", "=v", c[OP - 12], b[OP - 12]);
+  } else {
+    GW_DPP_ADD("quad_perm:[1,0,3,2]", "0xf", "=v", d[OP - 14], c[OP - 14]);
+  }
+}
+#undef GW_DPP_ADD
+
 template <int N, bool WAIT = false>
 __device__ __forceinline__ float add_row_ror(float x) {
   float y;

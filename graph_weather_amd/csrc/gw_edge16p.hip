@@ -117,11 +117,15 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
 
   bool stamp = false;
   const int ts_thread = team_b ? 256 : 0, ts_base = (int)blockIdx.x * 32 + (team_b ? 16 : 0);
+#ifdef GW_TUNING  // (phase clocks exist in tuning builds only: a scalar branch per stamp is not free in a loop bound by what a wave can issue)
 #define GW_TS(i)                                                      \
   if (stamp) {                                                        \
     const unsigned long long c_ = gw_clock();                         \
     if ((int)threadIdx.x == ts_thread) a.dbg[ts_base + (i)] = c_;     \
   }
+#else
+#define GW_TS(i)
+#endif
 
   if (n == 0) return;
   __syncthreads();  // parameter blocks visible
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
         f32x4 acc[2][4];
         unsigned pk[8];
         __builtin_amdgcn_s_setprio(1);
-        team_layer<2, false, false, 18>(
+        team_layer<2, false, false, 18, true>(
             acc, wr, h1, lane, [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + fresh(f0) + 16 * t); },  // b_mid
             [&](int g, int m, f32x4 (&ac)[4]) {
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -349,9 +353,9 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
       GW_TS(7)
       if (s < n) {
         // ---- output layer of tile s, transposed; per group the sums / sums of squares over the wave's 64 features ----
-        float s1[4], s2[4];
+        float s1[4], s2[4], ra[4], rb[2], rc[2], rd[2];  // (running sums of 4 edges; registers of their 16-lane reduce-scatter)
         __builtin_amdgcn_s_setprio(1);
-        team_layer<4, true, false, 4>(
+        team_layer<4, true, false, 4, true>(
             o, wr, h2, lane, [&](f32x4& dst, int t) { dst = parT[(tw * 16 + fresh(j)) * 4 + t]; },
             [&](int g, int mm, f32x4 (&ac)[4]) {
               if (mm < 16) {
@@ -360,17 +364,9 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
                 s1[r] = t == 0 ? x : s1[r] + x;
                 s2[r] = t == 0 ? x * x : fmaf(x, x, s2[r]);
               } else {
-                const int lo = ((mm - 16) * 32) / 12, hi = ((mm - 15) * 32) / 12;
-#pragma unroll
-                for (int op = lo; op < hi; ++op) {
-                  const int step = op >> 3, v = op & 7;
-                  float& x = v < 4 ? s1[v] : s2[v - 4];
-                  x = step == 0 ? (g == 3 ? add_row_ror<8, true>(x) : add_row_ror<8>(x))
-                                : (step == 1 ? add_row_ror<4>(x) : (step == 2 ? add_row_ror<2>(x) : add_row_ror<1>(x)));
-                }
-                if (mm == 27 && j == 0) {
-                  *(f32x4*)(ln1 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s1[0], s1[1], s1[2], s1[3]};
-                  *(f32x4*)(ln2 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+                reduce_ops(g, mm, s1, s2, ra, rb, rc, rd);
+                if (mm == 27 && (j & 3) == 0) {  // bank b = j >> 2 holds the sums (2 (b & 1), + 1) of s1 (b < 2) / s2: edges 4 q + ...
+                  *(float2*)(ln1 + (fresh(j) >> 3) * (4 * kTileCols) + tw * kTileCols + 16 * g + 4 * fresh(q) + 2 * ((fresh(j) >> 2) & 1)) = float2{rd[0], rd[1]};
                 }
               }
             });

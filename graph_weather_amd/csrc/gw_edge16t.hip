@@ -62,7 +62,8 @@ constexpr int kS_ParP = kT_Stage + 8192;     // float[2][256]: gamma, beta in th
 constexpr int kS_Cnt = kT_Stage + 10240;     // float[4][64]: edges of each destination slot
 constexpr int kS_Part = kT_Stage + 11264;    // int[4][64]: 1 = the slot is a piece of a run that continues in a neighbouring tile
 constexpr int kS_Smat = kT_Stage + 12288;    // uint4[4 ring][4 slot groups][2 halves][64 lanes]: the B operand S of the segment sums
-static_assert(kS_Smat + 4 * 4 * 2 * 64 * 16 <= kT_Stage + kTileCols * kStageLd * 4, "the slot tables fit the staging area");
+constexpr int kS_Zc0 = kS_Smat + 4 * 4 * 2 * 64 * 16;  // half4[8][256 threads]: the cached layer-1 part of column pass 0 (as kT_Zc holds pass 1's)
+static_assert(kS_Zc0 + 8 * 256 * 8 <= kT_Stage + kTileCols * kStageLd * 4, "the slot tables fit the staging area");
 
 // GATHER form: exactly one projected table has a row set per batch element (the decoder's P_s); PH: that table is fp16 rows
 // (GW_LAYOUT_ROWS_F16).  The other projected tables are fp32 rows shared by the batch and cached per chunk.
@@ -182,11 +183,15 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   // team B [16, 32)); tuning builds: a.tune bit 0 = no s_setprio around the MFMA phases, bit 1 = no residual loads (zeros)
   bool stamp = false;
   const int ts_thread = team_b ? 256 : 0, ts_base = (int)blockIdx.x * 32 + (team_b ? 16 : 0);
+#ifdef GW_TUNING  // (phase clocks exist in tuning builds only: a scalar branch per stamp is not free in a loop bound by what a wave can issue)
 #define GW_TS(i)                                                      \
   if (stamp) {                                                        \
     const unsigned long long c_ = gw_clock();                         \
     if ((int)threadIdx.x == ts_thread) a.dbg[ts_base + (i)] = c_;     \
   }
+#else
+#define GW_TS(i)
+#endif
   const bool use_prio = (GW_TUNE_ARG(a) & 1) == 0;
   const bool use_res = (GW_TUNE_ARG(a) & 2) == 0;
   const bool t_skip_ln = (GW_TUNE_ARG(a) & 4) != 0;     // (wrong results: timing experiments) team B skips LayerNorm / staging
@@ -205,6 +210,8 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   for (int s = 0; s < 8; ++s) zc[s][0] = zc[s][1] = half2_t{(_Float16)0.f, (_Float16)0.f};
   typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
   half4_t* const zc1 = (half4_t*)(lds + kT_Zc) + (threadIdx.x & 255);  // [s][thread]: + 256 s
+  // (segment-aligned form: pass 0's part sits in LDS too - 16 registers carried around team A's loop were 9 scratch loads per tile)
+  half4_t* const zc0 = (half4_t*)(lds + (SEGT ? kS_Zc0 : kT_Zc)) + (threadIdx.x & 255);
   int cached_eb = -1;
 
   // Unit u = 0..7 of a (column, piece) thread: 4 features = 8 bytes of one B-fragment slot of Hbuf1.
@@ -255,7 +262,9 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (cp == 0) {
+        if (cp == 0 && SEGT) {
+          zc0[256 * u] = half4_t{(_Float16)z[u].x, (_Float16)z[u].y, (_Float16)z[u].z, (_Float16)z[u].w};
+        } else if (cp == 0) {
           zc[u][0] = half2_t{(_Float16)z[u].x, (_Float16)z[u].y};
           zc[u][1] = half2_t{(_Float16)z[u].z, (_Float16)z[u].w};
         } else {
@@ -278,10 +287,10 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
   auto cache_add = [&](f32x4 (&z)[8], int cp) {  // z += the cached batch-shared part of this column pass
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (cp == 0) {
+      if (cp == 0 && !SEGT) {
         z[u] += f32x4{(float)zc[u][0][0], (float)zc[u][0][1], (float)zc[u][1][0], (float)zc[u][1][1]};
       } else {
-        const half4_t c = zc1[256 * u];
+        const half4_t c = cp == 0 ? zc0[256 * u] : zc1[256 * u];
         z[u] += f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
       }
     }
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
       const int i = u >> 1, e = u & 1;
       const h4_t x4 = h4_t{xh[i][4 * e], xh[i][4 * e + 1], xh[i][4 * e + 2], xh[i][4 * e + 3]};
       h4_t c4;
-      if (cp == 0) c4 = h4_t{zc[u][0][0], zc[u][0][1], zc[u][1][0], zc[u][1][1]};
+      if (cp == 0) c4 = zc0[256 * u];  // (F16MID implies the segment-aligned form: both passes' cached parts in LDS)
       else c4 = zc1[256 * u];
       const h4_t hsum = __builtin_elementwise_min(__builtin_elementwise_max(x4 + c4, zero), cap);
       *(h4_t*)(out + uslot(u)) = hsum;
@@ -561,9 +570,15 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         f32x4 acc[2][4];
         unsigned pk[8];  // bf16 pairs of the group being packed: row tile t -> pk[2 t], pk[2 t + 1]
         if (use_prio) __builtin_amdgcn_s_setprio(1);
+        // (SEGT: ONE address register for the layer's bias reads - 16-byte reads at immediate offsets instead of a recomputed
+        //  address and two 8-byte reads per row tile and group: the layer is bound by what a wave can issue between its MFMAs)
+        const float* const pbm = SEGT ? par_l : nullptr;
         team_layer<2, false, F16MID, (SEGT ? 18 : 28)>(  // (SEGT: the pieces read the accumulators in slots 2..17 only)
             acc, wr, h1, lane,
-            [&](f32x4& dst, int t) { dst = *(const f32x4*)(par_l + 16 * t); },  // b_mid
+            [&](f32x4& dst, int t) {  // b_mid
+              if constexpr (SEGT) dst = *(const f32x4*)__builtin_assume_aligned(pbm + 16 * t, 16);
+              else dst = *(const f32x4*)(par_l + 16 * t);
+            },
             [&](int g, int m, f32x4 (&ac)[4]) {
               // m = 0..15: relu of one accumulator value; 16..23: bf16 pack of a pair; 24 / 25: the 16-byte store of K-step s0 / s0 + 1
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -708,6 +723,20 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
             // (asm MFMAs on plain vector registers: the builtin lets the allocator put these accumulators into the AGPR half
             //  and rotate the resident weights out of their way; wait states as in layer_group - inline asm is opaque to the
             //  hazard recogniser; an accumulator is touched by every 4th MFMA)
+            // (the destination row, the slot's edge count and gamma / beta of the lane's 16 positions are requested in front of the
+            //  product: their LDS round trips run under its MFMAs instead of behind them)
+            const int slot = 16 * nt + j;
+            const bool mine = slot < nslots && GW_SKIP(a) != 1;
+            const int p0 = fresh(64 * tw + 16 * q);
+            const int drow = dsl[ring * kTileCols + (mine ? slot : 0)];
+            const float cnt = cntf[ring * kTileCols + (mine ? slot : 0)];
+            f32x4 gm[4], bt[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              gm[t] = *(const f32x4*)(parP + p0 + 4 * t);
+              bt[t] = *(const f32x4*)(parP + 256 + p0 + 4 * t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 dsum[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) dsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -718,19 +747,13 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
               for (int t = 0; t < 4; ++t)
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(dsum[t]) : "v"(ypk[t][h]), "v"(sb[h]));
             asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dsum[0]), "+v"(dsum[1]), "+v"(dsum[2]), "+v"(dsum[3]));
-            const int slot = 16 * nt + j;
-            if (slot < nslots && GW_SKIP(a) != 1) {
+            if (mine) {
               // agg[row][position p0 + 4 t + r] = gamma sum + count beta (parameters in position order: one float4 per t)
-              const size_t row = (size_t)(t_prev.b * a.n_dst + dsl[ring * kTileCols + slot]);
-              const float cnt = cntf[ring * kTileCols + slot];
-              const int p0 = fresh(64 * tw + 16 * q);
+              const size_t row = (size_t)(t_prev.b * a.n_dst + drow);
 #pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const f32x4 gm = *(const f32x4*)(parP + p0 + 4 * t);
-                const f32x4 bt = *(const f32x4*)(parP + 256 + p0 + 4 * t);
+              for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dsum[t][r] = fmaf(dsum[t][r], gm[r], cnt * bt[r]);
-              }
+                for (int r = 0; r < 4; ++r) dsum[t][r] = fmaf(dsum[t][r], gm[t][r], cnt * bt[t][r]);
               if (a.agg_bf16k) {
                 __bf16* dstp = (__bf16*)a.agg + row * 256 + p0;
                 *(GW_AS1 bf16x8*)dstp = to_bf16x8(dsum[0], dsum[1]);
@@ -756,9 +779,9 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
         if (s < n) {
           // ---- output layer of tile s, transposed: Hbuf2 -> registers; per group (in the shadow of the next group's MFMAs) the
           // sums and sums of squares over this wave's 64 features: 4 row tiles in registers, then the 16 feature lanes of the row ----
-          float s1[4], s2[4];
+          float s1[4], s2[4], ra[4], rb[2], rc[2], rd[2];  // (running sums of 4 edges; registers of their 16-lane reduce-scatter)
           if (use_prio) __builtin_amdgcn_s_setprio(1);
-          team_layer<4, true, false, 4>(  // (four accumulator sets: the next group's is free - its bias is read 28 MFMAs ahead)
+          team_layer<4, true, false, 4, true>(  // (four accumulator sets: the next group's is free - its bias is read 28 MFMAs ahead)
               o, wr, h2, lane,
               [&](f32x4& dst, int t) { dst = parT[(tw * 16 + fresh(j)) * 4 + t]; },  // b_out of the lane's feature of tile t x 4 edges
               [&](int g, int mm, f32x4 (&ac)[4]) {
@@ -768,19 +791,9 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
                   s1[r] = t == 0 ? x : s1[r] + x;
                   s2[r] = t == 0 ? x * x : fmaf(x, x, s2[r]);
                 } else {  // 12 slots: 4 rotate-and-add steps for each of the 8 sums, then the partial sums of the 4 edges -> LDS
-                  const int lo = ((mm - 16) * 32) / 12, hi = ((mm - 15) * 32) / 12;
-#pragma unroll
-                  for (int op = lo; op < hi; ++op) {
-                    const int step = op >> 3, v = op & 7;
-                    float& x = v < 4 ? s1[v] : s2[v - 4];
-                    // (first step: the sums come from the compiler's own VALU code.  Inside the layer a whole filler slot lies
-                    //  between producer and use; in the tail after the last MFMA - group 3 - nothing does: wait states there)
-                    x = step == 0 ? (g == 3 ? add_row_ror<8, true>(x) : add_row_ror<8>(x))
-                                  : (step == 1 ? add_row_ror<4>(x) : (step == 2 ? add_row_ror<2>(x) : add_row_ror<1>(x)));
-                  }
-                  if (mm == 27 && j == 0) {
-                    *(f32x4*)(ln1 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s1[0], s1[1], s1[2], s1[3]};
-                    *(f32x4*)(ln2 + tw * kTileCols + 16 * g + 4 * fresh(q)) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+                  reduce_ops(g, mm, s1, s2, ra, rb, rc, rd);
+                  if (mm == 27 && (j & 3) == 0) {  // bank b = j >> 2 holds the sums (2 (b & 1), + 1) of s1 (b < 2) / s2: edges 4 q + ...
+                    *(float2*)(ln1 + (fresh(j) >> 3) * (4 * kTileCols) + tw * kTileCols + 16 * g + 4 * fresh(q) + 2 * ((fresh(j) >> 2) & 1)) = float2{rd[0], rd[1]};
                   }
                 }
               });
