@@ -149,7 +149,10 @@ def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path
         assert len(layers) == 256, f"{name}: {len(layers)} MFMAs take their weight operand from an AGPR"
         if segt:  # team B's layer: activations as A (VGPR), weights as B (AGPR)
             assert sum(1 for i in layers if lines[i].split(None, 1)[1].split(",")[2].strip().startswith("a[")) == 128, name
-            assert sum(1 for ln in lines if ln.startswith("v_add_f32_dpp") and "row_ror" in ln) == 4 * 32, name
+            # LayerNorm sums: a 16-instruction reduce-scatter per group (8 row_mirror, 4 row_half_mirror, 2 + 2 quad_perm)
+            dpp = [ln for ln in lines if ln.startswith("v_add_f32_dpp")]
+            assert len(dpp) == 4 * 16 and sum("row_mirror" in ln for ln in dpp) == 32 and sum("row_half_mirror" in ln for ln in dpp) == 16 \
+                and sum("quad_perm" in ln for ln in dpp) == 16, (name, len(dpp))
         first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
         assert not any(ln.startswith("v_accvgpr") for ln in lines[first_barrier:]), name
         mfma = layers
@@ -163,7 +166,7 @@ def test_processor_form_on_segment_tiles_keeps_weights_resident_and_has_no_scrat
     """csrc/gw_edge16p.hip (processor block on segment-aligned tiles): both instantiations (e' written / dropped) fit two waves
     per SIMD without scratch, keep their matrix in the AGPR half (256 layer MFMAs read a weight operand from an AGPR - team A as
     the A operand, team B's transposed layer as the B operand - plus 8 segment-sum MFMAs on plain VGPRs), make no AGPR <-> VGPR
-    copies after the prologue, reduce the LayerNorm statistics on DPP row rotations (4 steps x 8 sums x 4 groups) and stay
+    copies after the prologue, reduce the LayerNorm statistics with a 16-instruction DPP reduce-scatter per group and stay
     within the LDS of one CU."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -189,7 +192,8 @@ def test_processor_form_on_segment_tiles_keeps_weights_resident_and_has_no_scrat
         assert sum(1 for o in ops if o[2].startswith("a[")) == 128, name   # transposed output layer: weight = B operand
         first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
         assert not any(ln.startswith("v_accvgpr") for ln in lines[first_barrier:]), name
-        assert sum(1 for ln in lines if ln.startswith("v_add_f32_dpp") and "row_ror" in ln) == 128, name
+        dpp = [ln for ln in lines if ln.startswith("v_add_f32_dpp")]
+        assert len(dpp) == 64 and sum("row_mirror" in ln for ln in dpp) == 32 and sum("quad_perm" in ln for ln in dpp) == 16, name
 
 
 @pytest.mark.timeout(600)
