@@ -335,14 +335,16 @@ __global__ __launch_bounds__(512, 2) void edge16t_kernel(const Edge16Args a) {
     char* out = h1 + pslot(32 * cp + gcol);
     const h4_t zero = h4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     const h4_t cap = h4_t{(_Float16)65504.f, (_Float16)65504.f, (_Float16)65504.f, (_Float16)65504.f};
+    // (all 8 cached parts first: reads interleaved with the Hbuf1 writes below are serialised behind them - the compiler cannot
+    //  tell the two LDS regions apart - and cost an LDS round trip per unit)
+    h4_t c4[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c4[u] = cp == 0 ? zc0[256 * u] : zc1[256 * u];  // (F16MID implies the segment-aligned form: both in LDS)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = u >> 1, e = u & 1;
       const h4_t x4 = h4_t{xh[i][4 * e], xh[i][4 * e + 1], xh[i][4 * e + 2], xh[i][4 * e + 3]};
-      h4_t c4;
-      if (cp == 0) c4 = zc0[256 * u];  // (F16MID implies the segment-aligned form: both passes' cached parts in LDS)
-      else c4 = zc1[256 * u];
-      const h4_t hsum = __builtin_elementwise_min(__builtin_elementwise_max(x4 + c4, zero), cap);
+      const h4_t hsum = __builtin_elementwise_min(__builtin_elementwise_max(x4 + c4[u], zero), cap);
       *(h4_t*)(out + uslot(u)) = hsum;
     }
   };
