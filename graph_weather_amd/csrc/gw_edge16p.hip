@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
       // half 2 - the middle layer covers the round trip
       bf16x8 rest[kGroups][2];
       if (EOUT && s >= 1) {
-        const char* rb = a.res_tiles + tile_row(t_prev) * kHBytes + (size_t)s0 * 1024 + (size_t)(fresh(lane) * 16);
+        const char* rb = a.res_tiles + tile_row(t_prev) * kHBytes + (size_t)s0 * 1024 + (size_t)(unsigned)(fresh(lane) * 16);
 #pragma unroll
         for (int g = 0; g < kGroups; ++g)
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
         // + residual -> bf16 -> the lane's own 16-byte slots of the e' tile ----
         const float* const sb0 = scr + (tw * 64 + 4 * fresh(q)) * kScrLd + fresh(j);         // rows of even 16-blocks (i < 4)
         const float* const sb1 = scr + (tw * 64 + 4 * (fresh(q) ^ 1)) * kScrLd + fresh(j);   // rows of odd 16-blocks (i >= 4): halves swapped
-        char* const ob = a.e_out_tiles + tile_row(t_prev) * kHBytes + (size_t)s0 * 1024 + (size_t)(fresh(lane) * 16);
+        char* const ob = a.e_out_tiles + tile_row(t_prev) * kHBytes + (size_t)s0 * 1024 + (size_t)(unsigned)(fresh(lane) * 16);
 #pragma unroll
         for (int g = 0; g < kGroups; ++g)
 #pragma unroll
