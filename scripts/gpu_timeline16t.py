@@ -36,6 +36,9 @@ with torch.no_grad():
         L.gw_debug_timestamps(None, 0, -1)
 rec = buf.cpu().numpy().reshape(cap, 32)
 rec = rec[rec[:, 0] != 0]
+if rec.shape[0] == 0:
+    raise SystemExit("no stamps: the phase clocks are compiled into tuning builds only - rebuild with GW_TUNING=1 "
+                     "(GW_TUNING=1 python -c 'import __graft_entry__ as g; g.build()')")
 print(WHICH, "batch", B, "workgroups", rec.shape[0], "env", {k: v for k, v in os.environ.items() if k.startswith("GW_")}, "(ticks = shader cycles)")
 # stamps are GW_TS(i) of csrc/gw_edge16t.hip, written on each workgroup's 4th pipeline step; offsets from the team's stamp 0
 LA = {0: "step start", 1: "after alpha", 2: "middle layer done", 6: "gather of the next tile issued", 7: "after beta", 9: "gather pass 0 stored",
