@@ -145,6 +145,14 @@ __device__ __forceinline__ void mfma_t(f32x4& acc, const bf16x8& b, const bf16x8
 // x + (x of the lane N places further round this lane's row of 16): one VALU instruction with a DPP operand (no LDS; written as
 // asm because the builtin comes out as v_mov_b32_dpp into a zeroed register + the add).  A DPP operand must not have been written
 // by one of the two preceding VALU instructions (asm is opaque to the hazard recogniser): callers keep producer and use apart.
+// a * b + c as ONE scalar VALU instruction the SLP vectoriser cannot pair (v_pk_fma_f32 needs adjacent register pairs: it assembles
+// them with moves, and a packed fp32 instruction beside MFMAs costs more than the two it replaces - MI355X_MICROARCH.md)
+__device__ __forceinline__ float fma_s(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 // Reduce-scatter of 8 per-lane sums over the 16 lanes of a DPP row in 16 instructions (an all-reduce of each takes 4 x 8):
 //   step A  row_mirror       (l <-> 15 - l): lanes 0-7 keep v[0..3], lanes 8-15 keep v[4..7]        8 ops -> 4 registers
 //   step B  row_half_mirror  (l <-> 7 - l within 8): banks 0 / 2 keep the first two, banks 1 / 3 the other two   4 ops -> 2

@@ -231,11 +231,13 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
         for (int g = 0; g < kGroups; ++g)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
+            // (scalar adds spelled out: left to the SLP vectoriser they become v_pk_add_f32 on register PAIRS it first has to
+            //  assemble with two moves each - three instructions for two adds in a phase that is bound by instruction issue)
             f32x4 lo, hi;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              lo[r] = sb0[(32 * ks + r) * kScrLd + 16 * g] + (float)rest[g][ks][r];
-              hi[r] = sb1[(32 * ks + 16 + r) * kScrLd + 16 * g] + (float)rest[g][ks][4 + r];
+              asm("v_add_f32 %0, %1, %2" : "=v"(lo[r]) : "v"(sb0[(32 * ks + r) * kScrLd + 16 * g]), "v"((float)rest[g][ks][r]));
+              asm("v_add_f32 %0, %1, %2" : "=v"(hi[r]) : "v"(sb1[(32 * ks + 16 + r) * kScrLd + 16 * g]), "v"((float)rest[g][ks][4 + r]));
             }
             *(GW_AS1 bf16x8*)(ob + (size_t)g * 8192 + ks * 1024) = to_bf16x8(lo, hi);
           }
@@ -298,7 +300,11 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
           f32x4 gnx0 = *(const f32x4*)(lnc + (tw * kTileCols + 4 * fresh(q)) * 2);
           f32x4 gnx1 = *(const f32x4*)(lnc + (tw * kTileCols + 4 * fresh(q) + 2) * 2);
           // scratch rows of this lane's features: local feature 16 (j >> 2) + 4 t + (j & 3) -> row scr_row(.), + 4 q + 16 g columns
-          float* const swr = scr + (tw * 64) * kScrLd + 4 * fresh(q);
+          // this lane's features: local feature fl + 4 t, fl = 16 (j >> 2) + (j & 3), scratch row scr_row(.) = fl + 4 (t ^ b) with
+          // b = bit 4 of fl: TWO row addresses for the tile (rows of even / odd t), everything else is an immediate offset
+          const int fl = 16 * (fresh(j) >> 2) + (fresh(j) & 3), fb = (fresh(j) >> 2) & 1;
+          float* const swr_e = scr + (tw * 64 + fl + 4 * fb) * kScrLd + 4 * fresh(q);
+          float* const swr_o = scr + (tw * 64 + fl + 4 * (1 - fb)) * kScrLd + 4 * fresh(q);
 #pragma unroll
           for (int g = 0; g < kGroups; ++g) {
             const f32x4 gab0 = gnx0, gab1 = gnx1;  // (rstd, -mean rstd) x edges 4 q + (0, 1) and + (2, 3)
@@ -309,16 +315,12 @@ __global__ __launch_bounds__(512, 2) void edge16p_kernel(const Edge16Args a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               f32x4 y;
-              y[0] = fmaf(fmaf(o[g][t][0], gab0[0], gab0[1]), gm4[t], bt4[t]);
-              y[1] = fmaf(fmaf(o[g][t][1], gab0[2], gab0[3]), gm4[t], bt4[t]);
-              y[2] = fmaf(fmaf(o[g][t][2], gab1[0], gab1[1]), gm4[t], bt4[t]);
-              y[3] = fmaf(fmaf(o[g][t][3], gab1[2], gab1[3]), gm4[t], bt4[t]);
-              if (EOUT) {
-                // (row index: j-dependent part computed per use - it folds to one v_mad with the immediate of (t, g))
-                const int fl = 16 * (fresh(j) >> 2) + (fresh(j) & 3);
-                const int row = (fl + 4 * t) ^ ((((fl + 4 * t) >> 4) & 1) << 2);
-                *(f32x4*)(swr + row * kScrLd + 16 * g) = y;
-              }
+              // (scalar FMAs spelled out, as the adds of the e' tile below: no v_pk_fma_f32 on assembled register pairs)
+              y[0] = fma_s(fma_s(o[g][t][0], gab0[0], gab0[1]), gm4[t], bt4[t]);
+              y[1] = fma_s(fma_s(o[g][t][1], gab0[2], gab0[3]), gm4[t], bt4[t]);
+              y[2] = fma_s(fma_s(o[g][t][2], gab1[0], gab1[1]), gm4[t], bt4[t]);
+              y[3] = fma_s(fma_s(o[g][t][3], gab1[2], gab1[3]), gm4[t], bt4[t]);
+              if (EOUT) *(f32x4*)((t & 1 ? swr_o : swr_e) + (t >> 1) * 8 * kScrLd + 16 * g) = y;  // (scratch row scr_row(fl + 4 t))
               asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ypk[t][g >> 1][2 * (g & 1)]) : "v"(y[0]), "v"(y[1]));
               asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ypk[t][g >> 1][2 * (g & 1) + 1]) : "v"(y[2]), "v"(y[3]));
             }
