@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 DTYPE_F32, DTYPE_BF16 = 0, 1
 LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16, LAYOUT_ROWS_BF16K = 0, 1, 2, 3
 EDGE_DETERMINISTIC, EDGE_SEGMENT_TILES, EDGE_AGG_BF16K, EDGE_SEGMENT_SPLIT = 1, 2, 4, 8
@@ -41,7 +41,8 @@ class GwOperand(Structure):
 class GwMlpWeights(Structure):
     _fields_ = [("w1", c_void_p * 3), ("b1", c_void_p), ("w_mid", c_void_p), ("b_mid", c_void_p), ("w_out", c_void_p),
                 ("b_out", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("hidden", c_int32),
-                ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32), ("ln_width", c_int32)]
+                ("n_mid", c_int32), ("n_out", c_int32), ("weight_dtype", c_int32), ("ln_width", c_int32), ("k_in", c_int32),
+                ("out_rows", c_int32)]
 
 
 PACK_MAX_ITEMS = 16

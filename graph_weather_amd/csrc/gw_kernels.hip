@@ -1247,6 +1247,9 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   if (head->hidden != 128 || head->n_mid != 1 || head->n_out > 80 || head->n_out <= 0 || head->ln_gamma || !head->w1[0] || !head->b1 ||
       !head->w_mid || !head->b_mid || !head->w_out || !head->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: the head must be 256 -> 128 -> 128 -> <= 80 features without norm");
+  // the kernel streams 8 K-steps of the head's first Linear and 80 rows of its last one whatever the caller packed
+  if (head->k_in != 256 || (head->out_rows != 80 && !(head->out_rows == 0 && head->n_out == 80)))
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: the head must be packed for 256 inputs (k_in) and 80 output rows (out_rows)");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
   a.n_cols = (int)n_rows;

@@ -227,6 +227,7 @@ class PackedMLP:
         # output heads (n_out < 80) run on a fixed 5-tile (80 row) kernel variant: the last Linear, its bias and a LayerNorm on
         # the head are packed as 80 rows (rows n_out..79 zero; n_out itself still masks the stores)
         head = 80 if self.n_out < 80 else 0
+        self.k_in, self.out_rows = int(weights[0].shape[1]), head  # (what fixed-size consumers check: include/gw_amd.h v15)
         self.w_out = pack(weights[-1], 0, self.hidden, rows=head)
         self.b_out = pad(biases[-1], n_out=head)
         self.gamma = pad(ln[0], n_out=head) if ln is not None else None
@@ -249,6 +250,7 @@ class PackedMLP:
         w.hidden, w.n_mid, w.n_out = self.hidden, self.n_mid, self.n_out
         w.weight_dtype = self.weight_dtype
         w.ln_width = self.ln_width
+        w.k_in, w.out_rows = self.k_in, self.out_rows
         return w
 
 

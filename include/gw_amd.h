@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 14
+#define GW_ABI_VERSION 15
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -176,6 +176,11 @@ typedef struct gw_mlp_weights {
   int32_t ln_width;    /* features LayerNorm normalises over; 0 = n_out.  Narrower models (node/edge width < 256,
                           graph_net_block.py:234-244 defaults to 128) run zero-padded to 256: their statistics then span
                           the first ln_width features only (fp32 weights) */
+  int32_t k_in;        /* (v15) input features the layer-1 slices were packed for, summed over the operands; 0 = not recorded.
+                          Entry points that stream a FIXED number of K-steps from w1 (gw_node_update_head_forward: the
+                          head's 256 inputs) refuse anything else instead of reading past the packed buffer */
+  int32_t out_rows;    /* (v15) rows w_out / b_out were packed with (gw_pack_linear rows > n_out: zero rows of an output
+                          head); 0 = gw_padded_n(n_out).  gw_node_update_head_forward requires 80 */
 } gw_mlp_weights;
 
 struct gw_activation_save; /* training only, defined with the backward entry points below; NULL in inference */
@@ -278,7 +283,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
  *   x_new[j] = LN(MLP_node(cat[x[j], agg[j]]))            (graph_net_block.py:189-191; the decoder's rows are zeros: no x_res)
  *   out[j, :n] = MLP_head(x_new[j]) + residual[j, :n]     (node_decoder 256 -> 128 -> 128 -> n <= 80 features, no norm)
  * x_new stays in registers: the [rows, 256] table between the two MLPs is neither written nor read.
- * Packed sizes the kernel streams unconditionally (the caller guarantees them; gw_pack_many with these shapes):
+ * Packed sizes the kernel streams unconditionally - checked through head->k_in == 256 and head->out_rows == 80 (v15):
  * head->w1[0] = [128, 256] slice (8 K-steps x 8 row tiles), head->w_mid = [128, 128], head->w_out / b_out packed with rows = 80. */
 int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
                                 const gw_mlp_weights* w, const gw_mlp_weights* head, const gw_operand* residual /* may be NULL */,

@@ -331,6 +331,25 @@ def test_node_update_with_head_stays_inside_its_buffers(rows, B, n_out, with_res
     _both(run)
 
 
+def test_node_update_with_head_refuses_a_head_packed_for_another_width():
+    """gw_node_update_head_forward streams 8 K-steps of the head's first Linear and 80 rows of its last one: a head packed for another
+    input width (gw_mlp_weights.k_in) or with fewer output rows (out_rows) is refused instead of being read past its end."""
+    rs = np.random.RandomState(9)
+    mlp = _mlp(rs, 512, 256, 256, True, torch.bfloat16)
+    n = 50
+    xp = torch.zeros(n, 256, device=DEV)
+    a = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    g = Guards(False)
+    pm = _packed(g, mlp, ((0, 256), (256, 512)), torch.bfloat16)
+    narrow = _packed(g, _mlp(rs, 128, 128, 78, False, torch.bfloat16), ((0, 128),), torch.bfloat16)  # a 128-wide head
+    with pytest.raises(RuntimeError, match="k_in"):
+        ops.node_update_head_forward(pm, narrow, n, n, Operand(xp, 0, 256, projected=True), Operand(a, n, 256), None)
+    ok = _packed(g, _mlp(rs, 256, 128, 78, False, torch.bfloat16), ((0, 256),), torch.bfloat16)
+    ok.out_rows = 78  # as if the caller had packed the last Linear with its natural 78 rows
+    with pytest.raises(RuntimeError, match="out_rows"):
+        ops.node_update_head_forward(pm, ok, n, n, Operand(xp, 0, 256, projected=True), Operand(a, n, 256), None)
+
+
 @pytest.mark.parametrize("rows,n_chain,n_fan", [(1000, 2, 3), (77, 1, 0), (1, 2, 1), (4097, 2, 2)])
 def test_chain_backward_stays_inside_its_buffers(rows, n_chain, n_fan):
     """gw_mlp_chain_backward: gradient rows, ReLU masks, transposed packs and every output between canaries."""
