@@ -67,7 +67,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "gw_amd.h"))
     # GW_TUNING=1 builds the A/B knobs in (env-selected kernel variants, skip switches that give wrong results - used by
-    # scripts/gpu_tune.sh / gpu_ab.sh only); the shipped library is built without them.  The flag set is recorded beside
+    # scripts/gpu_tune.sh and GW_TUNING=1 scripts/gpu_run.sh only; GW_HIPCC_EXTRA adds flags such as -DGW_LAYER_ABL=1); the shipped library is built without them.  The flag set is recorded beside
     # the library so that switching modes rebuilds.
     flags = HIPCC_FLAGS + (["-DGW_TUNING"] + os.environ.get("GW_HIPCC_EXTRA", "").split() if os.environ.get("GW_TUNING") == "1" else [])
     stamp = LIB_PATH + ".flags"
