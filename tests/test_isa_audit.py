@@ -155,6 +155,9 @@ def test_team_kernels_feed_every_mfma_from_agprs_and_interleave_fillers(tmp_path
                 and sum("quad_perm" in ln for ln in dpp) == 16, (name, len(dpp))
         first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
         assert not any(ln.startswith("v_accvgpr") for ln in lines[first_barrier:]), name
+        # the phase clocks (s_memtime stamps + their branches) exist in tuning builds only: the tile loop is bound by what a wave
+        # can issue between its MFMAs
+        assert not any(ln.startswith("s_memtime") for ln in lines), name
         mfma = layers
         for phase in (mfma[:128], mfma[128:]):
             gaps = [b_ - a_ - 1 for a_, b_ in zip(phase, phase[1:])]
