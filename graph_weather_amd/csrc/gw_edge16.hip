@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void edge16_gather_kernel(const Edge16Args a) 
 //   acc[t] += W_e[tile t][s] . E[s]      (E = the group's 8 KiB of the edge tile, one coalesced 16-byte load per K-step)
 //   H1[s] = bf16(relu(acc[2 s]), relu(acc[2 s + 1]))   (one coalesced 16-byte store per K-step)
 // No inter-wave synchronisation after the weight copy: the gathers of one wave overlap the MFMAs of its neighbours.
-constexpr int kL1Waves = 8;
+// 12 waves = 3 per SIMD (168 registers each after the accumulators were halved: no spill): the kernel is bound by the latency of
+// its gathers and tile loads, and a third wave per SIMD hides more of it (8 waves: 0.215 ms per block, 12: 0.194, 16 without the
+// fragment prefetch - 128 registers - 0.203; A/B on one box, 1 degree, batch 16)
+constexpr int kL1Waves = 12;
+constexpr bool kL1Prefetch = kL1Waves <= 12;  // next group's e fragments in flight under this group's MFMAs (32 registers)
 constexpr int kL1Lds = 128 * 1024 + 1024;  // W_e + b1
 // Round 4: a group is worked off in two halves of 8 output row tiles (32 accumulator registers instead of 64), which leaves room
 // to request the NEXT group's edge-tile fragments (8 KiB per group: the only bytes of this kernel that come from HBM) and its row
@@ -186,8 +190,10 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
     int ridn[2] = {0, 0};
     if (more) {  // the next group's fragments and row indices: in flight under this group's 128 MFMAs
       nxt = locate(un);
+      if constexpr (kL1Prefetch) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) bfn[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + nxt.eoff + s * 1024);
+        for (int s = 0; s < 8; ++s) bfn[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + nxt.eoff + s * 1024);
+      }
 #pragma unroll
       for (int p = 0; p < 2; ++p)
         if (p < a.n_proj) ridn[p] = a.p_kind[p] == 0 ? ldgi(a.src + nxt.k) : (a.p_kind[p] == 1 ? ldgi(a.dst + nxt.k) : nxt.k);
@@ -242,7 +248,10 @@ __global__ __launch_bounds__(64 * kL1Waves, 2) void edge16_l1_kernel(const Edge1
     u = un;
     cur = nxt;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bf[s] = bfn[s];
+    for (int s = 0; s < 8; ++s) {
+      if constexpr (kL1Prefetch) bf[s] = bfn[s];
+      else bf[s] = *(const GW_AS1 bf16x8*)(a.e_tiles + cur.eoff + s * 1024);  // (more waves per SIMD cover the round trip instead)
+    }
     ridx[0] = ridn[0];
     ridx[1] = ridn[1];
   }
