@@ -44,7 +44,9 @@ LAYER = 2 * D * D  # one 256 x 256 layer on one column
 
 CONFIGS = {
     "c2": dict(grid=1.0, resolution=2, batch=2, precision="fp32"),
+    "c2x3": dict(grid=1.0, resolution=2, batch=2, precision="bf16x3"),   # c2 with split-operand products (inside the 1e-3 bar)
     "c3": dict(grid=1.0, resolution=2, batch=16, precision="bf16"),
+    "c3x3": dict(grid=1.0, resolution=2, batch=16, precision="bf16x3"),  # c3's batch with split-operand products
     "c4": dict(grid=1.0, resolution=2, batch=64, precision="fp32"),  # global batch, sharded over the ranks
     "c5": dict(grid=0.25, resolution=3, batch=1, precision="fp32"),
 }
@@ -152,25 +154,32 @@ def cpu_baseline(lat_lons, state, graphs):
             "single_socket": socket, "sample": sample}
 
 
-def pmc_traffic(name="pmc_decoder_edge.json"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
-    WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE applied by scripts/gpu_pmc.sh).  None if not collected.
-    These counters are NOT collected in the bench run itself: the figure is read from the tracked profile of the same
-    workload (a PMC pass serialises kernels and cannot share a run with the timed region)."""
-    p = os.path.join(ROOT, "profiles", name)
-    try:
-        d = json.load(open(p))
-        if d.get("hbm_read_bytes") is None or d.get("hbm_write_bytes") is None:
-            return None, None
-        return d["hbm_read_bytes"] + d["hbm_write_bytes"], d
-    except (OSError, ValueError):
-        return None, None
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 --pmc summary of the c2 workload
+    (profiles/rNN_pmc_c2.json, re-collected every round by scripts/gpu_final.sh; profiles/pmc_decoder_edge.json = round 2's):
+    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE applied by scripts/gpu_pmc.sh.  Returns
+    (bytes, summary dict, file name); None if not collected.  These counters are NOT collected in the bench run itself: the
+    figure is read from the tracked profile of the same workload (a PMC pass serialises kernels and cannot share a run with
+    the timed region)."""
+    import glob
+
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_c2.json")), reverse=True)
+    names.append(os.path.join(ROOT, "profiles", "pmc_decoder_edge.json"))
+    for p in names:
+        try:
+            d = json.load(open(p))
+            if d.get("hbm_read_bytes") is None or d.get("hbm_write_bytes") is None:
+                continue
+            return d["hbm_read_bytes"] + d["hbm_write_bytes"], d, os.path.basename(p)
+        except (OSError, ValueError):
+            continue
+    return None, None, None
 
 
 def pmc_c3_traffic():
     """Counter traffic (bytes per launch) of the bf16 kernels at C3 from the tracked per-kernel PMC summary: the newest of
     profiles/r04_pmc_c3.json / r03_pmc_c3.json / r02_pmc_c3_edge16_v2.json.  Returns ({"processor_block": bytes, "decoder": bytes}, file)."""
-    for name in ("r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3_edge16_v2.json"):
+    for name in ("r05_pmc_c3.json", "r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3_edge16_v2.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -241,7 +250,8 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
     elements a launch processed come from the timer (under per-sample streams a processor launch handles one sample, the
     decoder launch the whole batch).  ``stanza_timer``: a separate one-stream pass for the processor / encoder edge updates
     (when the timed region ran the mesh stack on several streams, a launch's HIP-event time includes co-scheduled work)."""
-    peak = PEAK_F32_MATRIX_TFLOPS if precision == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+    # bf16x3: every product is three bf16 MFMAs - the peak for PRODUCT FLOPs is a third of the bf16 MFMA peak
+    peak = {"fp32": PEAK_F32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS, "bf16x3": PEAK_BF16_MATRIX_TFLOPS / 3.0}[precision]
     e_dec, e_lat = graphs.dec_plan.num_edges, graphs.lat_plan.num_edges
     dec_ms = timer.mean_ms("decoder_edge")
     dec_b = timer.mean_units("decoder_edge")
@@ -254,25 +264,30 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
     # algorithmic HBM bytes of one decoder edge launch: per (sample, edge) the cached product row and the residual edge-feature
     # row (2 x 1 KiB), per destination row one 1 KiB sum written; indices 8 B per edge
     alg_bytes = dec_b * e_dec * (2 * 1024 + 8) + dec_b * graphs.num_grid * 1024
-    if precision != "fp32":
+    if precision == "bf16x3":
+        # split mode: per (sample, edge) the fp32 product row of the source node and the cached per-edge product row (2 x 1 KiB); no
+        # residual row (its sums enter the node update as a cached table); per destination one fp32 sum row
+        alg_bytes = dec_b * e_dec * (2 * 1024 + 8) + dec_b * graphs.num_grid * 1024
+    elif precision != "fp32":
         # bf16 path: per (sample, edge) the fp16 product row of the source node (512 B), the batch-shared cached product row once
         # per edge (1 KiB), no residual row (its sums enter the node update as a cached table); per destination one bf16 sum (512 B)
         alg_bytes = dec_b * e_dec * (512 + 8) + e_dec * 1024 + dec_b * graphs.num_grid * 512
     # gather / scatter stage of one processor block: 2 E D s + 2 M D 4 bytes per sample, s = bytes per stored
     # edge-feature element between blocks (4: fp32 rows; 2: bf16 edge tiles - "halve for bf16 storage")
-    e_bytes = 4 if precision == "fp32" else 2
+    e_bytes = 2 if precision == "bf16" else 4
     gs_bytes = proc_b * (2 * e_lat * D * e_bytes + 2 * graphs.num_mesh * D * 4)
     gs_bytes_fp32 = proc_b * (2 * e_lat * D * 4 + 2 * graphs.num_mesh * D * 4)
     gs_bytes_halved = proc_b * (2 * e_lat * D * 2 + 2 * graphs.num_mesh * D * 2)  # SURVEY 8(d) "halve for bf16 storage", node tables too
     ach = executed / (dec_ms * 1e-3) / 1e12
     gs_traffic, gs_traffic_file = (None, None)
-    if precision != "fp32" and proc_b == 16 and graphs.num_grid == 64800:
+    if precision == "bf16" and proc_b == 16 and graphs.num_grid == 64800:
         t, gs_traffic_file = pmc_c3_traffic()
         gs_traffic = None if t is None else t["processor_block"]
     return {
         "bound": "mfma", "kernel": "decoder edge update (gw_edge_update_forward on the mesh->grid graph)",
         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-        "basis": "EXECUTED matrix FLOPs per launch (2 x 256x256 layers per edge and sample) / HIP-event duration",
+        "basis": "EXECUTED matrix FLOPs per launch (2 x 256x256 layers per edge and sample) / HIP-event duration"
+                 + ("; bf16x3 issues 3 bf16 MFMAs per product: peak = bf16 MFMA peak / 3" if precision == "bf16x3" else ""),
         "launch_ms": dec_ms, "launch_batch": dec_b, "executed_flops_per_launch": executed,
         "algorithmic_flops_per_launch": algorithmic, "algorithmic_tflops": algorithmic / (dec_ms * 1e-3) / 1e12,
         "algorithmic_frac": algorithmic / (dec_ms * 1e-3) / 1e12 / peak,
@@ -289,7 +304,7 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
                            "achieved_tbs": gs_bytes / (proc_ms * 1e-3) / 1e12, "peak_tbs": PEAK_HBM_TBS,
                            "frac": gs_bytes / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                            "frac_fp32_basis": gs_bytes_fp32 / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-                           "frac_fully_halved_basis": None if precision == "fp32" else gs_bytes_halved / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                           "frac_fully_halved_basis": None if precision != "bf16" else gs_bytes_halved / (proc_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                            "basis_note": "frac = storage basis (edge features as stored: bf16 tiles in bf16 mode; node tables fp32); "
                                          "frac_fully_halved_basis = SURVEY 8(d) bytes with every table halved; frac_fp32_basis = the "
                                          "reference's fp32 bytes",
@@ -299,8 +314,11 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
     }
 
 
-def run_extra(name, dev, steps, warmup):
-    """One of the other BASELINE configurations on this GPU (N = 1): value, ms_per_step, dominant kernel."""
+def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
+    """One of the other BASELINE configurations on this GPU (N = 1): value, ms_per_step, dominant kernel.  ``repeats`` > 1: the
+    timed region is run that many times and the MEDIAN reported (all values listed) - boxes of the pool differ by 2-5 %.
+    ``parity`` (16-bit modes): the same batch through the fp32 kernels of the same model; max |delta| / max |fp32 delta| of the
+    decoder delta (out - input) - the fp32 kernels themselves are pinned to the oracle at 1e-6 (tests/test_gpu_round2.py)."""
     import gc
 
     from graph_weather_amd.utils import seeded_features
@@ -313,25 +331,87 @@ def run_extra(name, dev, steps, warmup):
     graphs = model.encoder.graphs
     build_s = time.perf_counter() - t0
     model = model.to(dev).eval()
-    if cfg["precision"] == "bf16":
-        model.set_compute_dtype(torch.bfloat16)
+    set_precision(model, cfg["precision"])
     feats = seeded_features(cfg["batch"], len(lat_lons), 102, seed=42).to(dev)
     gc.collect()
-    elapsed, timer = time_forward(model, feats, steps, warmup, torch.cuda.synchronize)
+    runs = [time_forward(model, feats, steps, warmup if i == 0 else 1, torch.cuda.synchronize) for i in range(max(1, repeats))]
+    runs.sort(key=lambda r: r[0])
+    elapsed, timer = runs[len(runs) // 2]
     ms = 1e3 * elapsed / steps
     r = kernel_report(graphs, cfg["batch"], cfg["precision"], timer, ms)
     out = {"workload": f"{cfg['grid']:g}deg grid ({len(lat_lons)} nodes), mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), "
                        f"batch {cfg['batch']}, {cfg['precision']}",
            "value": cfg["batch"] * steps / elapsed, "unit": "forecasts/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+           "repeats": len(runs), "ms_per_step_all": [1e3 * e / steps for e, _ in runs],
            "graph_build_s": build_s, "dominant_kernel": r["kernel"], "launch_ms": r["launch_ms"], "frac": r["frac"], "peak": r["peak"],
            "step_frac": r["step_frac"], "other_kernels_ms": r["other_kernels_ms"], "gather_scatter_frac": r["gather_scatter"]["frac"],
            "gather_scatter": r["gather_scatter"],
            "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
            "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}
+    if parity and cfg["precision"] != "fp32":
+        with torch.no_grad():
+            y = model(feats)
+            set_precision(model, "fp32")
+            y32 = model(feats)
+        d32 = (y32 - feats[..., :78]).double()
+        err = (y.double() - y32.double()).abs().max().item() / max(d32.abs().max().item(), 1e-30)
+        out["parity_vs_fp32_kernels"] = {"max_rel_of_delta_scale": err, "bar": 1e-3, "inside_bar": err <= 1e-3,
+                                         "note": "same model, same batch, fp32-MFMA kernels (pinned to the CPU oracle at ~1e-6); the "
+                                                 "oracle comparisons of this mode are tests/test_gpu_split.py"}
+        del y, y32, d32
     del model, feats
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def set_precision(model, precision: str) -> None:
+    model.set_compute_dtype({"fp32": torch.float32, "bf16": torch.bfloat16, "bf16x3": "bf16x3"}[precision])
+
+
+def h2d_step_ms(model, feats, steps=20):
+    """DESIGN.md PCIe note as a number: the c2 step when the batch starts in pinned HOST memory.  serial = copy, then forward,
+    every step on one stream; overlapped = the copy of step i + 1 on a copy stream under the forward of step i (two device
+    buffers).  ``value`` of the bench line never includes a host copy (inputs are HBM resident in the timed region)."""
+    host = feats.cpu().pin_memory()
+    dev = feats.device
+    bufs = [torch.empty_like(feats), torch.empty_like(feats)]
+    main = torch.cuda.current_stream(dev)
+    copy = torch.cuda.Stream(device=dev)
+    res = {}
+    with torch.no_grad():
+        for _ in range(2):
+            bufs[0].copy_(host, non_blocking=True)
+            model(bufs[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bufs[0].copy_(host, non_blocking=True)
+            model(bufs[0])
+        torch.cuda.synchronize()
+        res["serial_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        with torch.cuda.stream(copy):
+            bufs[0].copy_(host, non_blocking=True)
+            ready[0].record(copy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            cur, nxt = i & 1, (i + 1) & 1
+            with torch.cuda.stream(copy):
+                if i >= 1:
+                    copy.wait_event(done[nxt])  # the forward that read this buffer two steps ago has finished
+                bufs[nxt].copy_(host, non_blocking=True)
+                ready[nxt].record(copy)
+            main.wait_event(ready[cur])
+            model(bufs[cur])
+            done[cur].record(main)
+        torch.cuda.synchronize()
+        res["overlapped_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+    res["bytes_per_step"] = host.numel() * 4
+    res["note"] = "input batch copied from pinned host memory every step (PCIe); not part of `value`"
+    return res
 
 
 def run_wide(dev, steps=3, warmup=2):
@@ -541,10 +621,11 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE.json configuration: c2 (default, the metric's config: 1deg fp32 batch 2 per GPU), c3 (bf16, batch 16 "
-                         "per GPU), c4 (global batch 64 sharded over the ranks), c5 (0.25deg, mesh res 3, batch 1 per GPU)")
+                         "per GPU), c4 (global batch 64 sharded over the ranks), c5 (0.25deg, mesh res 3, batch 1 per GPU); c2x3 / c3x3 = "
+                         "c2 / c3's batch with split-operand (bf16x3) products")
     ap.add_argument("--grid", type=float, default=None, help="override the grid spacing in degrees")
     ap.add_argument("--batch", type=int, default=None, help="override the batch per GPU")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None, help="override the matrix-product dtype")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default=None, help="override the matrix-product dtype")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE metric (default); train = forward + loss + backward + gradient all-reduce + AdamW")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams of the mesh stack in the forward (0 = automatic: per-sample "
@@ -594,8 +675,8 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     graphs = model.encoder.graphs
     model = model.to(dev).eval()
-    if cfg["precision"] == "bf16":
-        model.set_compute_dtype(torch.bfloat16)
+    if cfg["precision"] != "fp32":
+        set_precision(model, cfg["precision"])
     if args.streams and hasattr(model, "processor"):
         model.processor.graph_processor.streams = args.streams
     feats = seeded_features(batch, len(lat_lons), 102, seed=42 + rank).to(dev)  # resident in HBM before timing
@@ -627,7 +708,13 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
         _, stanza_timer = time_forward(model, feats, 5, 1, torch.cuda.synchronize)
         gp.streams = keep
     total_batch = batch
+    per_rank_ms, dist_world = [1e3 * elapsed / args.steps], 1
     if world > 1:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # (each rank's own clock over the barrier-bracketed region, for the record)
+        per_rank_ms = [1e3 * float(e.item()) / args.steps for e in every]
+        dist_world = dist.get_world_size()
         t = torch.tensor([elapsed, float(batch)], dtype=torch.float64, device=dev)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
@@ -640,33 +727,40 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
         if timer is not None:
             roof = kernel_report(graphs, batch, prec, timer, ms, stanza_timer)
             is_c2 = (cfg["grid"] == 1.0 and batch == 2 and prec == "fp32")
-            traffic, pmc = pmc_traffic() if is_c2 else (None, None)
+            traffic, pmc, pmc_file = pmc_traffic() if is_c2 else (None, None, None)
             roof["traffic"] = traffic
-            roof["traffic_unit"] = ("bytes per launch, read from the tracked rocprofv3 PMC summary of the same workload "
-                                    "(profiles/pmc_decoder_edge.json; counters are not collected inside the bench run)")
+            roof["traffic_file"] = pmc_file
+            roof["traffic_unit"] = ("bytes per launch, read from the newest tracked rocprofv3 PMC summary of the same workload "
+                                    "(profiles/" + str(pmc_file) + "; counters are not collected inside the bench run)")
             roof["mfma_busy_frac_pmc"] = None if pmc is None else pmc.get("mfma_busy_frac")
         out = {
             "metric": "forward forecasts/sec (1° grid, 102→78 feat)", "value": total_batch * args.steps / elapsed,
             "unit": "forecasts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.config == "c4" else "weak", "vs_baseline": None,
-            "dtype": "f32" if prec == "fp32" else "bf16 (MFMA operands; fp32 accumulate, LayerNorm, residuals, sums)",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands; fp32 accumulate, LayerNorm, residuals, sums)",
+                      "bf16x3": "bf16x3 (hi/lo bf16 operand pairs, 3 MFMAs per product; fp32 accumulate, LayerNorm, residuals, sums)"}[prec],
             "data": "synthetic",
             "config": {"workload": f"{args.config}: GraphWeatherForecaster {cfg['grid']:g}deg grid ({len(lat_lons)} nodes), 102->78 feat, "
                                    f"batch={batch} on rank 0, {prec}, mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), random-init weights",
                        "global_batch": total_batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
             "roofline": roof,
             "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
+            "per_rank_ms_per_step": per_rank_ms, "dist_world_size": dist_world,
         }
         if world == 1 and not args.no_extra and on_gpu:
             out["cold_ms_per_step"] = cold_step_ms(model, feats)
             out["cold_note"] = ("forward right after every parameter changed: packed weights, edge / mesh embeddings and their layer-1 "
                                 "products are rebuilt (the reference recomputes the embeddings on every forward)")
         if world == 1 and not args.no_extra and args.config == "c2" and on_gpu:
+            h2d = h2d_step_ms(model, feats)
             del model, feats
             gc.collect()
             torch.cuda.empty_cache()
-            out["extra"] = {"c3": run_extra("c3", dev, steps=10, warmup=3), "c5": run_extra("c5", dev, steps=5, warmup=2),
-                            "wide1024": run_wide(dev), "train": run_train_extra(dev)}
+            out["extra"] = {"c2_split": run_extra("c2x3", dev, steps=20, warmup=3, repeats=3, parity=True),
+                            "c3_split": run_extra("c3x3", dev, steps=20, warmup=3, repeats=3, parity=True),
+                            "c3": run_extra("c3", dev, steps=20, warmup=3, repeats=3, parity=True),
+                            "c5": run_extra("c5", dev, steps=5, warmup=2),
+                            "wide1024": run_wide(dev), "train": run_train_extra(dev), "h2d": h2d}
         if world == 1 and not args.no_cpu_baseline and cfg["grid"] == 1.0:
             out["cpu_baseline"] = cpu_baseline(lat_lons, cpu_state, graphs)
         else:
@@ -681,6 +775,9 @@ def _cli():
     process-group backend, a non-GPU device and a stand-in model factory: the hooks tests/test_sharding.py uses to run this
     very command line (self-launch included) on CPU over gloo."""
     kw = {}
+    if (os.environ.get("GW_BENCH_BACKEND") or os.environ.get("GW_BENCH_FACTORY")) and os.environ.get("GW_BENCH_DEVICE") != "cpu":
+        # the stand-in hooks exist for the CPU tests only: on a GPU device the line printed must come from the real model over RCCL
+        raise SystemExit("bench.py: GW_BENCH_BACKEND / GW_BENCH_FACTORY are honoured only together with GW_BENCH_DEVICE=cpu")
     if os.environ.get("GW_BENCH_BACKEND"):
         kw["backend"] = os.environ["GW_BENCH_BACKEND"]
     if os.environ.get("GW_BENCH_DEVICE"):

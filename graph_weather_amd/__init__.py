@@ -19,6 +19,7 @@ from .layers import (  # noqa: F401
     set_compute_dtype,
     set_deterministic,
 )
+from .ops import BF16X3  # noqa: F401  (set_compute_dtype(model, BF16X3): split-operand products, csrc/gw_split.hip)
 from .graphcast import GraphCast, GraphCastConfig  # noqa: F401
 from .losses import NormalizedMSELoss  # noqa: F401
 from .regional import (  # noqa: F401

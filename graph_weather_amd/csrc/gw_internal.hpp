@@ -85,6 +85,10 @@ struct ChainArgs {
 // bf16-weight launches (gw_bf16.hip): kind 0 mlp, 1 edge update, 2 node update, 3 project (grid_y slices), 4 node update + POST,
 // 5 mlp + POST, 6 node update + output head.
 int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
+// split-operand launches (gw_split.hip, GW_DTYPE_BF16X3): the same kinds; operands and outputs are fp32 rows only
+int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
+// one matrix item of gw_pack_many into the split stream (strides in floats)
+void pack_x3_item(const float* w, long long stride_f, long long stride_k, int n_out, int kseg, int ntp, int nsteps, void* out, void* stream);
 
 // debug timestamp hook (gw_debug_timestamps) and tuning overrides, defined in gw_kernels.hip
 extern unsigned long long* g_dbg;

@@ -761,6 +761,14 @@ namespace {
 
 int fail(int code, const char* msg) { return gw::set_error(code, msg); }
 
+// 16-bit matrix-core modes: GW_DTYPE_BF16 (gw_bf16.hip, + the resident kernels) and GW_DTYPE_BF16X3 (gw_split.hip: split operands,
+// fp32 rows everywhere - none of the bf16 mode's 16-bit table formats)
+bool is16(int dt) { return dt == GW_DTYPE_BF16 || dt == GW_DTYPE_BF16X3; }
+int launch16(int dt, int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream) {
+  return dt == GW_DTYPE_BF16X3 ? gw::chainx3_launch(kind, a, k_in, hidden, n_out, grid_y, stream)
+                               : gw::chain16_launch(kind, a, k_in, hidden, n_out, grid_y, stream);
+}
+
 int g_stagger_override = -1;  // GW_STAGGER env (tuning): -1 = automatic
 
 template <typename K>
@@ -878,14 +886,15 @@ int gw_padded_n(int n) { return ((n + 31) / 32) * 32; }
 int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats, int32_t n_vecs, const gw_pad_item* vecs,
                  void* stream) {
   if (n_mats < 0 || n_vecs < 0 || n_mats > GW_PACK_MAX_ITEMS || n_vecs > GW_PACK_MAX_ITEMS || (n_mats > 0 && !mats) ||
-      (n_vecs > 0 && !vecs) || (weight_dtype != GW_DTYPE_F32 && weight_dtype != GW_DTYPE_BF16))
+      (n_vecs > 0 && !vecs) || (weight_dtype != GW_DTYPE_F32 && !is16(weight_dtype)))
     return fail(GW_E_BADARG, "gw_pack_many: bad arguments");
   if (n_mats == 0 && n_vecs == 0) return GW_OK;
   PackManyArgs a;
   memset(&a, 0, sizeof(a));
   a.n_mats = n_mats;
   a.n_vecs = n_vecs;
-  a.bf16 = weight_dtype == GW_DTYPE_BF16;
+  a.bf16 = is16(weight_dtype);
+  const bool x3 = weight_dtype == GW_DTYPE_BF16X3;
   for (int i = 0; i < n_mats; ++i) {
     const gw_pack_item& m = mats[i];
     if (!m.w || !m.out || m.n_out <= 0 || m.kseg <= 0) return fail(GW_E_BADARG, "gw_pack_many: bad matrix item");
@@ -903,6 +912,15 @@ int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats,
   for (int i = 0; i < n_vecs; ++i) {
     if (!vecs[i].v || !vecs[i].out || vecs[i].n <= 0) return fail(GW_E_BADARG, "gw_pack_many: bad vector item");
     a.v[i] = vecs[i];
+  }
+  if (x3) {  // split streams (gw_split.hip): one launch per matrix, the vectors through the shared kernel
+    for (int i = 0; i < n_mats; ++i)
+      gw::pack_x3_item(a.m[i].w, a.m[i].stride_f, a.m[i].stride_k, a.m[i].n_out, a.m[i].kseg, a.ntq[i], a.nsteps[i], a.m[i].out, stream);
+    if (int rc = check_launch("pack_linear_x3_kernel launch")) return rc;
+    if (n_vecs == 0) return GW_OK;
+    a.n_mats = 0;
+    hipLaunchKernelGGL(pack_many_kernel, dim3(64, 1), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("pack_many_kernel launch");
   }
   hipLaunchKernelGGL(pack_many_kernel, dim3(64, n_mats + (n_vecs > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("pack_many_kernel launch");
@@ -990,14 +1008,14 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
   a.out_ld = out_ld;
   a.out_cols = w->n_out;
   if (int rc = fill_save(a, save, w, "gw_mlp_forward")) return rc;
-  if (w->weight_dtype == GW_DTYPE_BF16) {
+  if (is16(w->weight_dtype)) {
     if (residual && w->n_out == 256 && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
     if (w->n_out == 256 && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
     if (x->k == 256 && x->ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input ld must be a multiple of 4");
     if (x->k > 128 && x->k != 256) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=128 or ==256");
     if (w->ln_gamma && (w->n_out != 256 || (w->ln_width > 0 && w->ln_width != w->n_out)))
       return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: LayerNorm over fewer than 256 features is implemented for float32 weights only");
-    return gw::chain16_launch(0, a, x->k, w->hidden, w->n_out, 1, stream);
+    return launch16(w->weight_dtype, 0, a, x->k, w->hidden, w->n_out, 1, stream);
   }
   if (w->hidden == 256 && w->n_out == 256) {
     if (residual && (residual->ld % 4 != 0)) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: residual ld must be a multiple of 4");
@@ -1027,9 +1045,11 @@ int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand
   if (x->k <= 0 || !w->w1[0] || !w->w_out || !w->b1 || !w->b_out) return fail(GW_E_BADARG, "gw_mlp_post_forward: missing weights / empty operand");
   if (x->layout != GW_LAYOUT_ROWS_F32) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: x is fp32 rows");
   if (bad_layers(w)) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: at least 2 hidden layers (n_mid >= 1) are required");
-  if (w->weight_dtype != GW_DTYPE_BF16 || w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || (w->ln_width > 0 && w->ln_width != 256))
-    return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: bf16 weights, hidden 256, 256 outputs with LayerNorm");
+  if (!is16(w->weight_dtype) || w->hidden != 256 || w->n_out != 256 || !w->ln_gamma || (w->ln_width > 0 && w->ln_width != 256))
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: bf16 / bf16x3 weights, hidden 256, 256 outputs with LayerNorm");
   if (post_layout != GW_LAYOUT_ROWS_F32 && post_layout != GW_LAYOUT_ROWS_F16) return fail(GW_E_BADARG, "gw_mlp_post_forward: bad post_layout");
+  if (post_layout == GW_LAYOUT_ROWS_F16 && w->weight_dtype != GW_DTYPE_BF16)
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: fp16 products come with bf16 weights");
   if (out && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_post_forward: out_ld must be a multiple of 4");
   ChainArgs a;
   memset(&a, 0, sizeof(a));
@@ -1047,7 +1067,7 @@ int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand
   }
   a.n_post = n_post;
   a.proj_half = post_layout == GW_LAYOUT_ROWS_F16;
-  return gw::chain16_launch(5, a, x->k, w->hidden, w->n_out, 1, stream);
+  return launch16(w->weight_dtype, 5, a, x->k, w->hidden, w->n_out, 1, stream);
 }
 
 size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_operand* x_src, const gw_operand* x_dst,
@@ -1056,7 +1076,7 @@ size_t gw_edge_update_workspace_bytes(int32_t batch, int32_t n_edges, const gw_o
   const bool det = (flags & GW_EDGE_DETERMINISTIC) != 0;
   if (gw::edge16_eligible(x_src, x_dst, e_in, w)) return gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && w->weight_dtype == GW_DTYPE_F32 && gw::edge_fast_eligible(x_src, x_dst, e_in, w)) return gw::edge_fast_carry_bytes(batch, n_edges);
-  if (det && w->weight_dtype == GW_DTYPE_BF16) return gw::edge_fast_carry_bytes(batch, n_edges);  // the general bf16 kernel (e.g. the encoder's raw node operand)
+  if (det && is16(w->weight_dtype)) return gw::edge_fast_carry_bytes(batch, n_edges);  // the general bf16 / bf16x3 kernel (e.g. the encoder's raw node operand)
   return 0;
 }
 
@@ -1095,9 +1115,10 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   // e_res->k == 0: no residual - for callers that want only the aggregate and have added the segment sums of their (batch-
   // shared) e into agg beforehand: sum(LN(.) + e) = sum(LN(.)) + sum(e).  bf16 path with resident weights only (edge16_launch).
   const bool no_res = e_res->k == 0;
-  if (no_res && (e_out_any != nullptr || save || !gw::edge16_eligible(x_src, x_dst, e_in, w) || (flags & GW_EDGE_DETERMINISTIC)))
+  const bool x3 = w->weight_dtype == GW_DTYPE_BF16X3;
+  if (no_res && (e_out_any != nullptr || save || !(x3 || (gw::edge16_eligible(x_src, x_dst, e_in, w) && !(flags & GW_EDGE_DETERMINISTIC)))))
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: an edge update without residual (e_res.k == 0) is implemented for the bf16 "
-                                  "path with resident weights, without e_out, activation saving or deterministic sums");
+                                  "path with resident weights (atomics mode) and for bf16x3 weights, without e_out or activation saving");
   if (!no_res && (e_res->k != 256 || e_res->ld % 4 != 0 || !e_res->ptr))
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: e_res (residual edge features) must be 256 wide");
   // edge tiles (bf16) are a format of the bf16 path with resident weights only
@@ -1132,7 +1153,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   }
   const size_t ws16 = gw::edge16_workspace_needed(batch, n_edges, e_in, det);
   if (det && save) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums are an inference option");
-  if (tiles_in || tiles_out || no_res || half_nodes) {
+  if (tiles_in || tiles_out || (no_res && !x3) || half_nodes) {
     if (save || (ws16 > 0 && (!workspace || workspace_bytes < ws16)) || !gw::edge16_eligible(x_src, x_dst, e_in, w))
       return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: bf16 edge tiles need bf16 weights, one middle layer, projected node "
                                     "operands, no activation saving and the workspace of gw_edge_update_workspace_bytes");
@@ -1150,7 +1171,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   if (!save && gw::edge16_eligible(x_src, x_dst, e_in, w) && (ws16 == 0 || (workspace && workspace_bytes >= ws16)))
     return gw::edge16_launch(batch, n_edges, src, dst, x_src, x_dst, e_in, e_res, w, e_out, nullptr, agg, n_dst, workspace,
                              det ? GW_EDGE_DETERMINISTIC : 0, stream);
-  if (det && (w->weight_dtype != GW_DTYPE_BF16 || !workspace || workspace_bytes < gw::edge_fast_carry_bytes(batch, n_edges)))
+  if (det && (!is16(w->weight_dtype) || !workspace || workspace_bytes < gw::edge_fast_carry_bytes(batch, n_edges)))
     return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: deterministic segment sums exist on the fast fp32 edge kernel (at most one "
                                   "raw operand, native 256 widths) and on the bf16 kernels, and need their workspace");
   ChainArgs a;
@@ -1163,7 +1184,7 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.seg_idx[1] = dst;
   fill_operand(a, 2, e_in);
   fill_weights(a, w);
-  fill_residual(a, e_res);
+  if (!no_res) fill_residual(a, e_res);
   a.out = e_out;
   a.out_ld = 256;
   a.out_cols = 256;
@@ -1171,10 +1192,10 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg_idx = dst;
   a.agg_rows_pb = n_dst;
   if (int rc = fill_save(a, save, w, "gw_edge_update_forward")) return rc;
-  if (w->weight_dtype == GW_DTYPE_BF16) {
+  if (is16(w->weight_dtype)) {
     if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
     if (det) a.carry = (float*)workspace;
-    if (int rc = gw::chain16_launch(1, a, 256, 256, 256, 1, stream)) return rc;
+    if (int rc = launch16(w->weight_dtype, 1, a, 256, 256, 256, 1, stream)) return rc;
     return det ? gw::segment_fixup_launch(((int64_t)a.n_cols + 63) / 64, a.carry, agg, stream) : GW_OK;
   }
   return launch_chain(chain_kernel<64, true, 3, 16, 16, EPI_EDGE>, a, stream, 1, 1);
@@ -1223,9 +1244,9 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
     return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: fp16 post products come with bf16 weights");
   a.proj_half = post_layout == GW_LAYOUT_ROWS_F16;
   a.zero_rows = zero_rows;
-  if (w->weight_dtype == GW_DTYPE_BF16) {
+  if (is16(w->weight_dtype)) {
     if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
-    return gw::chain16_launch(n_post > 0 ? 4 : 2, a, 256, 256, 256, 1, stream);
+    return launch16(w->weight_dtype, n_post > 0 ? 4 : 2, a, 256, 256, 256, 1, stream);
   }
   if (n_post > 0) return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, 2);
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
@@ -1237,13 +1258,14 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   if (!x || !agg || !w || !head || !out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_head_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: more than 2^31-1 rows");
-  if (w->weight_dtype != GW_DTYPE_BF16 || head->weight_dtype != GW_DTYPE_BF16)
-    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: bf16 weights only (the fp32 path runs the two launches)");
+  if (!is16(w->weight_dtype) || head->weight_dtype != w->weight_dtype)
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: bf16 or bf16x3 weights, the same for both MLPs (the fp32 path runs the two launches)");
+  const bool b16 = w->weight_dtype == GW_DTYPE_BF16;  // (the 16-bit table formats belong to the bf16 mode)
   if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out || bad_layers(w) || w->n_mid != 1 || !w->ln_gamma ||
       (w->ln_width > 0 && w->ln_width != 256))
     return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: node MLP must be 512 -> 256 -> 256 -> 256 with LayerNorm");
-  if (bad_agg(agg, true) || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: agg must be 256 wide (raw)");
-  if (x->k != 0 && (bad256(x, true) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: x must be 256 wide or zeros");
+  if (bad_agg(agg, b16) || !w->w1[1]) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: agg must be 256 wide (raw)");
+  if (x->k != 0 && (bad256(x, b16) || (!x->projected && !w->w1[0]))) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: x must be 256 wide or zeros");
   if (head->hidden != 128 || head->n_mid != 1 || head->n_out > 80 || head->n_out <= 0 || head->ln_gamma || !head->w1[0] || !head->b1 ||
       !head->w_mid || !head->b_mid || !head->w_out || !head->b_out)
     return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: the head must be 256 -> 128 -> 128 -> <= 80 features without norm");
@@ -1270,7 +1292,7 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   a.out = out;
   a.out_ld = out_ld;
   a.out_cols = head->n_out;
-  return gw::chain16_launch(6, a, 256, 256, 256, 1, stream);
+  return launch16(w->weight_dtype, 6, a, 256, 256, 256, 1, stream);
 }
 
 int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, int32_t n_slices,
@@ -1302,7 +1324,7 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   a.relu_mask = relu_mask;
   if (zero_rows && weight_dtype != GW_DTYPE_F32) return fail(GW_E_UNSUPPORTED, "gw_project_forward: zero_rows needs fp32 weights");
   a.zero_rows = zero_rows;
-  if (weight_dtype == GW_DTYPE_BF16) return gw::chain16_launch(3, a, 256, 256, 256, n_slices, stream);
+  if (is16(weight_dtype)) return launch16(weight_dtype, 3, a, 256, 256, 256, n_slices, stream);
   return launch_chain(chain_kernel<64, true, 1, 16, 16, EPI_ROWS, true>, a, stream, n_slices, 3);
 }
 

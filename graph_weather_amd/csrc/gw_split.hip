@@ -1,0 +1,667 @@
+// gw_split.hip - split-operand ("bf16x3") variant of the fused MLP kernels: GW_DTYPE_BF16X3.
+//
+// The reference computes every Linear in fp32 (graph_net_block.py:45-61); BASELINE.json asks for its outputs within 1e-3 and for
+// matrix products on the bf16 matrix cores.  One bf16 operand carries 8 significant bits (measured 9.5e-3 end to end), so this
+// mode keeps BOTH operands of every product as a pair of bf16 values
+//       x = x_hi + x_lo,   x_hi = bf16(x) (RNE),  x_lo = bf16(x - x_hi)          (16 significant bits, fp32 exponent range)
+// and evaluates  x . w  ~=  x_hi . w_hi + x_hi . w_lo + x_lo . w_hi   on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: three
+// MFMAs per product (the dropped x_lo . w_lo term is 2^-16 relative to a product).  Three bf16 MFMAs cost 48 cycles per
+// 16x16x32 block against 256 cycles for the eight v_mfma_f32_16x16x4_f32 of the exact-fp32 kernels: 5.3 x the matrix rate at
+// ~1e-5 per product.  Everything that is not a matrix product (bias, LayerNorm statistics, residual adds, segment sums, every
+// tensor in HBM) stays fp32, exactly as in the fp32 kernels.
+//
+// Structure: the transposed, register-resident scheme of gw_bf16.hip (weights = A operand streamed through LDS by
+// global_load_lds DMA, activations = B operand, K order k(s, q, i) = 32 s + 16 (i >> 2) + 4 q + (i & 3), so a layer's accumulator
+// is the next layer's B operand).  The packed stream carries, per 32-wide K-step, the hi fragments of all row tiles followed by
+// their lo fragments (gw_pack_linear_bf16x3); activations are split in registers when a layer's output becomes the next layer's
+// input.  A wave reads two fragments (hi, lo) from LDS per three MFMAs; the 4-byte-per-weight stream is the fp32 kernels' volume.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "gw_device.hpp"
+#include "gw_internal.hpp"
+
+using namespace gw;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBufBytes = 32768;            // one weight chunk buffer: one K-step of 16 row tiles (hi + lo)
+constexpr int kStageLd = 260;
+constexpr int kStageFloats = 64 * kStageLd;
+constexpr int kLdsWeights = 2 * kBufBytes;  // double buffered
+// the segment-sum stage of the edge epilogue lies OVER the weight buffers (nothing streams any more by then): two 64-column
+// workgroups per CU fit the 160 KiB
+constexpr int kLdsEdge = (kStageFloats + 64) * 4 > kLdsWeights ? (kStageFloats + 64) * 4 : kLdsWeights;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// DMA `bytes` (multiple of 1 KiB) of the packed weight stream into LDS at byte offset lds_off; pieces round-robin over the waves.
+template <int NW>
+__device__ __forceinline__ void issue_bytes(const char* __restrict__ g, int bytes, unsigned lds_off, int lane, int wave) {
+  const int npieces = bytes >> 10;
+  for (int p = wave; p < npieces; p += NW)
+    glds16_asm_s((const float*)(g + (size_t)p * 1024), (unsigned)lane * 16u,
+                 __builtin_amdgcn_readfirstlane(lds_off + (unsigned)p * 1024u));
+}
+
+// x -> (bf16(x), bf16(x - bf16(x))) for the 8 values of one B fragment
+__device__ __forceinline__ void split8(f32x4 a, f32x4 b, bf16x8& h, bf16x8& l) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const __bf16 ha = (__bf16)a[r];
+    h[r] = ha;
+    l[r] = (__bf16)(a[r] - (float)ha);
+    const __bf16 hb = (__bf16)b[r];
+    h[4 + r] = hb;
+    l[4 + r] = (__bf16)(b[r] - (float)hb);
+  }
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+
+// One layer pass: acc[g][t] += W[16t.., k] . x[g][k] on split operands, K = 32 KS, NT row tiles, NTP = tiles per K-step in the
+// packed stream (NT rounded up to 4).  The stream of this pass starts at gw; its first chunk has already been issued into buffer
+// `parity`; while the last chunk computes, the first chunk of the next pass (next_gw, next_bytes) is issued.
+template <int NW, int NG, int KS, int BKS, int NT, int NTP>
+__device__ __forceinline__ void pass_x3(f32x4 (&acc)[NG][NT], const bf16x8 (&bh)[NG][BKS], const bf16x8 (&bl)[NG][BKS],
+                                        const char* __restrict__ gw, const char* __restrict__ next_gw, int next_bytes, const char* lds,
+                                        int& parity, int lane, int wave) {
+  constexpr int STEP_BYTES = 2 * NTP * 1024;  // hi fragments of the NTP tiles, then their lo fragments
+  constexpr int CS = (2 * STEP_BYTES <= kBufBytes) ? 2 : 1;  // K-steps per chunk
+  constexpr int NCH = (KS + CS - 1) / CS;
+  constexpr int UPS = NTP / 2;  // units per K-step: a unit = 2 row tiles = 4 ds_read_b128 (hi, hi, lo, lo) -> 6 NG MFMAs
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int steps_c = (KS - c * CS) < CS ? (KS - c * CS) : CS;
+    wait_vm<0>();
+    lds_barrier();  // chunk c has landed for every wave; nobody still reads the other buffer
+    if (c + 1 < NCH) {
+      const int sn = (KS - (c + 1) * CS) < CS ? (KS - (c + 1) * CS) : CS;
+      issue_bytes<NW>(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+    } else if (next_gw != nullptr) {
+      issue_bytes<NW>(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+    }
+    const char* buf = lds + parity * kBufBytes + lane * 16;
+    // fragments travel through a ring of three register sets, requested two units ahead of the MFMAs that use them
+    const int NU = steps_c * UPS;
+    bf16x8 af[3][4];
+    auto ldu = [&](bf16x8 (&f)[4], int u) {
+      const int su = u / UPS, t2 = u - su * UPS;
+      const char* p = buf + su * STEP_BYTES + (2 * t2) * 1024;
+      f[0] = *(const bf16x8*)(p);
+      f[1] = *(const bf16x8*)(p + 1024);
+      f[2] = *(const bf16x8*)(p + NTP * 1024);
+      f[3] = *(const bf16x8*)(p + NTP * 1024 + 1024);
+    };
+    ldu(af[0], 0);
+    if (NU > 1) ldu(af[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < CS * UPS; ++u) {
+      if (u < NU) {
+        if (u + 2 < NU) ldu(af[(u + 2) % 3], u + 2);
+        const int su = u / UPS, t2 = u - su * UPS;
+        const int ks = c * CS + su;
+        // term-major: two MFMAs (x NG) lie between two that accumulate into the same registers
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            if (2 * t2 + tt < NT) {
+#pragma unroll
+              for (int g = 0; g < NG; ++g) {
+                const bf16x8 wa = af[u % 3][term == 2 ? 2 + tt : tt];
+                const bf16x8 xb = term == 1 ? bl[g][ks] : bh[g][ks];
+                acc[g][2 * t2 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[g][2 * t2 + tt], 0, 0, 0);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    parity ^= 1;
+  }
+}
+
+template <int NG, int NT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NG][NT], const float* __restrict__ bias, int q) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 bv = bias ? ldg4(bias + 16 * t + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g][t] = bv;
+  }
+}
+
+// (bh, bl)[s] <- split(row[k(s,q,i)]) for a raw operand row (valid features [0, kvalid))
+template <int KS, bool FULL, int DEPTH>
+__device__ __forceinline__ void load_raw(bf16x8 (&bh)[KS], bf16x8 (&bl)[KS], const float* __restrict__ row, int kvalid, int q) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool pairs = !FULL && (kvalid & 1) == 0 && ((size_t)row & 7) == 0;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    f32x4 lo, hi;
+    if (FULL) {
+      lo = ldg4(row + 32 * s + 4 * q);
+      hi = ldg4(row + 32 * s + 16 + 4 * q);
+    } else if (pairs) {  // rows of an even number of floats at an 8-byte aligned base (102 input features): 8-byte loads
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const int k0 = 32 * s + 4 * q + r, k1 = k0 + 16;
+        const f32x2 a = k0 < kvalid ? *(const GW_AS1 f32x2*)(row + k0) : f32x2{0.f, 0.f};
+        const f32x2 b = k1 < kvalid ? *(const GW_AS1 f32x2*)(row + k1) : f32x2{0.f, 0.f};
+        lo[r] = a.x;
+        lo[r + 1] = a.y;
+        hi[r] = b.x;
+        hi[r + 1] = b.y;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k0 = 32 * s + 4 * q + r, k1 = k0 + 16;
+        lo[r] = k0 < kvalid ? ldg1(row + k0) : 0.f;
+        hi[r] = k1 < kvalid ? ldg1(row + k1) : 0.f;
+      }
+    }
+    split8(lo, hi, bh[s], bl[s]);
+    if ((s & (DEPTH - 1)) == DEPTH - 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the next layer's B operand from this layer's accumulators (row tiles 2s, 2s+1 = K-step s)
+template <int NT, bool RELU>
+__device__ __forceinline__ void acc_to_b(bf16x8 (&bh)[NT / 2], bf16x8 (&bl)[NT / 2], const f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int s = 0; s < NT / 2; ++s) {
+    if (RELU)
+      split8(relu4(acc[2 * s]), relu4(acc[2 * s + 1]), bh[s], bl[s]);
+    else
+      split8(acc[2 * s], acc[2 * s + 1], bh[s], bl[s]);
+  }
+}
+
+__device__ __forceinline__ const float* operand_row(const float* ptr, const int* idx, int rows_pb, int ld, int b, int k) {
+  const int r = idx ? ldgi(idx + k) : k;
+  return ptr + ((size_t)b * (size_t)rows_pb + (size_t)r) * (size_t)ld;
+}
+
+// K1S: 32-wide K-steps of a raw layer-1 operand (8: k = 256, 4: k <= 128, 1: k <= 32); HT / OT: hidden / output row tiles.
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST, bool HEAD, int NW, int NG>
+__global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kernel(const ChainArgs a) {
+  constexpr int kCols = NW * NG * 16;  // columns per workgroup
+  static_assert(EPI != EPI_EDGE || NW == 4, "the segment-sum epilogue walks 64 columns per round on 4 waves");
+  extern __shared__ __attribute__((aligned(16))) char ldsx[];
+  constexpr int HTP = (HT + 3) / 4 * 4, OTP = (OT + 3) / 4 * 4;
+  constexpr int HKS = HT / 2;  // K-steps of a layer fed by the hidden activations
+  constexpr int H_STEP = 2 * HTP * 1024, O_STEP = 2 * OTP * 1024;
+  constexpr int H_CS = (2 * H_STEP <= kBufBytes) ? 2 : 1, O_CS = (2 * O_STEP <= kBufBytes) ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const int tile_c0 = blockIdx.x * kCols;
+
+  int cc[NG], bb[NG], kk[NG];
+  bool valid[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c_raw = tile_c0 + g * (NW * 16) + wave * 16 + j;
+    valid[g] = c_raw < a.n_cols;
+    cc[g] = valid[g] ? c_raw : a.n_cols - 1;
+    bb[g] = cc[g] / a.cols_per_batch;
+    kk[g] = cc[g] - bb[g] * a.cols_per_batch;
+  }
+
+  bool on[3], prj[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    on[i] = (i < NSEG) && (a.seg_k[i] > 0) && (a.seg_proj[i] == 0);
+    prj[i] = (i < NSEG) && (a.seg_k[i] > 0) && (a.seg_proj[i] != 0);
+  }
+  const char* w1[3] = {(const char*)a.w1[0], (const char*)a.w1[1], (const char*)a.w1[2]};
+  if (SINGLE) w1[0] = (const char*)a.proj_w[blockIdx.y];
+  const char* w_mid = (const char*)a.w_mid;
+  const char* w_out = (const char*)a.w_out;
+  constexpr int K1_CS = H_CS;
+  constexpr int K1FIRST = (K1S < K1_CS ? K1S : K1_CS) * H_STEP;
+  const char* after_l1 = SINGLE ? nullptr : (a.n_mid > 0 ? w_mid : w_out);
+  const int after_l1_bytes = SINGLE ? 0 : (a.n_mid > 0 ? H_CS * H_STEP : O_CS * O_STEP);
+  int parity = 0;
+  {
+    const char* first = on[0] ? w1[0] : (on[1] ? w1[1] : (on[2] ? w1[2] : after_l1));
+    const int first_bytes = (on[0] || on[1] || on[2]) ? K1FIRST : after_l1_bytes;
+    issue_bytes<NW>(first, first_bytes, 0u, lane, wave);
+  }
+
+  // ---- layer 1 ----
+  constexpr int BKS = K1S > HKS ? K1S : HKS;
+  constexpr bool SHARE_ACC = (OT == HT);
+  f32x4 acc[NG][HT];
+  bf16x8 bh[NG][BKS], bl[NG][BKS];
+  init_bias<NG, HT>(acc, a.b1, q);
+  {
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) {
+      if (on[i]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float* row = operand_row(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+          load_raw<K1S, K1FULL, (NG == 1 ? 8 : 4)>(reinterpret_cast<bf16x8(&)[K1S]>(bh[g]), reinterpret_cast<bf16x8(&)[K1S]>(bl[g]), row,
+                                                  a.seg_k[i], q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const char* nx = after_l1;
+        int nb = after_l1_bytes;
+#pragma unroll
+        for (int i2 = NSEG - 1; i2 > i; --i2)
+          if (on[i2]) {
+            nx = w1[i2];
+            nb = K1FIRST;
+          }
+        pass_x3<NW, NG, K1S, BKS, HT, HTP>(acc, bh, bl, w1[i], nx, nb, ldsx, parity, lane, wave);
+      } else if (prj[i]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float* row = operand_row(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            acc[g][t] += ldg4(row + 16 * t + 4 * q);
+            if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  }
+
+  f32x4 o_sep[SHARE_ACC ? 1 : NG][SHARE_ACC ? 1 : OT];
+  f32x4 (&o)[NG][OT] = *reinterpret_cast<f32x4(*)[NG][OT]>(SHARE_ACC ? (void*)acc : (void*)o_sep);
+  if constexpr (!SINGLE) {
+    // ---- middle layers (hidden -> hidden) ----
+#pragma unroll 1
+    for (int l = 0; l < a.n_mid; ++l) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        acc_to_b<HT, true>(reinterpret_cast<bf16x8(&)[HKS]>(bh[g]), reinterpret_cast<bf16x8(&)[HKS]>(bl[g]), acc[g]);
+      __builtin_amdgcn_sched_barrier(0);
+      init_bias<NG, HT>(acc, a.b_mid + l * (HT * 16), q);
+      const bool last = (l + 1 == a.n_mid);
+      const char* nx = last ? w_out : w_mid + (size_t)(l + 1) * HKS * H_STEP;
+      const int nb = last ? O_CS * O_STEP : H_CS * H_STEP;
+      pass_x3<NW, NG, HKS, BKS, HT, HTP>(acc, bh, bl, w_mid + (size_t)l * HKS * H_STEP, nx, nb, ldsx, parity, lane, wave);
+    }
+    // ---- output layer ----
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      acc_to_b<HT, true>(reinterpret_cast<bf16x8(&)[HKS]>(bh[g]), reinterpret_cast<bf16x8(&)[HKS]>(bl[g]), acc[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    init_bias<NG, OT>(o, a.b_out, q);
+    pass_x3<NW, NG, HKS, BKS, OT, OTP>(o, bh, bl, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
+                                       POST ? H_CS * H_STEP : (HEAD ? 2 * (2 * 8 * 1024) : 0), ldsx, parity, lane, wave);
+  }
+
+  // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
+  if (!SINGLE && a.gamma != nullptr) {
+    constexpr float inv_n = 1.0f / (OT * 16);
+    float mean[NG], rstd[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) s += (o[g][t].x + o[g][t].y) + (o[g][t].z + o[g][t].w);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      mean[g] = s * inv_n;
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = o[g][t][r] - mean[g];
+          v += d * d;
+        }
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      rstd[g] = 1.0f / sqrtf(v * inv_n + 1e-5f);
+    }
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      const f32x4 gm = ldg4(a.gamma + 16 * t + 4 * q);
+      const f32x4 bt = ldg4(a.beta + 16 * t + 4 * q);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[g][t][r] = (o[g][t][r] - mean[g]) * rstd[g] * gm[r] + bt[r];
+    }
+  }
+
+  // ---- residual ----
+  if (!SINGLE && !HEAD && a.res_ptr != nullptr) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]);
+#pragma unroll
+      for (int t = 0; t < OT; ++t) {
+        const int f0 = 16 * t + 4 * q;
+        if (EPI == EPI_DEC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) o[g][t][r] += ldg1(rrow + f0 + r);
+        } else {
+          o[g][t] += ldg4(rrow + f0);
+          if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  // ---- store ----
+  float* outp = SINGLE ? a.proj_out[blockIdx.y] : a.out;
+  if (!HEAD && outp != nullptr) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (valid[g]) {
+        float* orow = outp + (size_t)cc[g] * (size_t)a.out_ld;
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+          const int f0 = 16 * t + 4 * q;
+          if (EPI == EPI_DEC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (f0 + r < a.out_cols) stg1(orow + f0 + r, o[g][t][r]);
+          } else {
+            stg4(orow + f0, o[g][t]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- HEAD: the output head on the new rows while they are still in registers (ChainArgs): 256 -> 128 relu -> 128 relu ->
+  // <= 80 features (+ residual rows): AssimilatorDecoder.node_decoder + the Decoder residual (assimilator_decoder.py:197,
+  // decoder.py:93) behind the decoder's node update; the [rows, 256] table between them is never written or read ----
+  if constexpr (HEAD) {
+    static_assert(!HEAD || (OT == 16 && HT == 16 && SHARE_ACC && !POST && !SINGLE), "HEAD follows a 256-wide node update");
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc_to_b<16, false>(reinterpret_cast<bf16x8(&)[8]>(bh[g]), reinterpret_cast<bf16x8(&)[8]>(bl[g]), o[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int HS = 2 * 8 * 1024;  // bytes of one K-step of a packed slice with <= 8 row tiles (hi + lo)
+    f32x4 hh[NG][8];
+    init_bias<NG, 8>(hh, a.hd_b1, q);
+    pass_x3<NW, NG, 8, BKS, 8, 8>(hh, bh, bl, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, ldsx, parity, lane, wave);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc_to_b<8, true>(reinterpret_cast<bf16x8(&)[4]>(bh[g]), reinterpret_cast<bf16x8(&)[4]>(bl[g]), hh[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    init_bias<NG, 8>(hh, a.hd_b2, q);
+    pass_x3<NW, NG, 4, BKS, 8, 8>(hh, bh, bl, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, ldsx, parity, lane, wave);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc_to_b<8, true>(reinterpret_cast<bf16x8(&)[4]>(bh[g]), reinterpret_cast<bf16x8(&)[4]>(bl[g]), hh[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 y[NG][5];
+    init_bias<NG, 5>(y, a.hd_b3, q);
+    pass_x3<NW, NG, 4, BKS, 5, 8>(y, bh, bl, (const char*)a.hd_w3, nullptr, 0, ldsx, parity, lane, wave);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (valid[g]) {
+        const float* rrow = a.res_ptr ? operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, bb[g], kk[g]) : nullptr;
+        float* orow = a.out + (size_t)cc[g] * (size_t)a.out_ld;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const bool pairs = (a.out_cols & 1) == 0 && ((size_t)orow & 7) == 0 && ((size_t)rrow & 7) == 0;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const int f0 = 16 * t + 4 * q;
+          if (pairs) {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2)
+              if (f0 + r < a.out_cols) {
+                const f32x2 rv = rrow ? *(const GW_AS1 f32x2*)(rrow + f0 + r) : f32x2{0.f, 0.f};
+                *(GW_AS1 f32x2*)(orow + f0 + r) = f32x2{y[g][t][r] + rv.x, y[g][t][r + 1] + rv.y};
+              }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (f0 + r < a.out_cols) stg1(orow + f0 + r, y[g][t][r] + (rrow ? ldg1(rrow + f0 + r) : 0.f));
+          }
+        }
+      }
+    }
+  }
+
+  // ---- POST: the next block's layer-1 products of the new rows, while they are still in registers (see ChainArgs) ----
+  if constexpr (POST) {
+    static_assert(!POST || (OT == 16 && HT == 16 && SHARE_ACC), "POST works on 256-wide rows");
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc_to_b<16, false>(reinterpret_cast<bf16x8(&)[8]>(bh[g]), reinterpret_cast<bf16x8(&)[8]>(bl[g]), o[g]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.zero_rows != nullptr) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (valid[g]) {
+          float* zrow = a.zero_rows + (size_t)cc[g] * 256;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) stg4(zrow + 16 * t + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+    }
+#pragma unroll 1
+    for (int sl = 0; sl < a.n_post; ++sl) {
+      init_bias<NG, HT>(acc, nullptr, q);  // (acc aliases o: the new rows have been stored and split into bh / bl)
+      const char* nx = sl + 1 < a.n_post ? (const char*)a.proj_w[sl + 1] : nullptr;
+      pass_x3<NW, NG, 8, BKS, HT, HTP>(acc, bh, bl, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, ldsx, parity, lane, wave);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (valid[g]) {
+          float* prow = a.proj_out[sl] + (size_t)cc[g] * 256;
+#pragma unroll
+          for (int t = 0; t < HT; ++t) stg4(prow + 16 * t + 4 * q, acc[g][t]);
+        }
+    }
+  }
+
+  // ---- segment sum over destination-sorted columns, 64 columns at a time through LDS (see gw_edge.hip) ----
+  if (EPI == EPI_EDGE) {
+    float* stage = (float*)ldsx;  // over the weight buffers: every pass of this workgroup is complete (barrier below)
+    int* gdl = (int*)(stage + kStageFloats);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      __syncthreads();  // the last pass's fragment reads / the previous round's readers are done
+      {
+        float* srow = stage + (wave * 16 + j) * kStageLd + 4 * q;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2)
+          if (g2 == g) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) *(f32x4*)(srow + 16 * t) = o[g2][t];
+            if (q == 0) gdl[wave * 16 + j] = valid[g2] ? bb[g2] * a.agg_rows_pb + ldgi(a.agg_idx + kk[g2]) : -1;
+          }
+      }
+      __syncthreads();
+      const int f = threadIdx.x;
+      float vv[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) vv[i] = stage[i * kStageLd + f];
+      const int gdv = gdl[lane];
+      const int gdn = gdl[lane < 63 ? lane + 1 : lane];
+      const unsigned long long ends = __ballot(lane == 63 || gdn != gdv);
+      // deterministic mode: carry records instead of atomics (gw_internal.hpp; same scheme as gw_edge.hip)
+      bool open_lo = true, open_hi = true;
+      float* rec = nullptr;
+      if (a.carry != nullptr) {
+        const int chunk_c0 = tile_c0 + g * 64;
+        rec = a.carry + (size_t)(chunk_c0 >> 6) * kCarryFloats;
+        const int c_prev = chunk_c0 - 1, c_next = chunk_c0 + 64;
+        int gd_prev = -2, gd_next = -2;
+        if (c_prev >= 0 && c_prev < a.n_cols) {
+          const int bp = c_prev / a.cols_per_batch;
+          gd_prev = bp * a.agg_rows_pb + ldgi(a.agg_idx + (c_prev - bp * a.cols_per_batch));
+        }
+        if (c_next < a.n_cols) {
+          const int bn = c_next / a.cols_per_batch;
+          gd_next = bn * a.agg_rows_pb + ldgi(a.agg_idx + (c_next - bn * a.cols_per_batch));
+        }
+        open_lo = gd_prev == __builtin_amdgcn_readlane(gdv, 0);
+        open_hi = gd_next == __builtin_amdgcn_readlane(gdv, 63);
+        if (f == 0 && chunk_c0 < a.n_cols) {
+          rec[512] = __int_as_float(-1);
+          rec[513] = __int_as_float(-1);
+          rec[514] = __int_as_float(0);
+        }
+      }
+      float run = 0.f;
+      bool first = true;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        run += vv[i];
+        if (__builtin_expect((ends >> i) & 1ull, 0)) {
+          const int cur = __builtin_amdgcn_readlane(gdv, i);
+          if (cur >= 0) {
+            float* dstp = a.agg + (size_t)cur * 256 + f;
+            if (rec != nullptr) {
+              const bool lo = first && open_lo, hi = i == 63 && open_hi;
+              if (lo) {
+                rec[f] = run;
+                if (f == 0) {
+                  rec[512] = __int_as_float(cur);
+                  if (hi) rec[514] = __int_as_float(1);
+                }
+              } else if (hi) {
+                rec[256 + f] = run;
+                if (f == 0) rec[513] = __int_as_float(cur);
+              } else {
+                stg1(dstp, run);
+              }
+            } else if (first || i == 63) {
+              __hip_atomic_fetch_add((GW_AS1 float*)dstp, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              stg1(dstp, run);
+            }
+          }
+          first = false;
+          run = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// ---- weight packing: nn.Linear [n_out, k_total] slice -> split bf16 MFMA A-operand stream ---------------------------
+// out[s][half][tile][lane][i]: half 0 = bf16(w), half 1 = bf16(w - bf16(w)) of
+// W[16 tile + (lane & 15)][k_lo + 32 s + 16 (i >> 2) + 4 (lane >> 4) + (i & 3)], 0 outside
+__global__ void pack_linear_x3_kernel(const float* __restrict__ w, long long sf, long long sk, int n_out, int kseg, int ntp, int nsteps,
+                                      __bf16* __restrict__ out) {
+  const size_t total = (size_t)nsteps * ntp * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e & 7);
+    const int lane = (int)((e >> 3) & 63);
+    const int tile = (int)((e >> 9) % ntp);
+    const int s = (int)((e >> 9) / ntp);
+    const int f = 16 * tile + (lane & 15);
+    const int kx = 32 * s + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+    const float v = (f < n_out && kx < kseg) ? w[(long long)f * sf + (long long)kx * sk] : 0.f;
+    const __bf16 h = (__bf16)v;
+    const size_t o = ((size_t)s * 2 * ntp + tile) * 512 + (size_t)lane * 8 + i;
+    out[o] = h;
+    out[o + (size_t)ntp * 512] = (__bf16)(v - (float)h);
+  }
+}
+
+template <typename K>
+int launchx3(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes, int threads, int cols) {
+  static DeviceOnce once;  // per template instantiation and device
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEdge);
+  const int grid = (a.n_cols + cols - 1) / cols;
+  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(threads), lds_bytes, (hipStream_t)stream, a);
+  return check_launch("chainx3_kernel launch");
+}
+
+// one (kind, form) -> instantiation.  Product build: 4 waves x 1 group (64 columns, two workgroups per CU).  Tuning builds also
+// carry form 42 = 4 x 2 (128 columns, one workgroup per CU) and 81 = 8 x 1 (128 columns share one weight stream, two waves per
+// SIMD; row-wise kinds only) behind GW_X3_FORM / GW_X3_FORM_EDGE.
+template <int K1S, bool K1F, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST, bool HEAD>
+int launch_kind(ChainArgs& a, void* stream, int gy, int lds, int form) {
+#ifdef GW_TUNING
+  if (form == 42) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 2>, a, stream, gy, lds, 256, 128);
+  if constexpr (EPI != EPI_EDGE) {
+    if (form == 81) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 8, 1>, a, stream, gy, lds, 512, 128);
+  }
+#endif
+  (void)form;
+  return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 1>, a, stream, gy, lds, 256, 64);
+}
+#define GW_X3(K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, GY, LDS) \
+  return launch_kind<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD>(a, stream, GY, LDS, form)
+
+}  // namespace
+
+namespace gw {
+
+int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream) {
+  static const int f_rows = GW_TUNE("GW_X3_FORM", 41), f_edge = GW_TUNE("GW_X3_FORM_EDGE", 41);
+  const int form = kind == 1 ? f_edge : f_rows;
+  switch (kind) {
+    case 0:  // mlp rows
+      if (hidden == 256 && n_out == 256) {
+        if (k_in <= 32) GW_X3(1, false, 1, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
+        if (k_in <= 128) GW_X3(4, false, 1, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
+        if (k_in == 256) GW_X3(8, true, 1, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
+      } else if (hidden == 256 && n_out <= 80 && k_in == 256) {
+        GW_X3(8, true, 1, 16, 5, EPI_DEC, false, false, false, 1, kLdsWeights);
+      } else if (hidden == 128 && n_out <= 80 && k_in == 256) {
+        GW_X3(8, true, 1, 8, 5, EPI_DEC, false, false, false, 1, kLdsWeights);
+      }
+      return set_error(GW_E_UNSUPPORTED, "bf16x3 mlp: unsupported (hidden, n_out, k) combination");
+    case 1:  // edge update
+      GW_X3(8, true, 3, 16, 16, EPI_EDGE, false, false, false, 1, kLdsEdge);
+    case 2:  // node update
+      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
+    case 3:  // projections (grid_y slices)
+      GW_X3(8, true, 1, 16, 16, EPI_ROWS, true, false, false, grid_y, kLdsWeights);
+    case 4:  // node update + POST products
+      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, true, false, 1, kLdsWeights);
+    case 6:  // node update + output head (decoder)
+      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, false, true, 1, kLdsWeights);
+    case 5:  // mlp rows + POST products of the output rows (node encoder -> layer-1 products of the encoder's edge MLP)
+      if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32) GW_X3(4, false, 1, 16, 16, EPI_ROWS, false, true, false, 1, kLdsWeights);
+      return set_error(GW_E_UNSUPPORTED, "bf16x3 mlp + post products: hidden 256, 256 outputs, 33..128 inputs");
+  }
+  return set_error(GW_E_BADARG, "chainx3_launch: bad kind");
+}
+
+void pack_x3_item(const float* w, long long sf, long long sk, int n_out, int kseg, int ntp, int nsteps, void* out, void* stream) {
+  const size_t total = (size_t)nsteps * ntp * 512;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(pack_linear_x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, sf, sk, n_out, kseg, ntp, nsteps, (__bf16*)out);
+}
+
+}  // namespace gw
+
+extern "C" {
+
+// K-steps (32 input features each) of a packed slice: as gw_packed_bytes_bf16 (1, 4 or k / 32 steps)
+static int packed_steps_x3(int kseg) { return kseg <= 32 ? 1 : (kseg <= 128 ? 4 : (kseg + 31) / 32); }
+
+size_t gw_packed_bytes_bf16x3(int n_out, int k_lo, int k_hi) {
+  const int kseg = k_hi - k_lo;
+  const int nsteps = packed_steps_x3(kseg);
+  const int ntp = (((n_out + 15) / 16) + 3) / 4 * 4;
+  return (size_t)nsteps * ntp * 2048;
+}
+
+int gw_pack_linear_bf16x3(const float* w, int n_out, int k_total, int k_lo, int k_hi, void* out, void* stream) {
+  if (!w || !out || n_out <= 0 || k_lo < 0 || k_hi <= k_lo || k_hi > k_total)
+    return gw::set_error(GW_E_BADARG, "gw_pack_linear_bf16x3: bad arguments");
+  const int kseg = k_hi - k_lo;
+  gw::pack_x3_item(w + k_lo, k_total, 1, n_out, kseg, (((n_out + 15) / 16) + 3) / 4 * 4, packed_steps_x3(kseg), out, stream);
+  return gw::check_launch("pack_linear_x3_kernel launch");
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from .graphs import build_forecast_graphs
+from .graphs import TopologyRecord, build_forecast_graphs
 from .layers import Decoder, Encoder, Processor, fused_forward, set_compute_dtype
 
 try:  # forecast.py:8,61 - hub mixin gives save_pretrained / from_pretrained / push_to_hub
@@ -48,7 +48,7 @@ class GraphWeatherForecasterConfig:
         return GraphWeatherForecaster(**self.__dict__)
 
 
-class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
+class GraphWeatherForecaster(TopologyRecord, torch.nn.Module, PyTorchModelHubMixin):
     """forecast.py:61-247 (constraint layer and thermalizer are optional extras outside the hot path)."""
 
     def __init__(self, lat_lons: list, resolution: int = 2, feature_dim: int = 78, aux_dim: int = 24,
@@ -99,8 +99,8 @@ class GraphWeatherForecaster(torch.nn.Module, PyTorchModelHubMixin):
                                hidden_dim_decoder=hidden_dim_decoder, hidden_layers_decoder=hidden_layers_decoder,
                                use_checkpointing=use_checkpointing, _graphs=graphs)
 
-    def set_compute_dtype(self, dtype: torch.dtype) -> "GraphWeatherForecaster":
-        """float32 (default) or bfloat16 matrix products - see ``layers.set_compute_dtype``."""
+    def set_compute_dtype(self, dtype) -> "GraphWeatherForecaster":
+        """float32 (default), bfloat16 or "bf16x3" (split-operand) matrix products - see ``layers.set_compute_dtype``."""
         set_compute_dtype(self, dtype)
         return self
 

@@ -14,11 +14,11 @@ import torch
 
 from . import autograd as ag
 from . import wide
-from .graphs import build_forecast_graphs
+from .graphs import TopologyRecord, build_forecast_graphs
 from .layers import Decoder, Encoder, Processor, fused_forward
 
 
-class GraphCast(torch.nn.Module):
+class GraphCast(TopologyRecord, torch.nn.Module):
     def __init__(self, lat_lons: list, resolution: int = 2, input_dim: int = 78, output_dim: int = 78, hidden_dim: int = 256,
                  num_processor_blocks: int = 9, hidden_layers: int = 2, mlp_norm_type: str = "LayerNorm",
                  use_checkpointing: bool = False, efficient_batching: bool = False):

@@ -193,7 +193,11 @@ class ForecastGraphs:
     def topology_hash(self) -> str:
         """Digest of the three edge lists: equal hashes = same mesh numbering and topology.  A checkpoint is only meaningful on
         the topology it was trained on (real h3 for reference-trained weights); ``check_topology`` compares."""
-        return topology_hash(self.enc_edge_index, self.lat_edge_index, self.dec_edge_index)
+        h = getattr(self, "_topo_hash", None)
+        if h is None:  # (memoised: the arrays are immutable by convention; 0.25 degree hashes 116 MB)
+            h = topology_hash(self.enc_edge_index, self.lat_edge_index, self.dec_edge_index)
+            object.__setattr__(self, "_topo_hash", h)
+        return h
 
     def as_oracle_dict(self) -> dict:
         return {
@@ -292,7 +296,45 @@ def check_topology(module, expected_hash: str, strict: bool = False) -> bool:
     return False
 
 
-_BUILT: list = []  # the last few (key, ForecastGraphs): see build_forecast_graphs
+class TopologyRecord:
+    """Mixin of the models built on ``ForecastGraphs`` (``self.encoder.graphs``): ``state_dict()`` records which mesh topology
+    the weights belong to (``_metadata[""]["gw_topology"]`` / ``["gw_provider"]`` - metadata survives ``torch.save`` and adds no
+    key, so reference checkpoints and ``strict=True`` loads are unaffected) and ``load_state_dict()`` compares it with the
+    running one.  The reference numbers mesh cells with h3 (encoder.py:76-104, assimilator_decoder.py:69-101); this image has
+    no h3 wheel and builds the mesh with ``mesh.H3Like`` - same counts, possibly another numbering - so a checkpoint trained
+    elsewhere loads (equal shapes) but may mean something else: that is said out loud here instead of staying silent."""
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        md = getattr(sd, "_metadata", None)
+        graphs = getattr(getattr(self, "encoder", None), "graphs", None)
+        top_level = not (kwargs.get("prefix") or (len(args) > 1 and args[1]))
+        if md is not None and graphs is not None and top_level:
+            md.setdefault("", {})
+            md[""]["gw_topology"] = graphs.topology_hash()
+            md[""]["gw_provider"] = graphs.provider
+        return sd
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        import warnings
+
+        res = super().load_state_dict(state_dict, *args, **kwargs)
+        graphs = getattr(getattr(self, "encoder", None), "graphs", None)
+        if graphs is None:
+            return res
+        md = getattr(state_dict, "_metadata", None) or {}
+        expected = md.get("", {}).get("gw_topology") if isinstance(md.get("", {}), dict) else None
+        if expected is not None:
+            check_topology(self, expected)
+        elif graphs.provider != "h3":
+            warnings.warn("graph_weather_amd: this checkpoint carries no mesh-topology record (e.g. it was written by the reference, "
+                          "whose mesh cells are numbered by h3) and this model runs on the built-in mesh provider (%r, topology %s): "
+                          "the tensors load, but parity with the weights' original mesh numbering is unverified - see "
+                          "graphs.check_topology" % (graphs.provider, graphs.topology_hash()))
+        return res
+
+
+_BUILT: list = []  # the last few (key, ForecastGraphs, provider): see build_forecast_graphs
 
 
 def build_forecast_graphs(lat_lons, resolution: int = 2, provider=None) -> ForecastGraphs:
@@ -304,11 +346,13 @@ def build_forecast_graphs(lat_lons, resolution: int = 2, provider=None) -> Forec
     provider = provider if provider is not None else _mesh.get_provider()
     ll = np.ascontiguousarray(np.asarray(lat_lons, dtype=np.float64).reshape(-1, 2))
     key = (hashlib.sha256(ll.tobytes()).hexdigest(), int(resolution), id(provider) if not isinstance(provider, _mesh.H3Like) else "builtin")
-    for k, g in _BUILT:
+    for k, g, _ in _BUILT:
         if k == key:
             return g
     g = _build_forecast_graphs(lat_lons, resolution, provider)
-    _BUILT.append((key, g))
+    # (the entry holds the provider object: an id() used as key cannot be recycled while the entry lives.  The plans and their
+    # lazily attached tile maps are shared by every model built on the grid and are immutable by convention.)
+    _BUILT.append((key, g, provider))
     del _BUILT[:-2]
     return g
 

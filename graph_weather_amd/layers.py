@@ -25,7 +25,7 @@ from . import ops
 from . import wide
 from .autograd import OperandSpec
 from .graphs import ForecastGraphs, GraphPlan, build_forecast_graphs
-from .ops import Operand, PackedMLP
+from .ops import BF16X3, Operand, PackedMLP
 
 _NORMS = ["LayerNorm", "GraphNorm", "InstanceNorm", "BatchNorm", "MessageNorm"]
 
@@ -51,7 +51,7 @@ def _autograd_on(module: nn.Module, *inputs: Optional[torch.Tensor]) -> bool:
         for m in module.modules():
             if isinstance(m, MLP) and m.compute_dtype != torch.float32:
                 raise NotImplementedError("graph_weather_amd: the backward pass is implemented for float32 matrix products; "
-                                          "call the bfloat16 mode under torch.no_grad() (inference)")
+                                          "call the bfloat16 / bf16x3 modes under torch.no_grad() (inference)")
     return on
 
 
@@ -98,12 +98,19 @@ def set_deterministic(module: nn.Module, flag: bool = True) -> nn.Module:
     return module
 
 
-def set_compute_dtype(module: nn.Module, dtype: torch.dtype) -> nn.Module:
+def set_compute_dtype(module: nn.Module, dtype) -> nn.Module:
     """Select the matrix-product dtype of every MLP under ``module``: ``torch.float32`` (default, the reference's
-    arithmetic) or ``torch.bfloat16`` (bf16 MFMA with fp32 accumulation; parameters, activations in HBM, LayerNorm,
-    residuals and segment sums stay fp32) - what a reference user gets from ``torch.autocast(dtype=torch.bfloat16)``."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32 or torch.bfloat16")
+    arithmetic), ``torch.bfloat16`` (bf16 MFMA with fp32 accumulation; parameters, activations in HBM, LayerNorm,
+    residuals and segment sums stay fp32) - what a reference user gets from ``torch.autocast(dtype=torch.bfloat16)`` - or
+    ``"bf16x3"`` (``ops.BF16X3``): every product as three bf16 MFMAs on hi / lo operand pairs (16 significant bits per operand,
+    fp32 accumulate, csrc/gw_split.hip) - the reference's fp32 outputs to a few 1e-5 of their scale, i.e. inside BASELINE.json's
+    1e-3, at several times the fp32 matrix rate; every tensor in HBM stays fp32 rows.  The 16-bit modes are inference only."""
+    if isinstance(dtype, str):
+        if dtype.lower() not in (BF16X3, "split"):
+            raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32, torch.bfloat16 or \"bf16x3\"")
+        dtype = BF16X3
+    elif dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32, torch.bfloat16 or \"bf16x3\"")
     for m in module.modules():
         if isinstance(m, MLP):
             m.compute_dtype = dtype
@@ -477,13 +484,13 @@ class GraphProcessor(nn.Module):
         return x, (e_cur if want_edges else None)
 
     def forward_streams(self, batch: int) -> int:
-        """Streams the fused inference forward runs this stack on: ``self.streams`` if set, else 2 for fp32 matrix products and
-        batch >= 2 (mesh-sized fp32 launches leave workgroup slots idle in their last round; the bf16 kernels are persistent
-        and occupy every CU by themselves), else 1."""
+        """Streams the fused inference forward runs this stack on: ``self.streams`` if set, else 2 for fp32 / bf16x3 matrix products
+        and batch >= 2 (their mesh-sized launches of 64-column workgroups leave workgroup slots idle in the last round; the bf16
+        kernels are persistent and occupy every CU by themselves), else 1."""
         if self.streams > 0:
             return max(1, min(int(self.streams), batch))
-        fp32 = all(b.edge_model.edge_mlp.compute_dtype == torch.float32 for b in self.blocks)
-        return 2 if (fp32 and batch >= 2) else 1
+        tiled = all(b.edge_model.edge_mlp.compute_dtype in (torch.float32, BF16X3) for b in self.blocks)  # (64-column workgroups)
+        return 2 if (tiled and batch >= 2) else 1
 
     def side_streams(self, device, n: int):
         key = (str(device), n)
@@ -498,7 +505,12 @@ class GraphProcessor(nn.Module):
             blk.edge_model.edge_mlp.packed()
             blk.node_model.node_mlp.packed()
         if len(self.blocks):
-            self._shared_e0(self.blocks[0], e, plan.num_edges)
+            # (on the stream of the caller, before the per-sample chains fork: whichever of the two cached forms block 0 reads)
+            seg = self._seg_for(plan)
+            if seg is not None:
+                self._shared_e0_seg(self.blocks[0], e, seg)
+            else:
+                self._shared_e0(self.blocks[0], e, plan.num_edges)
 
     def _seg_for(self, plan: GraphPlan):
         """The plan's segment-aligned tiles when the whole stack can run on them (bf16 inference with the resident kernels in
@@ -521,13 +533,14 @@ class GraphProcessor(nn.Module):
         key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key(), seg.n_pad)
         hit = getattr(self, "_e0_seg_cache", None)
         if hit is None or hit[0] != key or hit[3] is not e_cur:
-            pe = self._shared_e0(blk, e_cur, int(e_cur.shape[0]))[1]
+            pe = self._shared_e0(blk, e_cur, int(e_cur.shape[0]), tiles=False)[1]
             e_pad = seg.pad_rows(e_cur)
             self._e0_seg_cache = (key, seg.pad_rows(pe), ops.edge_rows_to_tiles(e_pad, 1, seg.n_pad, seg.n_pad), e_cur)
         return self._e0_seg_cache[1], self._e0_seg_cache[2]
 
-    def _shared_e0(self, blk, e_cur: torch.Tensor, n_edges: int):
-        """(We . e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights)."""
+    def _shared_e0(self, blk, e_cur: torch.Tensor, n_edges: int, tiles: bool = True):
+        """(We . e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights).
+        ``tiles=False``: the caller reads only the product (the segment-tile route keeps its own padded tile set)."""
         mlp_e = blk.edge_model.edge_mlp
         pm_e = mlp_e.packed()
         tiled = (mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None
@@ -536,7 +549,7 @@ class GraphProcessor(nn.Module):
         if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
             pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
             self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
-        if tiled and len(self._e0_cache) == 3:  # the residual of the resident bf16 kernel: e as one shared tile set
+        if tiled and tiles and len(self._e0_cache) == 3:  # the residual of the resident bf16 kernel: e as one shared tile set
             self._e0_cache = self._e0_cache + (ops.edge_rows_to_tiles(e_cur, 1, n_edges, n_edges),)
         return self._e0_cache
 
@@ -549,9 +562,10 @@ class GraphProcessor(nn.Module):
         train = _autograd_on(self, x, e)
         carried = None if train else pre_proj  # (P_s, P_d, zeroed aggregate) made by the previous node update
         tail = None
-        seg = None if (train or want_edges or lo != 0) else self._seg_for(plan)
-        if seg is not None and not shared and e_cur.dtype != torch.uint8:
-            e_cur = ops.edge_rows_to_tiles(seg.pad_batched_rows(e_cur.contiguous(), batch), batch, seg.n_pad, seg.n_pad)
+        # segment-aligned tiles: the running aggregate of that route starts from the cached segment sums of the BATCH-SHARED edge
+        # features of block 0 (csrc/gw_edge16p.hip: agg += sum(LN(.)) on top of sum(e)); per-sample edge features handed in by a
+        # caller (Processor.forward without efficient batching) take the tile route without segment alignment
+        seg = None if (train or want_edges or lo != 0 or not shared) else self._seg_for(plan)
         for i in range(lo, hi):
             blk = self.blocks[i]
             last = i == hi - 1
@@ -597,9 +611,12 @@ class GraphProcessor(nn.Module):
                 nxt_tiled = (npk is not None and nm.compute_dtype == torch.bfloat16 and npk.n_mid == 1 and npk.ln_width == 0
                              and npk.gamma is not None)
             out_kind = "tiles" if (tiled and need_e and nxt_tiled) else need_e
-            e_res = self._e0_cache[3] if (shared and tiled) else e_cur
             if seg is not None and shared:
                 e_res = self._shared_e0_seg(blk, e_cur, seg)[1]
+            elif shared and tiled:
+                e_res = self._shared_e0(blk, e_cur, n_edges)[3]
+            else:
+                e_res = e_cur
             # what the node update of this block also produces (inference): the next block's layer-1 node products
             post_w, post_zero, post_half = None, False, False
             if not train:
@@ -735,15 +752,17 @@ class Encoder(nn.Module):
         feats = features.contiguous().reshape(B * G, F)
         enc_plan, _ = self._plans(features.device)
         team = self.team_path(features)
+        x3 = self.split_path(features)
         ne = self.node_encoder
         fused_ps = None
-        if team and ne.compute_dtype == torch.bfloat16 and not ne._layout()[4] and 32 < ne.native_k() <= 128:
+        if ((team and ne.compute_dtype == torch.bfloat16) or (x3 and ne.compute_dtype == BF16X3)) and not ne._layout()[4] \
+                and 32 < ne.native_k() <= 128:
             # node encoder and the x[row] product of the edge MLP's layer 1 in ONE launch: the grid rows themselves are never
-            # written (the encoder drops them, encoder.py:219-223) - only Ws . node_encoder(features), as fp16 rows
+            # written (the encoder drops them, encoder.py:219-223) - only Ws . node_encoder(features) (bf16 mode: as fp16 rows)
             pm_e0 = self.graph_processor.blocks[0].edge_model.edge_mlp.packed()
             k = ne.native_k()
             x2 = feats if k <= F else torch.nn.functional.pad(feats, (0, k - F))
-            fused_ps = ops.mlp_post_forward(ne.packed(), Operand(x2, G, k), B * G, G, [pm_e0.w1[0]], post_half=True)[1][0]
+            fused_ps = ops.mlp_post_forward(ne.packed(), Operand(x2, G, k), B * G, G, [pm_e0.w1[0]], post_half=team)[1][0]
             xg = None
         else:
             xg = ne.run(feats, B * G, G)  # grid rows only
@@ -754,18 +773,19 @@ class Encoder(nn.Module):
         pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
         x_src, e_res = Feed(xg, G, "raw"), e
         seg = None
-        if team:
-            # bf16 inference on the team-pipelined edge kernel (csrc/gw_edge16t.hip): every operand of the edge MLP's layer 1
-            # enters as a product - Ws.xg is made once per grid node here (one edge per grid node: the same matrix work the raw
-            # operand would cost inside the edge kernel) and handed over as fp16 rows - and, e' being dropped (encoder.py:219) and
-            # e batch independent, the residual leaves the kernel: sum(LN(.) + e) = sum(LN(.)) + S, and Wa.S joins the cached
-            # node-update product of the mesh rows.
+        if team or x3:
+            # 16-bit inference (bf16: the team-pipelined edge kernel, csrc/gw_edge16t.hip; bf16x3: csrc/gw_split.hip): every operand
+            # of the edge MLP's layer 1 enters as a product - Ws.xg is made once per grid node here (one edge per grid node: the same
+            # matrix work the raw operand would cost inside the edge kernel; bf16 mode: handed over as fp16 rows) - and, e' being
+            # dropped (encoder.py:219) and e batch independent, the residual leaves the kernel: sum(LN(.) + e) = sum(LN(.)) + S, and
+            # Wa.S joins the cached node-update product of the mesh rows.
             pm_e = blk.edge_model.edge_mlp.packed()
             if fused_ps is None:
-                fused_ps = ops.project_forward([pm_e.w1[0]], Operand(xg, G, 256), B * G, G, out_half=True)[0]
+                fused_ps = ops.project_forward([pm_e.w1[0]], Operand(xg, G, 256), B * G, G, out_half=team)[0]
             x_src = Feed(fused_ps, G, "proj")
             px_xm = self._team_node_product(blk, enc_plan, e, px_xm)
             e_res = None
+        if team:
             seg = enc_plan.seg_tiles(split=True)  # (a polar mesh cell collects hundreds of grid nodes: runs split over tiles)
             if seg is not None:
                 pe = self._cached("enc_pe_pad", list(self.parameters()), lambda: seg.pad_rows(pe))
@@ -790,6 +810,15 @@ class Encoder(nn.Module):
             return False
         pm_e = mlp_e.packed()
         return pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and self.graphs.enc_plan.num_edges > 0
+
+    def split_path(self, features: Optional[torch.Tensor] = None) -> bool:
+        """Inference with bf16x3 (split-operand) products in both MLPs of the encoder block: the edge update then runs with every
+        layer-1 operand projected and without residual, like the bf16 team path, on fp32 rows (csrc/gw_split.hip)."""
+        blk = self.graph_processor.blocks[0]
+        mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
+        if wide.encoder_is_wide(self) or _autograd_on(self, features):
+            return False
+        return mlp_e.compute_dtype == BF16X3 and mlp_n.compute_dtype == BF16X3 and self.graphs.enc_plan.num_edges > 0
 
     def _team_node_product(self, blk, plan: GraphPlan, e: torch.Tensor, px_xm: torch.Tensor) -> torch.Tensor:
         """Wx.xm + Wa.S with S[dst] = the sum of the (batch-independent) edge features e over the destination's edges: the
@@ -945,6 +974,14 @@ class AssimilatorDecoder(nn.Module):
         pm_e = mlp_e.packed()
         return pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and self.graphs.dec_plan.num_edges > 0
 
+    def split_path(self) -> bool:
+        """Inference with bf16x3 (split-operand) products in both MLPs of the decoder block (see ``Encoder.split_path``)."""
+        blk = self.graph_processor.blocks[0]
+        mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
+        if wide.decoder_is_wide(self) or _autograd_on(self):
+            return False
+        return mlp_e.compute_dtype == BF16X3 and mlp_n.compute_dtype == BF16X3 and self.graphs.dec_plan.num_edges > 0
+
     def decode(self, processor_features: torch.Tensor, batch_size: int,
                residual: Optional[torch.Tensor] = None, ps: Optional[torch.Tensor] = None) -> torch.Tensor:
         """assimilator_decoder.py:173-200 (+ decoder.py:93 when ``residual`` [B*G, ld] is given).  ``ps`` (inference, fused
@@ -988,9 +1025,11 @@ class AssimilatorDecoder(nn.Module):
                     self._cache["dec_pe_pad"] = (key, seg.pad_rows(pe))
                 pe = self._cache["dec_pe_pad"][1]
             x_node = FEED_ZERO
-            if mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and n_e > 0:
+            x3 = self.split_path()
+            if x3 or (mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None
+                      and n_e > 0):
                 pm_n = blk.node_model.node_mlp.packed()
-                if not team:
+                if not (team or x3):
                     # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
                     hit = self._cache.get("dec_e_tiles")
                     if hit is None or hit[0] != key:
@@ -1005,10 +1044,10 @@ class AssimilatorDecoder(nn.Module):
                     hit = self._cache.get("dec_e_sum")
                     if hit is None or hit[0] != key:
                         e_sum = ag.segment_sum_rows(e, n_e, 1, 1, plan.n_dst, plan.dst_ptr(), None)
-                        # (fp16 rows, like every layer-1 product of the bf16 path: the node update adds them to its fp32
-                        # accumulator and rounds the sum to bf16)
+                        # (bf16 mode: fp16 rows, like every layer-1 product of that path: the node update adds them to its fp32
+                        # accumulator and rounds the sum to bf16; bf16x3: fp32 rows)
                         self._cache["dec_e_sum"] = (key, ops.project_forward([pm_n.w1[1]], Operand(e_sum, plan.n_dst, 256),
-                                                                             plan.n_dst, plan.n_dst, out_half=True)[0])
+                                                                             plan.n_dst, plan.n_dst, out_half=team)[0])
                     x_node = Feed(self._cache["dec_e_sum"][1], 0, "proj")
                     e = None
         res = None
@@ -1020,7 +1059,7 @@ class AssimilatorDecoder(nn.Module):
         if not train and x_node is not FEED_ZERO:
             head = None
             nd = self.node_decoder
-            if nd.compute_dtype == torch.bfloat16 and not wide.is_wide(nd) and not nd._layout()[4]:
+            if nd.compute_dtype == blk.node_model.node_mlp.compute_dtype and not wide.is_wide(nd) and not nd._layout()[4]:
                 pm_h = nd.packed()
                 if pm_h.hidden == 128 and pm_h.n_mid == 1 and pm_h.n_out <= 80 and pm_h.gamma is None:
                     head = (pm_h, res)  # node update + node_decoder (+ residual) in one launch: the grid-row table is never written

@@ -154,16 +154,35 @@ def pack_many(weight_dtype: int, mats, vecs, stream: int) -> None:
         vi += len(vc)
 
 
+BF16X3 = "bf16x3"
+"""Compute-dtype name of the split-operand mode (include/gw_amd.h: GW_DTYPE_BF16X3): every matrix product as three bf16 MFMAs on
+hi / lo operand pairs with fp32 accumulation - the reference's fp32 results to ~1e-5 at 5.3 x the fp32 matrix rate.  torch has no
+dtype for it, hence a name; ``set_compute_dtype(model, "bf16x3")``."""
+
+# torch dtype of a packed weight stream per GW_DTYPE_* (the split stream is typed int16: 2-byte elements no arithmetic is done on,
+# and distinct from the bf16 stream, so the dtype of a packed slice names its format)
+_STREAM_TORCH_DTYPE = {_lib.DTYPE_F32: torch.float32, _lib.DTYPE_BF16: torch.bfloat16, _lib.DTYPE_BF16X3: torch.int16}
+_STREAM_GW_DTYPE = {v: k for k, v in _STREAM_TORCH_DTYPE.items()}
+
+
+def gw_dtype_of(compute_dtype) -> int:
+    if compute_dtype == torch.float32:
+        return _lib.DTYPE_F32
+    if compute_dtype == torch.bfloat16:
+        return _lib.DTYPE_BF16
+    if isinstance(compute_dtype, str) and compute_dtype.lower() in (BF16X3, "bf16x3", "split"):
+        return _lib.DTYPE_BF16X3
+    raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32, torch.bfloat16 or \"bf16x3\"")
+
+
 class PackedMLP:
     """Device-resident packed form of one reference ``MLP`` (graph_net_block.py:45-61)."""
 
     def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
                  ln: Optional[Tuple[torch.Tensor, torch.Tensor]], splits: Sequence[Tuple[int, int]],
-                 compute_dtype: torch.dtype = torch.float32, ln_width: int = 0):
+                 compute_dtype=torch.float32, ln_width: int = 0):
         L = _lib.lib()
-        if compute_dtype not in (torch.float32, torch.bfloat16):
-            raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32 or torch.bfloat16")
-        self.weight_dtype = _lib.DTYPE_BF16 if compute_dtype == torch.bfloat16 else _lib.DTYPE_F32
+        self.weight_dtype = gw_dtype_of(compute_dtype)
         n_lin = len(weights)
         if n_lin < 2:
             raise RuntimeError("graph_weather_amd: MLP needs at least one hidden layer")
@@ -182,7 +201,7 @@ class PackedMLP:
 
         # Every slice and vector of the MLP goes through ONE gw_pack_many launch (27 MLPs x ~10 packing launches per weight
         # version otherwise: the bulk of a forward right after an optimizer step).  Items address the parameters in place.
-        bf16 = self.weight_dtype == _lib.DTYPE_BF16
+        wd = self.weight_dtype
         mats, vecs, keep = [], [], []
 
         def src(t):
@@ -193,8 +212,10 @@ class PackedMLP:
             return t
 
         def out_for(n_out, kseg):
-            if bf16:
+            if wd == _lib.DTYPE_BF16:
                 return torch.empty(L.gw_packed_bytes_bf16(n_out, 0, kseg) // 2, dtype=torch.bfloat16, device=dev)
+            if wd == _lib.DTYPE_BF16X3:
+                return torch.empty(L.gw_packed_bytes_bf16x3(n_out, 0, kseg) // 2, dtype=torch.int16, device=dev)
             return torch.empty(L.gw_packed_floats(n_out, 0, kseg), dtype=torch.float32, device=dev)
 
         def pack(w, k_lo, k_hi, out=None, rows=0):
@@ -309,7 +330,7 @@ def project_forward(w_slices: Sequence[torch.Tensor], x: Operand, n_rows: int, r
     wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w_slices])
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     if weight_dtype is None:
-        weight_dtype = _lib.DTYPE_BF16 if w_slices[0].dtype == torch.bfloat16 else _lib.DTYPE_F32
+        weight_dtype = _STREAM_GW_DTYPE[w_slices[0].dtype]
     with on_device_of(outs[0]):
         _lib.check(_lib.lib().gw_project_forward(n_rows, max(1, rows_per_batch), x.c(), n, wp, op, 256,
                                                  _lib.LAYOUT_ROWS_F16 if out_half else _lib.LAYOUT_ROWS_F32, weight_dtype,

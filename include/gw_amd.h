@@ -31,13 +31,21 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 15
+#define GW_ABI_VERSION 16
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
  * in registers - BASELINE.json configs[2]. */
 #define GW_DTYPE_F32 0
 #define GW_DTYPE_BF16 1
+/* GW_DTYPE_BF16X3 (v16): split-operand products.  Both operands of every Linear (graph_net_block.py:45-61: fp32 in the reference)
+ * are carried as a pair of bf16 values, v = hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 significant bits, fp32 exponent
+ * range), and x . w is evaluated as x_hi . w_hi + x_hi . w_lo + x_lo . w_hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
+ * (csrc/gw_split.hip): ~1e-5 per product - inside BASELINE.json's 1e-3 - at 3 bf16 MFMAs per product.  Streams from
+ * gw_pack_linear_bf16x3 (4 bytes per weight).  Every table this mode reads or writes is fp32 rows (GW_LAYOUT_ROWS_F32): none of
+ * the bf16 mode's 16-bit formats (edge tiles, fp16 product rows, bf16 K-order aggregates, segment-aligned tiles) applies.
+ * Inference only, like GW_DTYPE_BF16. */
+#define GW_DTYPE_BF16X3 2
 
 /* Memory layout of a per-edge table handed to / produced by gw_edge_update_forward.
  * GW_LAYOUT_ROWS_F32: row-major fp32 rows (the reference's layout, graph_net_block.py:279-301 carries [E, D] tensors).
@@ -111,6 +119,10 @@ int gw_pack_linear(const float* w, int n_out, int k_total, int k_lo, int k_hi, f
 /* bf16 form of the packed stream (byte size / packing); same arguments, out receives gw_packed_bytes_bf16() bytes. */
 size_t gw_packed_bytes_bf16(int n_out, int k_lo, int k_hi);
 int gw_pack_linear_bf16(const float* w, int n_out, int k_total, int k_lo, int k_hi, void* out, void* stream);
+/* (v16) split form (GW_DTYPE_BF16X3): per 32-wide K-step the bf16 hi fragments of all row tiles, then their lo fragments;
+ * out receives gw_packed_bytes_bf16x3() bytes (twice the bf16 stream). */
+size_t gw_packed_bytes_bf16x3(int n_out, int k_lo, int k_hi);
+int gw_pack_linear_bf16x3(const float* w, int n_out, int k_total, int k_lo, int k_hi, void* out, void* stream);
 /* Zero-pad a vector (bias / LayerNorm gamma, beta) to a multiple of 32 floats. out has gw_padded_n(n). */
 int gw_padded_n(int n);
 int gw_pad_vector(const float* v, int n, float* out, void* stream);
@@ -132,7 +144,7 @@ typedef struct gw_pack_item {
   int32_t rows;        /* rows of the packed stream, >= n_out (0 = n_out): an output head with n_out < 80 features is packed as
                           80 rows, the tile count its kernel variant walks; rows n_out.. are zero */
   int32_t reserved;
-  void* out;           /* gw_packed_floats(rows, 0, kseg) floats, or gw_packed_bytes_bf16(rows, 0, kseg) bytes */
+  void* out;           /* gw_packed_floats(rows, 0, kseg) floats, or gw_packed_bytes_bf16 / _bf16x3(rows, 0, kseg) bytes */
 } gw_pack_item;
 typedef struct gw_pad_item {
   const float* v;      /* device pointer, n floats */
@@ -172,11 +184,12 @@ typedef struct gw_mlp_weights {
   int32_t hidden;      /* 128 or 256 */
   int32_t n_mid;       /* hidden_layers - 1 */
   int32_t n_out;       /* 256, or <= 80 for the decoder head */
-  int32_t weight_dtype; /* GW_DTYPE_F32: streams from gw_pack_linear; GW_DTYPE_BF16: streams from gw_pack_linear_bf16 */
+  int32_t weight_dtype; /* GW_DTYPE_F32: streams from gw_pack_linear; GW_DTYPE_BF16: gw_pack_linear_bf16; GW_DTYPE_BF16X3: gw_pack_linear_bf16x3 */
   int32_t ln_width;    /* features LayerNorm normalises over; 0 = n_out.  Narrower models (node/edge width < 256,
                           graph_net_block.py:234-244 defaults to 128) run zero-padded to 256: their statistics then span
                           the first ln_width features only (fp32 weights) */
-  int32_t k_in;        /* (v15) input features the layer-1 slices were packed for, summed over the operands; 0 = not recorded.
+  int32_t k_in;        /* (v15) input features the layer-1 slices were packed for, summed over the operands; 0 = not recorded (MANDATORY - as is
+                          out_rows - for the `head` argument of gw_node_update_head_forward, which rejects a zeroed struct).
                           Entry points that stream a FIXED number of K-steps from w1 (gw_node_update_head_forward: the
                           head's 256 inputs) refuse anything else instead of reading past the packed buffer */
   int32_t out_rows;    /* (v15) rows w_out / b_out were packed with (gw_pack_linear rows > n_out: zero rows of an output
@@ -198,7 +211,7 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
  * post_out[s][c] = y[c] . post_w[s]^T (rows of 256; post_layout GW_LAYOUT_ROWS_F32 / _F16) - Encoder.node_encoder on the grid
  * rows (encoder.py:205) followed by the x[row] slice of the encoder block's edge MLP layer 1 (graph_net_block.py:131-134: one
  * edge per grid node, so the product costs what the raw operand would cost inside the edge kernel).  out may be NULL when only
- * the products are wanted (the encoder drops the grid rows, encoder.py:219-223).  bf16 weights, hidden 256, 256 outputs with
+ * the products are wanted (the encoder drops the grid rows, encoder.py:219-223).  bf16 / bf16x3 weights, hidden 256, 256 outputs with
  * LayerNorm, 33..128 input features. */
 int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_mlp_weights* w,
                         float* out /* may be NULL */, int32_t out_ld, int32_t n_post, const float* const* post_w,
@@ -237,7 +250,7 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
  * raw rows, pre-projected rows (operand.projected) or zeros (k == 0); e_res is the raw edge feature row (the residual of
  * graph_net_block.py:135) - or k == 0 for "none": a caller that wants only the aggregate of batch-shared edge features (the
  * decoder, assimilator_decoder.py:195 drops e') may add their per-destination sums into agg beforehand instead,
- * sum(LN(.) + e) = sum(LN(.)) + sum(e)  (bf16 weights with resident kernels, e_out == NULL, no save, atomics mode). */
+ * sum(LN(.) + e) = sum(LN(.)) + sum(e)  (bf16 weights with resident kernels in atomics mode, or bf16x3 weights; e_out == NULL, no save). */
 int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, const int32_t* dst,
                            const gw_operand* x_src, const gw_operand* x_dst, const gw_operand* e_in,
                            const gw_operand* e_res, const gw_mlp_weights* w,
@@ -278,7 +291,7 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
  * (graph_net_block.py:293-301) needs no projection launch between blocks.  zero_rows: [n_rows, 256] filled with zeros on the
  * side (the next block's aggregate buffer).  Inference only (save must be NULL), out_ld 256. */
 
-/* ---- NodeProcessor.forward followed by the output head, one launch (bf16 weights) -------------------------------------
+/* ---- NodeProcessor.forward followed by the output head, one launch (bf16 or bf16x3 weights) ---------------------------
  * AssimilatorDecoder.forward after its edge update (assimilator_decoder.py:195-200) + the Decoder residual (decoder.py:93):
  *   x_new[j] = LN(MLP_node(cat[x[j], agg[j]]))            (graph_net_block.py:189-191; the decoder's rows are zeros: no x_res)
  *   out[j, :n] = MLP_head(x_new[j]) + residual[j, :n]     (node_decoder 256 -> 128 -> 128 -> n <= 80 features, no norm)

@@ -329,6 +329,14 @@ def test_bench_self_launch_from_a_clean_environment(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 4  # c2: batch 2 on each of the two ranks
+    # what a SCALE record can check: the process group really had 2 ranks, each reported its own clock, value uses the slowest
+    assert d["dist_world_size"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) <= 1e-6 * d["ms_per_step"]
+    # the stand-in hooks are refused on anything but the CPU device (a stand-in model must never print the driver's GPU line)
+    env_gpu = dict(env)
+    env_gpu.pop("GW_BENCH_DEVICE")
+    r = subprocess.run(cmd, cwd=root, env=env_gpu, capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0 and "GW_BENCH_DEVICE=cpu" in (r.stderr + r.stdout)
     # a failing rank makes the launcher exit non-zero (bad factory -> every rank raises)
     env["GW_BENCH_FACTORY"] = "tests.test_sharding:_failing_factory"
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
