@@ -15,6 +15,14 @@
 // is the next layer's B operand).  The packed stream carries, per 32-wide K-step, the hi fragments of all row tiles followed by
 // their lo fragments (gw_pack_linear_bf16x3); activations are split in registers when a layer's output becomes the next layer's
 // input.  A wave reads two fragments (hi, lo) from LDS per three MFMAs; the 4-byte-per-weight stream is the fp32 kernels' volume.
+//
+// Measured (1 degree, profiles/r05_*): 5.3 x the matrix rate buys 2.0 x the fp32 forward (555 vs 278 forecasts/s at batch 2): a
+// 256 x 256 layer pass of a 64-column workgroup is 6.4 k cycles of MFMAs per wave but takes ~21 k - the same with the weight
+// chunks moved by LDS-DMA (all pieces up front / spread between the MFMA units / over the first half of a chunk) or through
+// registers (global_load_dwordx4 + ds_write_b128), with 64 or 128 columns per weight stream, 32 or 64 KiB chunks, a 3- or 5-deep
+// fragment ring.  What does not move it either way is what a pass is made of: 8 chunk hand-overs (DMA landing + barrier: ~25 % of
+// the pass), 256 KiB of fragment reads per wave (LDS array 25-40 % busy) and an MFMA pipe shared by two waves (33-43 % busy over the
+// kernel, SQ_VALU_MFMA_BUSY_CYCLES).  DESIGN.md "bf16x3" lists the experiments.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,20 +37,33 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kBufBytes = 32768;            // one weight chunk buffer: one K-step of 16 row tiles (hi + lo)
+// phase clocks (tuning builds only: gw_debug_timestamps + scripts/gpu_timeline_x3.py); nothing in the product build
+#ifdef GW_TUNING
+#define X3_STAMP(i) \
+  if (a.dbg != nullptr) { ts[i] = gw::gw_clock(); }
+#else
+#define X3_STAMP(i)
+#endif
+
+// One weight chunk buffer (double buffered): 32 KiB = one K-step of 16 row tiles (hi + lo) for the 4-wave workgroups (two per
+// CU), 64 KiB = two K-steps for the 8-wave workgroup (one per CU: half the chunk hand-overs per layer)
+constexpr int buf_bytes(int nw) { return nw == 8 ? 65536 : 32768; }
 constexpr int kStageLd = 260;
 constexpr int kStageFloats = 64 * kStageLd;
-constexpr int kLdsWeights = 2 * kBufBytes;  // double buffered
-// the segment-sum stage of the edge epilogue lies OVER the weight buffers (nothing streams any more by then): two 64-column
-// workgroups per CU fit the 160 KiB
-constexpr int kLdsEdge = (kStageFloats + 64) * 4 > kLdsWeights ? (kStageFloats + 64) * 4 : kLdsWeights;
+// LDS of a launch: the two weight buffers; the segment-sum stage of the edge epilogue (64 columns x 260 floats + 64 destination
+// ids per 4 waves) lies OVER them (nothing streams any more by then), so two 64-column workgroups per CU fit the 160 KiB
+constexpr int lds_bytes(int nw, bool edge) {
+  const int w = 2 * buf_bytes(nw), st = (nw / 4) * (kStageFloats + 64) * 4;
+  return edge && st > w ? st : w;
+}
+constexpr int kLdsMax = 160 * 1024;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // DMA `bytes` (multiple of 1 KiB) of the packed weight stream into LDS at byte offset lds_off; pieces round-robin over the waves.
 template <int NW>
 __device__ __forceinline__ void issue_bytes(const char* __restrict__ g, int bytes, unsigned lds_off, int lane, int wave) {
@@ -71,29 +92,57 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // One layer pass: acc[g][t] += W[16t.., k] . x[g][k] on split operands, K = 32 KS, NT row tiles, NTP = tiles per K-step in the
 // packed stream (NT rounded up to 4).  The stream of this pass starts at gw; its first chunk has already been issued into buffer
 // `parity`; while the last chunk computes, the first chunk of the next pass (next_gw, next_bytes) is issued.
-template <int NW, int NG, int KS, int BKS, int NT, int NTP>
+// The DMA pieces of chunk c + 1 are issued one at a time between the MFMA units of chunk c.  (Measured alternatives, same time
+// per pass within 10 %: all pieces up front; chunks through registers - global_load_dwordx4 + ds_write_b128 - instead of LDS-DMA:
+// DESIGN.md "bf16x3".)  RING = register sets the A fragments travel through: a unit's fragments are requested RING - 1 units
+// ahead of its MFMAs.
+template <int NW, int NG, int KS, int BKS, int NT, int NTP, int RING>
 __device__ __forceinline__ void pass_x3(f32x4 (&acc)[NG][NT], const bf16x8 (&bh)[NG][BKS], const bf16x8 (&bl)[NG][BKS],
                                         const char* __restrict__ gw, const char* __restrict__ next_gw, int next_bytes, const char* lds,
-                                        int& parity, int lane, int wave) {
+                                        int& parity, int lane, int wave, unsigned long long* waited = nullptr) {
+  constexpr int kBufBytes = buf_bytes(NW);
   constexpr int STEP_BYTES = 2 * NTP * 1024;  // hi fragments of the NTP tiles, then their lo fragments
-  constexpr int CS = (2 * STEP_BYTES <= kBufBytes) ? 2 : 1;  // K-steps per chunk
+  constexpr int CS = kBufBytes / STEP_BYTES;  // K-steps per chunk
   constexpr int NCH = (KS + CS - 1) / CS;
   constexpr int UPS = NTP / 2;  // units per K-step: a unit = 2 row tiles = 4 ds_read_b128 (hi, hi, lo, lo) -> 6 NG MFMAs
+  constexpr int PPW = (CS * STEP_BYTES / 1024 + NW - 1) / NW;  // DMA pieces per wave and full chunk
+  constexpr int UNITS = CS * UPS;
+  constexpr int AHEAD = RING - 1;
+  static_assert(PPW <= UNITS, "at most two DMA pieces per unit");
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int steps_c = (KS - c * CS) < CS ? (KS - c * CS) : CS;
+#ifdef GW_TUNING
+    unsigned long long t0w = 0, t1w = 0;
+    if (waited != nullptr) t0w = gw::gw_clock();
+#endif
     wait_vm<0>();
+#ifdef GW_TUNING
+    if (waited != nullptr) t1w = gw::gw_clock();
+#endif
     lds_barrier();  // chunk c has landed for every wave; nobody still reads the other buffer
+#ifdef GW_TUNING
+    if (waited != nullptr) {
+      const unsigned long long t2w = gw::gw_clock();
+      waited[0] += t1w - t0w;  // own DMA pieces landing
+      waited[1] += t2w - t1w;  // LDS drain + barrier
+    }
+#endif
+    // what goes into the other buffer while this chunk computes
+    const char* nsrc = nullptr;
+    int npieces = 0;
     if (c + 1 < NCH) {
       const int sn = (KS - (c + 1) * CS) < CS ? (KS - (c + 1) * CS) : CS;
-      issue_bytes<NW>(gw + (size_t)(c + 1) * CS * STEP_BYTES, sn * STEP_BYTES, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+      nsrc = gw + (size_t)(c + 1) * CS * STEP_BYTES;
+      npieces = sn * STEP_BYTES / 1024;
     } else if (next_gw != nullptr) {
-      issue_bytes<NW>(next_gw, next_bytes, (unsigned)((parity ^ 1) * kBufBytes), lane, wave);
+      nsrc = next_gw;
+      npieces = next_bytes >> 10;
     }
+    const unsigned nlds = (unsigned)((parity ^ 1) * kBufBytes);
     const char* buf = lds + parity * kBufBytes + lane * 16;
-    // fragments travel through a ring of three register sets, requested two units ahead of the MFMAs that use them
     const int NU = steps_c * UPS;
-    bf16x8 af[3][4];
+    bf16x8 af[RING][4];
     auto ldu = [&](bf16x8 (&f)[4], int u) {
       const int su = u / UPS, t2 = u - su * UPS;
       const char* p = buf + su * STEP_BYTES + (2 * t2) * 1024;
@@ -102,13 +151,15 @@ __device__ __forceinline__ void pass_x3(f32x4 (&acc)[NG][NT], const bf16x8 (&bh)
       f[2] = *(const bf16x8*)(p + NTP * 1024);
       f[3] = *(const bf16x8*)(p + NTP * 1024 + 1024);
     };
-    ldu(af[0], 0);
-    if (NU > 1) ldu(af[1], 1);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < CS * UPS; ++u) {
+    for (int u = 0; u < AHEAD; ++u)
+      if (u < NU) ldu(af[u], u);
+    __builtin_amdgcn_sched_barrier(0);
+    int issued = 0;  // pieces of this wave issued so far (compile-time after unrolling)
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
       if (u < NU) {
-        if (u + 2 < NU) ldu(af[(u + 2) % 3], u + 2);
+        if (u + AHEAD < NU) ldu(af[(u + AHEAD) % RING], u + AHEAD);
         const int su = u / UPS, t2 = u - su * UPS;
         const int ks = c * CS + su;
         // term-major: two MFMAs (x NG) lie between two that accumulate into the same registers
@@ -119,15 +170,36 @@ __device__ __forceinline__ void pass_x3(f32x4 (&acc)[NG][NT], const bf16x8 (&bh)
             if (2 * t2 + tt < NT) {
 #pragma unroll
               for (int g = 0; g < NG; ++g) {
-                const bf16x8 wa = af[u % 3][term == 2 ? 2 + tt : tt];
+                const bf16x8 wa = af[u % RING][term == 2 ? 2 + tt : tt];
                 const bf16x8 xb = term == 1 ? bl[g][ks] : bh[g][ks];
                 acc[g][2 * t2 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[g][2 * t2 + tt], 0, 0, 0);
               }
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      // this unit's share of the next chunk's DMA (pieces wave, wave + NW, ...): spread evenly over the units that exist
+      {
+        // (over the FIRST HALF of the chunk's units: the last piece then has half a chunk of MFMAs to land - issued over all units,
+        // a wave waited ~1 k cycles per chunk for its own last pieces: profiles/r05_x3_timeline.log)
+        const int span = (NU < UNITS ? NU : UNITS) / 2 > 0 ? (NU < UNITS ? NU : UNITS) / 2 : 1;
+        const int due = ((u + 1) * PPW + span - 1) / span;  // pieces due after unit u
+        const int due_c = u + 1 >= span ? PPW : (due < PPW ? due : PPW);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+          if (i >= issued && i < due_c) {
+            const int pc = wave + i * NW;
+            // inside a pass the piece count is a compile-time multiple of NW (no branch); only the hand-over to the next pass
+            // (which may not exist) tests a wave-uniform condition
+            const bool go = (c + 1 < NCH) ? (i * NW < npieces) : (pc < npieces);
+            if (go)
+              glds16_asm_s((const float*)(nsrc + (size_t)pc * 1024), (unsigned)lane * 16u,
+                           __builtin_amdgcn_readfirstlane(nlds + (unsigned)pc * 1024u));
+          }
+        }
+        issued = due_c > issued ? due_c : issued;
+      }
+      if (u < NU) __builtin_amdgcn_sched_barrier(0);
     }
     parity ^= 1;
   }
@@ -196,20 +268,29 @@ __device__ __forceinline__ const float* operand_row(const float* ptr, const int*
 }
 
 // K1S: 32-wide K-steps of a raw layer-1 operand (8: k = 256, 4: k <= 128, 1: k <= 32); HT / OT: hidden / output row tiles.
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST, bool HEAD, int NW, int NG>
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST, bool HEAD, int NW, int NG, int RING = 3>
 __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kernel(const ChainArgs a) {
   constexpr int kCols = NW * NG * 16;  // columns per workgroup
-  static_assert(EPI != EPI_EDGE || NW == 4, "the segment-sum epilogue walks 64 columns per round on 4 waves");
+  static_assert(EPI != EPI_EDGE || NW == 4 || NW == 8, "the segment-sum epilogue walks 64 columns per round and 4 waves");
   extern __shared__ __attribute__((aligned(16))) char ldsx[];
   constexpr int HTP = (HT + 3) / 4 * 4, OTP = (OT + 3) / 4 * 4;
   constexpr int HKS = HT / 2;  // K-steps of a layer fed by the hidden activations
+  constexpr int kBufBytes = buf_bytes(NW);
   constexpr int H_STEP = 2 * HTP * 1024, O_STEP = 2 * OTP * 1024;
-  constexpr int H_CS = (2 * H_STEP <= kBufBytes) ? 2 : 1, O_CS = (2 * O_STEP <= kBufBytes) ? 2 : 1;
+  constexpr int H_CS = kBufBytes / H_STEP, O_CS = kBufBytes / O_STEP;  // K-steps per chunk
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
   const int q = lane >> 4;
   const int tile_c0 = blockIdx.x * kCols;
+#ifdef GW_TUNING
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long waited[2] = {0, 0};
+#define X3_WAITED (a.dbg != nullptr ? waited : nullptr)
+#else
+#define X3_WAITED nullptr
+#endif
+  X3_STAMP(0)
 
   int cc[NG], bb[NG], kk[NG];
   bool valid[NG];
@@ -235,13 +316,16 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
   constexpr int K1_CS = H_CS;
   constexpr int K1FIRST = (K1S < K1_CS ? K1S : K1_CS) * H_STEP;
   const char* after_l1 = SINGLE ? nullptr : (a.n_mid > 0 ? w_mid : w_out);
-  const int after_l1_bytes = SINGLE ? 0 : (a.n_mid > 0 ? H_CS * H_STEP : O_CS * O_STEP);
+  constexpr int MID_FIRST = (HKS < H_CS ? HKS : H_CS) * H_STEP, OUT_FIRST = (HKS < O_CS ? HKS : O_CS) * O_STEP;  // first chunks
+  const int after_l1_bytes = SINGLE ? 0 : (a.n_mid > 0 ? MID_FIRST : OUT_FIRST);
   int parity = 0;
   {
     const char* first = on[0] ? w1[0] : (on[1] ? w1[1] : (on[2] ? w1[2] : after_l1));
     const int first_bytes = (on[0] || on[1] || on[2]) ? K1FIRST : after_l1_bytes;
     issue_bytes<NW>(first, first_bytes, 0u, lane, wave);
   }
+  // (first-chunk sizes are whole staging groups of pass_x3: half a chunk buffer)
+  static_assert(K1FIRST % (kBufBytes / 2) == 0 && MID_FIRST % (kBufBytes / 2) == 0 && OUT_FIRST % (kBufBytes / 2) == 0, "first chunks");
 
   // ---- layer 1 ----
   constexpr int BKS = K1S > HKS ? K1S : HKS;
@@ -250,6 +334,65 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
   bf16x8 bh[NG][BKS], bl[NG][BKS];
   init_bias<NG, HT>(acc, a.b1, q);
   {
+    // Projected operands (rows already multiplied by their layer-1 slice: gather-adds).  The first two of them are fetched with
+    // ALL their row pieces in flight at once (2 x 16 loads of 16 bytes per lane and group) - summed one operand after the other
+    // in batches of 8 the gathers were four serial memory round trips, 14 k of a decoder tile's 67 k cycles.
+    int ia = -1, ib = -1, ic = -1;
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i)
+      if (prj[i]) {
+        if (ia < 0) ia = i;
+        else if (ib < 0) ib = i;
+        else ic = i;
+      }
+    auto prow = [&](int i, int g) -> const float* {
+      const float* ptr = i == 0 ? a.seg_ptr[0] : (i == 1 ? a.seg_ptr[1] : a.seg_ptr[2]);
+      const int* idx = i == 0 ? a.seg_idx[0] : (i == 1 ? a.seg_idx[1] : a.seg_idx[2]);
+      const int rpb = i == 0 ? a.seg_rows_pb[0] : (i == 1 ? a.seg_rows_pb[1] : a.seg_rows_pb[2]);
+      const int ld = i == 0 ? a.seg_ld[0] : (i == 1 ? a.seg_ld[1] : a.seg_ld[2]);
+      return operand_row(ptr, idx, rpb, ld, bb[g], kk[g]);
+    };
+    if (ia >= 0) {
+      f32x4 pa[NG][HT], pb[NG][HT];
+      const bool two = ib >= 0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float* ra = prow(ia, g);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) pa[g][t] = ldg4(ra + 16 * t + 4 * q);
+      }
+      if (two) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float* rb = prow(ib, g);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) pb[g][t] = ldg4(rb + 16 * t + 4 * q);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[g][t] += pa[g][t];
+      if (two) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) acc[g][t] += pb[g][t];
+      }
+    }
+    if (ic >= 0) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float* row = prow(ic, g);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          acc[g][t] += ldg4(row + 16 * t + 4 * q);
+          if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // raw operands: one matrix pass each
 #pragma unroll
     for (int i = 0; i < NSEG; ++i) {
       if (on[i]) {
@@ -268,21 +411,17 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
             nx = w1[i2];
             nb = K1FIRST;
           }
-        pass_x3<NW, NG, K1S, BKS, HT, HTP>(acc, bh, bl, w1[i], nx, nb, ldsx, parity, lane, wave);
-      } else if (prj[i]) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const float* row = operand_row(a.seg_ptr[i], a.seg_idx[i], a.seg_rows_pb[i], a.seg_ld[i], bb[g], kk[g]);
-#pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            acc[g][t] += ldg4(row + 16 * t + 4 * q);
-            if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+        pass_x3<NW, NG, K1S, BKS, HT, HTP, RING>(acc, bh, bl, w1[i], nx, nb, ldsx, parity, lane, wave);
       }
     }
   }
 
+  X3_STAMP(1)
+  constexpr int HS = 2 * 8 * 1024;  // bytes of one K-step of a packed head slice (<= 8 row tiles, hi + lo)
+  constexpr int HD_CS = kBufBytes / HS;
+  constexpr int POST_FIRST = (8 < H_CS ? 8 : H_CS) * H_STEP;                            // products: K = 256, HT row tiles
+  constexpr int HD1_FIRST = (8 < HD_CS ? 8 : HD_CS) * HS, HD2_FIRST = (4 < HD_CS ? 4 : HD_CS) * HS;  // head: K = 256, then K = 128 twice
+  static_assert(POST_FIRST % (kBufBytes / 2) == 0 && HD1_FIRST % (kBufBytes / 2) == 0 && HD2_FIRST % (kBufBytes / 2) == 0, "first chunks");
   f32x4 o_sep[SHARE_ACC ? 1 : NG][SHARE_ACC ? 1 : OT];
   f32x4 (&o)[NG][OT] = *reinterpret_cast<f32x4(*)[NG][OT]>(SHARE_ACC ? (void*)acc : (void*)o_sep);
   if constexpr (!SINGLE) {
@@ -296,19 +435,21 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
       init_bias<NG, HT>(acc, a.b_mid + l * (HT * 16), q);
       const bool last = (l + 1 == a.n_mid);
       const char* nx = last ? w_out : w_mid + (size_t)(l + 1) * HKS * H_STEP;
-      const int nb = last ? O_CS * O_STEP : H_CS * H_STEP;
-      pass_x3<NW, NG, HKS, BKS, HT, HTP>(acc, bh, bl, w_mid + (size_t)l * HKS * H_STEP, nx, nb, ldsx, parity, lane, wave);
+      const int nb = last ? OUT_FIRST : MID_FIRST;
+      pass_x3<NW, NG, HKS, BKS, HT, HTP, RING>(acc, bh, bl, w_mid + (size_t)l * HKS * H_STEP, nx, nb, ldsx, parity, lane, wave, X3_WAITED);
     }
+    X3_STAMP(2)
     // ---- output layer ----
 #pragma unroll
     for (int g = 0; g < NG; ++g)
       acc_to_b<HT, true>(reinterpret_cast<bf16x8(&)[HKS]>(bh[g]), reinterpret_cast<bf16x8(&)[HKS]>(bl[g]), acc[g]);
     __builtin_amdgcn_sched_barrier(0);
     init_bias<NG, OT>(o, a.b_out, q);
-    pass_x3<NW, NG, HKS, BKS, OT, OTP>(o, bh, bl, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
-                                       POST ? H_CS * H_STEP : (HEAD ? 2 * (2 * 8 * 1024) : 0), ldsx, parity, lane, wave);
+    pass_x3<NW, NG, HKS, BKS, OT, OTP, RING>(o, bh, bl, w_out, POST ? (const char*)a.proj_w[0] : (HEAD ? (const char*)a.hd_w1 : nullptr),
+                                       POST ? POST_FIRST : (HEAD ? HD1_FIRST : 0), ldsx, parity, lane, wave, X3_WAITED);
   }
 
+  X3_STAMP(3)
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
   if (!SINGLE && a.gamma != nullptr) {
     constexpr float inv_n = 1.0f / (OT * 16);
@@ -386,6 +527,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     }
   }
 
+  X3_STAMP(4)
   // ---- HEAD: the output head on the new rows while they are still in registers (ChainArgs): 256 -> 128 relu -> 128 relu ->
   // <= 80 features (+ residual rows): AssimilatorDecoder.node_decoder + the Decoder residual (assimilator_decoder.py:197,
   // decoder.py:93) behind the decoder's node update; the [rows, 256] table between them is never written or read ----
@@ -394,21 +536,20 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc_to_b<16, false>(reinterpret_cast<bf16x8(&)[8]>(bh[g]), reinterpret_cast<bf16x8(&)[8]>(bl[g]), o[g]);
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int HS = 2 * 8 * 1024;  // bytes of one K-step of a packed slice with <= 8 row tiles (hi + lo)
     f32x4 hh[NG][8];
     init_bias<NG, 8>(hh, a.hd_b1, q);
-    pass_x3<NW, NG, 8, BKS, 8, 8>(hh, bh, bl, (const char*)a.hd_w1, (const char*)a.hd_w2, 2 * HS, ldsx, parity, lane, wave);
+    pass_x3<NW, NG, 8, BKS, 8, 8, RING>(hh, bh, bl, (const char*)a.hd_w1, (const char*)a.hd_w2, HD2_FIRST, ldsx, parity, lane, wave);
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc_to_b<8, true>(reinterpret_cast<bf16x8(&)[4]>(bh[g]), reinterpret_cast<bf16x8(&)[4]>(bl[g]), hh[g]);
     __builtin_amdgcn_sched_barrier(0);
     init_bias<NG, 8>(hh, a.hd_b2, q);
-    pass_x3<NW, NG, 4, BKS, 8, 8>(hh, bh, bl, (const char*)a.hd_w2, (const char*)a.hd_w3, 2 * HS, ldsx, parity, lane, wave);
+    pass_x3<NW, NG, 4, BKS, 8, 8, RING>(hh, bh, bl, (const char*)a.hd_w2, (const char*)a.hd_w3, HD2_FIRST, ldsx, parity, lane, wave);
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc_to_b<8, true>(reinterpret_cast<bf16x8(&)[4]>(bh[g]), reinterpret_cast<bf16x8(&)[4]>(bl[g]), hh[g]);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 y[NG][5];
     init_bias<NG, 5>(y, a.hd_b3, q);
-    pass_x3<NW, NG, 4, BKS, 5, 8>(y, bh, bl, (const char*)a.hd_w3, nullptr, 0, ldsx, parity, lane, wave);
+    pass_x3<NW, NG, 4, BKS, 5, 8, RING>(y, bh, bl, (const char*)a.hd_w3, nullptr, 0, ldsx, parity, lane, wave);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (valid[g]) {
@@ -455,7 +596,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     for (int sl = 0; sl < a.n_post; ++sl) {
       init_bias<NG, HT>(acc, nullptr, q);  // (acc aliases o: the new rows have been stored and split into bh / bl)
       const char* nx = sl + 1 < a.n_post ? (const char*)a.proj_w[sl + 1] : nullptr;
-      pass_x3<NW, NG, 8, BKS, HT, HTP>(acc, bh, bl, (const char*)a.proj_w[sl], nx, H_CS * H_STEP, ldsx, parity, lane, wave);
+      pass_x3<NW, NG, 8, BKS, HT, HTP, RING>(acc, bh, bl, (const char*)a.proj_w[sl], nx, POST_FIRST, ldsx, parity, lane, wave);
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         if (valid[g]) {
@@ -466,25 +607,28 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     }
   }
 
+  X3_STAMP(5)
   // ---- segment sum over destination-sorted columns, 64 columns at a time through LDS (see gw_edge.hip) ----
   if (EPI == EPI_EDGE) {
-    float* stage = (float*)ldsx;  // over the weight buffers: every pass of this workgroup is complete (barrier below)
+    // every 4 waves (256 threads = 256 features) own one 64-column chunk of the round: stage + destination ids per chunk
+    const int half = threadIdx.x >> 8;  // chunk of this thread's wave within the round (0 for 4-wave workgroups)
+    float* stage = (float*)ldsx + half * (kStageFloats + 64);  // over the weight buffers: every pass of this workgroup is complete
     int* gdl = (int*)(stage + kStageFloats);
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
       __syncthreads();  // the last pass's fragment reads / the previous round's readers are done
       {
-        float* srow = stage + (wave * 16 + j) * kStageLd + 4 * q;
+        float* srow = stage + ((wave & 3) * 16 + j) * kStageLd + 4 * q;
 #pragma unroll
         for (int g2 = 0; g2 < NG; ++g2)
           if (g2 == g) {
 #pragma unroll
             for (int t = 0; t < OT; ++t) *(f32x4*)(srow + 16 * t) = o[g2][t];
-            if (q == 0) gdl[wave * 16 + j] = valid[g2] ? bb[g2] * a.agg_rows_pb + ldgi(a.agg_idx + kk[g2]) : -1;
+            if (q == 0) gdl[(wave & 3) * 16 + j] = valid[g2] ? bb[g2] * a.agg_rows_pb + ldgi(a.agg_idx + kk[g2]) : -1;
           }
       }
       __syncthreads();
-      const int f = threadIdx.x;
+      const int f = threadIdx.x & 255;
       float vv[64];
 #pragma unroll
       for (int i = 0; i < 64; ++i) vv[i] = stage[i * kStageLd + f];
@@ -495,7 +639,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
       bool open_lo = true, open_hi = true;
       float* rec = nullptr;
       if (a.carry != nullptr) {
-        const int chunk_c0 = tile_c0 + g * 64;
+        const int chunk_c0 = tile_c0 + g * (NW * 16) + half * 64;
         rec = a.carry + (size_t)(chunk_c0 >> 6) * kCarryFloats;
         const int c_prev = chunk_c0 - 1, c_next = chunk_c0 + 64;
         int gd_prev = -2, gd_next = -2;
@@ -550,6 +694,21 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
       }
     }
   }
+#ifdef GW_TUNING
+  if (a.dbg != nullptr) {
+    ts[6] = gw::gw_clock();
+    if (threadIdx.x == 0 && (int)blockIdx.x < a.dbg_cap && blockIdx.y == 0) {
+      unsigned long long* rec = a.dbg + (size_t)blockIdx.x * 16;
+      for (int i = 0; i < 7; ++i) rec[i] = ts[i];
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      rec[8] = hw;
+      rec[10] = blockIdx.x;
+      rec[11] = waited[0];  // middle + output passes: cycles waiting for own DMA pieces
+      rec[12] = waited[1];  // ... and in the LDS drain + barrier
+    }
+  }
+#endif
 }
 
 // ---- weight packing: nn.Linear [n_out, k_total] slice -> split bf16 MFMA A-operand stream ---------------------------
@@ -574,62 +733,74 @@ __global__ void pack_linear_x3_kernel(const float* __restrict__ w, long long sf,
 }
 
 template <typename K>
-int launchx3(K kernel, ChainArgs& a, void* stream, int grid_y, int lds_bytes, int threads, int cols) {
+int launchx3(K kernel, ChainArgs& a, void* stream, int grid_y, int lds, int threads, int cols) {
   static DeviceOnce once;  // per template instantiation and device
-  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEdge);
+  if (once.first()) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
   const int grid = (a.n_cols + cols - 1) / cols;
-  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(threads), lds_bytes, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kernel, dim3(grid, grid_y), dim3(threads), lds, (hipStream_t)stream, a);
   return check_launch("chainx3_kernel launch");
 }
 
-// one (kind, form) -> instantiation.  Product build: 4 waves x 1 group (64 columns, two workgroups per CU).  Tuning builds also
-// carry form 42 = 4 x 2 (128 columns, one workgroup per CU) and 81 = 8 x 1 (128 columns share one weight stream, two waves per
-// SIMD; row-wise kinds only) behind GW_X3_FORM / GW_X3_FORM_EDGE.
+// one (kind, form) -> instantiation; form = 10 NW + NG.  Product build: 41 = 4 waves x 1 column group (64 columns, two workgroups
+// per CU).  Tuning builds also carry 42 = 4 x 2 (128 columns, one wave per SIMD), 81 = 8 x 1 (128 columns share one weight stream,
+// one workgroup per CU, 64 KiB chunks) and a 5-deep fragment ring (GW_X3_FORM / GW_X3_FORM_EDGE / GW_X3_RING): measured within
+// +-3 % of form 41 on every launch of the 1 degree forward (profiles/r05_x3_forms.log), so the product carries one form.
+constexpr int kRing = 3;  // register sets of the A-fragment ring
 template <int K1S, bool K1F, int NSEG, int HT, int OT, int EPI, bool SINGLE, bool POST, bool HEAD>
-int launch_kind(ChainArgs& a, void* stream, int gy, int lds, int form) {
+int launch_kind(ChainArgs& a, void* stream, int gy, int form) {
+  constexpr bool E = EPI == EPI_EDGE;
 #ifdef GW_TUNING
-  if (form == 42) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 2>, a, stream, gy, lds, 256, 128);
-  if constexpr (EPI != EPI_EDGE) {
-    if (form == 81) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 8, 1>, a, stream, gy, lds, 512, 128);
+  if (form == 42) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 2>, a, stream, gy, lds_bytes(4, E), 256, 128);
+  static const int ring = GW_TUNE("GW_X3_RING", kRing);
+  if (ring == 5) {
+    if (form == 81) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 8, 1, 5>, a, stream, gy, lds_bytes(8, E), 512, 128);
+    return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 1, 5>, a, stream, gy, lds_bytes(4, E), 256, 64);
   }
+  if (form == 81) return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 8, 1, kRing>, a, stream, gy, lds_bytes(8, E), 512, 128);
 #endif
   (void)form;
-  return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 1>, a, stream, gy, lds, 256, 64);
+  return launchx3(chainx3_kernel<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, 4, 1, kRing>, a, stream, gy, lds_bytes(4, E), 256, 64);
 }
-#define GW_X3(K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, GY, LDS) \
-  return launch_kind<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD>(a, stream, GY, LDS, form)
+#define GW_X3(K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD, GY) \
+  return launch_kind<K1S, K1F, NSEG, HT, OT, EPI, SINGLE, POST, HEAD>(a, stream, GY, form)
 
 }  // namespace
 
 namespace gw {
 
 int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream) {
+#ifdef GW_TUNING
+  if (g_dbg != nullptr && kind == g_dbg_kind) {  // gw_debug_timestamps: kinds 0 mlp, 1 edge, 2 node update (+ 4, 6), 3 project
+    a.dbg = g_dbg;
+    a.dbg_cap = g_dbg_cap;
+  }
+#endif
   static const int f_rows = GW_TUNE("GW_X3_FORM", 41), f_edge = GW_TUNE("GW_X3_FORM_EDGE", 41);
   const int form = kind == 1 ? f_edge : f_rows;
   switch (kind) {
     case 0:  // mlp rows
       if (hidden == 256 && n_out == 256) {
-        if (k_in <= 32) GW_X3(1, false, 1, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
-        if (k_in <= 128) GW_X3(4, false, 1, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
-        if (k_in == 256) GW_X3(8, true, 1, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
+        if (k_in <= 32) GW_X3(1, false, 1, 16, 16, EPI_ROWS, false, false, false, 1);
+        if (k_in <= 128) GW_X3(4, false, 1, 16, 16, EPI_ROWS, false, false, false, 1);
+        if (k_in == 256) GW_X3(8, true, 1, 16, 16, EPI_ROWS, false, false, false, 1);
       } else if (hidden == 256 && n_out <= 80 && k_in == 256) {
-        GW_X3(8, true, 1, 16, 5, EPI_DEC, false, false, false, 1, kLdsWeights);
+        GW_X3(8, true, 1, 16, 5, EPI_DEC, false, false, false, 1);
       } else if (hidden == 128 && n_out <= 80 && k_in == 256) {
-        GW_X3(8, true, 1, 8, 5, EPI_DEC, false, false, false, 1, kLdsWeights);
+        GW_X3(8, true, 1, 8, 5, EPI_DEC, false, false, false, 1);
       }
       return set_error(GW_E_UNSUPPORTED, "bf16x3 mlp: unsupported (hidden, n_out, k) combination");
     case 1:  // edge update
-      GW_X3(8, true, 3, 16, 16, EPI_EDGE, false, false, false, 1, kLdsEdge);
+      GW_X3(8, true, 3, 16, 16, EPI_EDGE, false, false, false, 1);
     case 2:  // node update
-      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, false, false, 1, kLdsWeights);
+      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, false, false, 1);
     case 3:  // projections (grid_y slices)
-      GW_X3(8, true, 1, 16, 16, EPI_ROWS, true, false, false, grid_y, kLdsWeights);
+      GW_X3(8, true, 1, 16, 16, EPI_ROWS, true, false, false, grid_y);
     case 4:  // node update + POST products
-      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, true, false, 1, kLdsWeights);
+      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, true, false, 1);
     case 6:  // node update + output head (decoder)
-      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, false, true, 1, kLdsWeights);
+      GW_X3(8, true, 2, 16, 16, EPI_ROWS, false, false, true, 1);
     case 5:  // mlp rows + POST products of the output rows (node encoder -> layer-1 products of the encoder's edge MLP)
-      if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32) GW_X3(4, false, 1, 16, 16, EPI_ROWS, false, true, false, 1, kLdsWeights);
+      if (hidden == 256 && n_out == 256 && k_in <= 128 && k_in > 32) GW_X3(4, false, 1, 16, 16, EPI_ROWS, false, true, false, 1);
       return set_error(GW_E_UNSUPPORTED, "bf16x3 mlp + post products: hidden 256, 256 outputs, 33..128 inputs");
   }
   return set_error(GW_E_BADARG, "chainx3_launch: bad kind");

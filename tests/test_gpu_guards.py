@@ -14,6 +14,7 @@ from graph_weather_amd.ops import Operand, PackedMLP  # noqa: E402
 
 DEV = "cuda:0"
 PAD = 1 << 16
+X3 = ops.BF16X3  # split-operand mode (csrc/gw_split.hip): the same entry points, fp32 rows everywhere
 
 
 class Guards:
@@ -82,7 +83,7 @@ def _both(fn):
         _same(plain[k], v.float().cpu(), k, 2e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3])
 @pytest.mark.parametrize("rows,in_dim,hidden,out,norm", [(1000, 102, 256, 256, True), (77, 78, 256, 256, True), (1, 256, 256, 256, True),
                                                         (1000, 256, 128, 78, False), (130, 31, 256, 256, True), (453, 2, 256, 256, True),
                                                         (129, 256, 256, 256, False)])
@@ -112,7 +113,7 @@ def _graph(rs, n_src, n_dst, E):
 
 
 @pytest.mark.parametrize("deterministic", [False, True])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3])
 @pytest.mark.parametrize("B,n_src,n_dst,E", [(2, 50, 40, 333), (1, 7, 5, 64), (3, 9, 4, 5), (2, 30, 30, 129)])
 def test_edge_update_raw_operands_stays_inside_its_buffers(dtype, deterministic, B, n_src, n_dst, E):
     """General kernels (encoder form): gathered raw node rows, raw per-sample edge rows."""
@@ -142,7 +143,7 @@ def test_edge_update_raw_operands_stays_inside_its_buffers(dtype, deterministic,
 
 
 @pytest.mark.parametrize("deterministic", [False, True])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3])
 @pytest.mark.parametrize("B,n_src,n_dst,E,use_dst,want_e", [(2, 50, 40, 333, True, True), (1, 7, 5, 64, False, False),
                                                             (3, 9, 4, 5, True, True), (16, 20, 30, 1000, False, False)])
 def test_edge_update_projected_operands_stays_inside_its_buffers(dtype, deterministic, B, n_src, n_dst, E, use_dst, want_e):
@@ -213,7 +214,7 @@ def test_rows_to_tiles_stays_inside_its_buffers():
         _both(run)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3])
 @pytest.mark.parametrize("rows,B,n_post", [(1000, 2, 3), (77, 1, 2), (5882, 1, 0), (130, 2, 1)])
 def test_node_update_with_post_products_stays_inside_its_buffers(dtype, rows, B, n_post):
     rs = np.random.RandomState(rows)
@@ -230,7 +231,10 @@ def test_node_update_with_post_products_stays_inside_its_buffers(dtype, rows, B,
         pw = []
         for w in post:  # packed [256, 256] slices of the next block's layer 1
             wd = w.to(DEV)
-            if dtype == torch.bfloat16:
+            if dtype == X3:
+                buf = torch.empty(L.gw_packed_bytes_bf16x3(256, 0, 256) // 2, dtype=torch.int16, device=DEV)
+                ops._lib.check(L.gw_pack_linear_bf16x3(wd.data_ptr(), 256, 256, 0, 256, buf.data_ptr(), st), "pack")
+            elif dtype == torch.bfloat16:
                 buf = torch.empty(L.gw_packed_bytes_bf16(256, 0, 256) // 2, dtype=torch.bfloat16, device=DEV)
                 ops._lib.check(L.gw_pack_linear_bf16(wd.data_ptr(), 256, 256, 0, 256, buf.data_ptr(), st), "pack")
             else:
@@ -252,12 +256,17 @@ def test_node_update_with_post_products_stays_inside_its_buffers(dtype, rows, B,
     _both(run)
 
 
-def _pack_bf16(w):
+def _pack_bf16(w, dtype=torch.bfloat16):
     L = ops._lib.lib()
     wd = w.to(DEV).contiguous()
-    buf = torch.empty(L.gw_packed_bytes_bf16(int(wd.shape[0]), 0, int(wd.shape[1])) // 2, dtype=torch.bfloat16, device=DEV)
-    ops._lib.check(L.gw_pack_linear_bf16(wd.data_ptr(), int(wd.shape[0]), int(wd.shape[1]), 0, int(wd.shape[1]), buf.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream), "pack")
+    n, k = int(wd.shape[0]), int(wd.shape[1])
+    st = torch.cuda.current_stream().cuda_stream
+    if dtype == X3:
+        buf = torch.empty(L.gw_packed_bytes_bf16x3(n, 0, k) // 2, dtype=torch.int16, device=DEV)
+        ops._lib.check(L.gw_pack_linear_bf16x3(wd.data_ptr(), n, k, 0, k, buf.data_ptr(), st), "pack")
+        return buf
+    buf = torch.empty(L.gw_packed_bytes_bf16(n, 0, k) // 2, dtype=torch.bfloat16, device=DEV)
+    ops._lib.check(L.gw_pack_linear_bf16(wd.data_ptr(), n, k, 0, k, buf.data_ptr(), st), "pack")
     return buf
 
 
@@ -284,19 +293,19 @@ def test_team_edge_update_without_residual_stays_inside_its_buffers(half, B, n_s
     _both(run)
 
 
-@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("half,dtype", [(False, torch.bfloat16), (True, torch.bfloat16), (False, X3)])
 @pytest.mark.parametrize("rows,B,in_dim,want_out", [(1000, 2, 102, False), (77, 1, 78, True), (333, 3, 128, False), (1, 1, 40, True)])
-def test_mlp_with_post_products_stays_inside_its_buffers(half, rows, B, in_dim, want_out):
-    """gw_mlp_post_forward (node encoder + the first layer-1 product of the encoder's edge MLP, one launch), bf16."""
+def test_mlp_with_post_products_stays_inside_its_buffers(half, dtype, rows, B, in_dim, want_out):
+    """gw_mlp_post_forward (node encoder + the first layer-1 product of the encoder's edge MLP, one launch), bf16 / bf16x3."""
     rs = np.random.RandomState(rows + in_dim)
-    mlp = _mlp(rs, in_dim, 256, 256, True, torch.bfloat16)
+    mlp = _mlp(rs, in_dim, 256, 256, True, dtype)
     post = torch.from_numpy((rs.standard_normal((256, 256)) / 16).astype(np.float32))
     n = rows * B
     x = torch.from_numpy(rs.standard_normal((n, in_dim)).astype(np.float32))
 
     def run(g):
-        pm = _packed(g, mlp, ((0, in_dim),), torch.bfloat16)
-        pw = g.wrap(_pack_bf16(post))
+        pm = _packed(g, mlp, ((0, in_dim),), dtype)
+        pw = g.wrap(_pack_bf16(post, dtype))
         out = g.wrap(torch.zeros(n, 256)) if want_out else None
         po = g.wrap(torch.zeros(n, 256, dtype=torch.float16 if half else torch.float32))
         ops.mlp_post_forward(pm, Operand(g.wrap(x), rows, in_dim), n, rows, [pw], post_half=half, out=out, post_out=[po])
@@ -308,21 +317,22 @@ def test_mlp_with_post_products_stays_inside_its_buffers(half, rows, B, in_dim, 
     _both(run)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3])
 @pytest.mark.parametrize("rows,B,n_out,with_res", [(1000, 2, 78, True), (77, 1, 78, False), (333, 3, 37, True), (1, 1, 80, True)])
-def test_node_update_with_head_stays_inside_its_buffers(rows, B, n_out, with_res):
+def test_node_update_with_head_stays_inside_its_buffers(dtype, rows, B, n_out, with_res):
     """gw_node_update_head_forward (decoder node update + output head + residual, one launch), bf16; the x operand is the projected
     batch-shared table the round-3 decoder feeds (rows_per_batch 0)."""
     rs = np.random.RandomState(rows + n_out)
-    mlp = _mlp(rs, 512, 256, 256, True, torch.bfloat16)
-    head = _mlp(rs, 256, 128, n_out, False, torch.bfloat16)
+    mlp = _mlp(rs, 512, 256, 256, True, dtype)
+    head = _mlp(rs, 256, 128, n_out, False, dtype)
     n = rows * B
     xp = torch.from_numpy(rs.standard_normal((rows, 256)).astype(np.float32))
     a = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32))
     feats = torch.from_numpy(rs.standard_normal((n, 102)).astype(np.float32))
 
     def run(g):
-        pm = _packed(g, mlp, ((0, 256), (256, 512)), torch.bfloat16)
-        hd = _packed(g, head, ((0, 256),), torch.bfloat16)
+        pm = _packed(g, mlp, ((0, 256), (256, 512)), dtype)
+        hd = _packed(g, head, ((0, 256),), dtype)
         out = g.wrap(torch.zeros(n, n_out))
         ops.node_update_head_forward(pm, hd, n, rows, Operand(g.wrap(xp), 0, 256, projected=True), Operand(g.wrap(a), rows, 256),
                                      Operand(g.wrap(feats), rows, n_out) if with_res else None, out=out)

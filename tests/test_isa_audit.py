@@ -264,3 +264,39 @@ def test_row_wise_kernels_keep_the_register_budget_of_two_workgroups_per_cu(tmp_
     for name, (vgpr, scratch) in chains.items():
         # (the general 3-operand edge form parks 28 bytes of loop invariants: bounded, it is not on the forecaster's path)
         assert vgpr <= 256 and scratch <= 32, (name, vgpr, scratch)
+
+
+@pytest.mark.timeout(600)
+def test_split_kernels_fit_two_workgroups_per_cu_and_issue_three_mfmas_per_fragment_pair(tmp_path):
+    """csrc/gw_split.hip (GW_DTYPE_BF16X3): every instantiation of the product build is the 4-wave x 1-group form, whose only
+    latency hiding is the second workgroup on the CU - <= 256 registers, no scratch - and whose arithmetic is exactly three
+    bf16 MFMAs (x_hi.w_hi, x_lo.w_hi, x_hi.w_lo) per pair of weight fragments read from LDS: MFMA count = 1.5 x the
+    ds_read_b128 count of the passes, a multiple of 6 per unit.  No phase clocks in the product build."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graph_weather_amd", "csrc", "gw_split.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "s.o", "-save-temps"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+    text = (tmp_path / "gw_split-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    names = re.findall(r"^(_Z\w*chainx3_kernel\w*):", text, re.M)
+    assert len(names) == 11, names  # mlp x 5 shapes, edge, node update (+ post, + head), project, mlp + post
+    assert all(n.endswith("ELi4ELi1ELi3EEEvN2gw9ChainArgsE") for n in names), names
+    assert "s_memtime" not in text
+    # 256 x 256 passes per instantiation family: (raw layer-1 operands) + middle + output (+ products / head)
+    for name in names:
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        assert scratch == 0 and vgpr <= 256, (name, vgpr, scratch)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        n_mfma = sum(ln.startswith("v_mfma_f32_16x16x32_bf16") for ln in lines)
+        n_frag = sum(ln.startswith("ds_read_b128") for ln in lines)
+        assert n_mfma > 0 and n_mfma % 3 == 0, (name, n_mfma)
+        # a head's last layer reads fragments of 8 row tiles and multiplies 5 of them: at most 1.5 MFMAs per fragment read
+        assert 2 * n_mfma <= 3 * n_frag, (name, n_mfma, n_frag)
+        assert n_mfma >= 0.9 * 1.5 * n_frag, (name, n_mfma, n_frag)
+        assert not any(ln.startswith(("v_mfma_f32_16x16x4", "v_mfma_f32_32x32")) for ln in lines), name
