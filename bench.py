@@ -43,6 +43,7 @@ EDGE_MLP_FLOPS = 2 * (768 * 256 + 256 * 256 + 256 * 256)  # per edge, SURVEY.md 
 LAYER = 2 * D * D  # one 256 x 256 layer on one column
 
 CONFIGS = {
+    "c5x3": dict(grid=0.25, resolution=3, batch=1, precision="bf16x3"),  # c5 with split-operand products
     "c2": dict(grid=1.0, resolution=2, batch=2, precision="fp32"),
     "c2x3": dict(grid=1.0, resolution=2, batch=2, precision="bf16x3"),   # c2 with split-operand products (inside the 1e-3 bar)
     "c3": dict(grid=1.0, resolution=2, batch=16, precision="bf16"),
@@ -154,17 +155,18 @@ def cpu_baseline(lat_lons, state, graphs):
             "single_socket": socket, "sample": sample}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 --pmc summary of the c2 workload
-    (profiles/rNN_pmc_c2.json, re-collected every round by scripts/gpu_final.sh; profiles/pmc_decoder_edge.json = round 2's):
+def pmc_traffic(cfg="c2"):
+    """HBM bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 --pmc summary of the workload
+    (profiles/rNN_pmc_<cfg>.json, re-collected every round by scripts/gpu_final.sh; profiles/pmc_decoder_edge.json = round 2's c2):
     separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE applied by scripts/gpu_pmc.sh.  Returns
     (bytes, summary dict, file name); None if not collected.  These counters are NOT collected in the bench run itself: the
     figure is read from the tracked profile of the same workload (a PMC pass serialises kernels and cannot share a run with
     the timed region)."""
     import glob
 
-    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_c2.json")), reverse=True)
-    names.append(os.path.join(ROOT, "profiles", "pmc_decoder_edge.json"))
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % cfg)), reverse=True)
+    if cfg == "c2":
+        names.append(os.path.join(ROOT, "profiles", "pmc_decoder_edge.json"))
     for p in names:
         try:
             d = json.load(open(p))
@@ -339,6 +341,7 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
     elapsed, timer = runs[len(runs) // 2]
     ms = 1e3 * elapsed / steps
     r = kernel_report(graphs, cfg["batch"], cfg["precision"], timer, ms)
+    traffic, pmc, pmc_file = pmc_traffic(name) if name in ("c2x3",) else (None, None, None)
     out = {"workload": f"{cfg['grid']:g}deg grid ({len(lat_lons)} nodes), mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), "
                        f"batch {cfg['batch']}, {cfg['precision']}",
            "value": cfg["batch"] * steps / elapsed, "unit": "forecasts/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
@@ -348,6 +351,9 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
            "gather_scatter": r["gather_scatter"],
            "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
            "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}
+    if traffic is not None:
+        out["traffic"] = {"bytes_per_launch": traffic, "file": pmc_file, "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                          "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "lds_array_frac_pmc": pmc.get("lds_array_frac")}
     if parity and cfg["precision"] != "fp32":
         with torch.no_grad():
             y = model(feats)
@@ -506,17 +512,20 @@ def train_bench(args, cfg, batch, model, feats, lat_lons, dev, world, rank, back
             "value": total * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if args.config == "c4" else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"GraphWeatherForecaster {cfg['grid']:g}deg training step ({args.config}), batch={batch} on rank 0, fp32",
+            "vs_baseline": None, "dtype": "f32" if cfg["precision"] == "fp32" else cfg["precision"] + " products, fp32 saves / weight gradients / optimizer",
+            "data": "synthetic",
+            "config": {"workload": f"GraphWeatherForecaster {cfg['grid']:g}deg training step ({args.config}), batch={batch} on rank 0, {cfg['precision']}",
                        "global_batch": int(total), "parallelism": f"data parallel x{world}, bucketed gradient all-reduce (RCCL) on a flat buffer"},
             "collectives_per_step": len(flat.buckets) if world > 1 else 0,
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30 if dev.type == "cuda" else None}), flush=True)
     sh.shutdown(ctx)
 
 
-def run_train_extra(dev, steps=5, warmup=2):
-    """The training step of the c2 workload (1 degree, batch 2, fp32) measured in the driver's run: forward under autograd,
-    NormalizedMSELoss, backward into the flat gradient buffer, one-launch AdamW (N = 1: no collective)."""
+def run_train_extra(dev, steps=5, warmup=2, precision="fp32"):
+    """The training step of the c2 workload (1 degree, batch 2) measured in the driver's run: forward under autograd,
+    NormalizedMSELoss, backward into the flat gradient buffer, one-launch AdamW (N = 1: no collective).  precision "bf16x3" =
+    mixed precision: split-operand products in the forward and in the backward's input-gradient products; activation saves,
+    weight-gradient GEMMs, LayerNorm / ReLU backward, master weights and AdamW in fp32."""
     import gc
 
     import graph_weather_amd as gw
@@ -527,6 +536,8 @@ def run_train_extra(dev, steps=5, warmup=2):
     torch.cuda.reset_peak_memory_stats(dev)
     model, lat_lons = build_model(cfg, dev)
     model = model.to(dev).train()
+    if precision != "fp32":
+        set_precision(model, precision)
     crit = gw.NormalizedMSELoss([1.0] * 78, lat_lons, normalize=False)
     flat = sh.FlatGradients(model.parameters())
     opt = gw.AdamW(model.parameters(), lr=1e-4, flat=flat)
@@ -549,7 +560,7 @@ def run_train_extra(dev, steps=5, warmup=2):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(loss)
-    out = {"workload": "c2 training step: 1deg grid, batch 2, fp32: forward + NormalizedMSELoss + backward + AdamW (one GPU)",
+    out = {"workload": f"c2 training step: 1deg grid, batch 2, {precision}: forward + NormalizedMSELoss + backward + AdamW (one GPU)",
            "ms_per_step": 1e3 * elapsed / steps, "value": cfg["batch"] * steps / elapsed, "unit": "samples/s", "steps": steps,
            "warmup": warmup, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2**30}
     del model, feats, target, flat, opt
@@ -760,7 +771,9 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
                             "c3_split": run_extra("c3x3", dev, steps=20, warmup=3, repeats=3, parity=True),
                             "c3": run_extra("c3", dev, steps=20, warmup=3, repeats=3, parity=True),
                             "c5": run_extra("c5", dev, steps=5, warmup=2),
-                            "wide1024": run_wide(dev), "train": run_train_extra(dev), "h2d": h2d}
+                            "c5_split": run_extra("c5x3", dev, steps=5, warmup=2, parity=True),
+                            "wide1024": run_wide(dev), "train": run_train_extra(dev), "train_split": run_train_extra(dev, precision="bf16x3"),
+                            "h2d": h2d}
         if world == 1 and not args.no_cpu_baseline and cfg["grid"] == 1.0:
             out["cpu_baseline"] = cpu_baseline(lat_lons, cpu_state, graphs)
         else:

@@ -93,11 +93,13 @@ def _packed_transposed(mlp, layer: int, W: torch.Tensor, lo: int, hi: int):
     """Packed stream of W[:, lo:hi]^T of (kernel-shaped) Linear ``layer`` (cached per weight version) for the fast
     input-gradient product d @ W[:, lo:hi] through the forward's single-layer kernel; only for 256 x 256 blocks, else None.
     On a miss every such block of the MLP is packed by one ``gw_pack_many`` launch, straight from the weights (the items
-    address the transposed block by strides: no transposed copy)."""
+    address the transposed block by strides: no transposed copy).  The stream has the MLP's matrix-product dtype: fp32, or
+    the split bf16 pairs of the bf16x3 mode (the same three-MFMA products in the backward as in the forward)."""
     if W.shape[0] != 256 or hi - lo != 256:
         return None
     cache = mlp.__dict__.setdefault("_packed_t", {})
-    ver = mlp.native_key()  # versions of the parameters W was derived from (W itself may be a fresh zero-padded copy)
+    wd = ops.gw_dtype_of(mlp.compute_dtype)
+    ver = (mlp.native_key(), wd)  # versions of the parameters W was derived from (W itself may be a fresh zero-padded copy)
     if cache.get("ver") != ver:
         cache.clear()
         cache["ver"] = ver
@@ -115,15 +117,18 @@ def _packed_transposed(mlp, layer: int, W: torch.Tensor, lo: int, hi: int):
                 if b - a == 256:
                     blocks.append((l, a, b, Wl))
         if blocks:
-            n = int(_L().gw_packed_floats(256, 0, 256))
-            buf = torch.empty(len(blocks) * n, dtype=torch.float32, device=W.device)
+            if wd == _lib.DTYPE_BF16X3:
+                n, tdt = int(_L().gw_packed_bytes_bf16x3(256, 0, 256)) // 2, torch.int16
+            else:
+                n, tdt = int(_L().gw_packed_floats(256, 0, 256)), torch.float32
+            buf = torch.empty(len(blocks) * n, dtype=tdt, device=W.device)
             mats = []
             for i, (l, a, b, Wl) in enumerate(blocks):
                 out = buf[i * n:(i + 1) * n]
                 # "Linear" that maps gradients back: output feature f = input column a + f, input feature k = row k of W
                 mats.append((Wl.data_ptr() + 4 * a, 1, int(Wl.shape[1]), 256, 256, out.data_ptr()))
                 cache[(l, a, b)] = out
-            ops.pack_many(_lib.DTYPE_F32, mats, [], _st(W))
+            ops.pack_many(wd, mats, [], _st(W))
     return cache.get((layer, lo, hi))
 
 
@@ -134,7 +139,7 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
     pt = _packed_transposed(mlp, layer, W, lo, hi) if (d.shape[1] == 256 and d.stride(0) % 4 == 0) else None
     if pt is not None and (relu_of is None or (relu_of.shape[1] == 256 and relu_of.stride(0) == 256)):
         rows = int(d.shape[0])
-        return ops.project_forward([pt], Operand(d, rows, 256), rows, rows, weight_dtype=_lib.DTYPE_F32, relu_mask=relu_of)[0]
+        return ops.project_forward([pt], Operand(d, rows, 256), rows, rows, relu_mask=relu_of)[0]  # (dtype from the stream)
     out = gemm_nn(d, W, hi - lo, b_col0=lo)
     if relu_of is not None:
         relu_backward(out, relu_of, None)
@@ -194,7 +199,8 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     if (mlp is not None and 2 <= n_lin <= 3 and d.shape[1] == 256 and d.stride(0) % 4 == 0 and d.shape[0] > 0
             and all(saved.hidden[l].shape[1] == 256 and saved.hidden[l].stride(0) == 256 for l in range(n_lin - 1))):
         pts = [_packed_transposed(mlp, l, weights[2 * l], 0, int(weights[2 * l].shape[1])) for l in range(n_lin - 1, 0, -1)]
-        if all(p is not None for p in pts):
+        # (the register-resident chain kernel is an fp32 kernel; bf16x3 runs the same products as single launches of the split kernel)
+        if all(p is not None and p.dtype == torch.float32 for p in pts):
             fblk = [(tuple(blk), _packed_transposed(mlp, 0, weights[0], blk[0], blk[1])) for blk in (fan if fan_out is not None else ())]
             fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
             rows = int(d.shape[0])

@@ -677,9 +677,11 @@ __global__ void pack_many_kernel(const PackManyArgs a) {
         const int kk = 16 * (s >> 2) + 4 * (lane >> 4) + (s & 3);
         out[i] = (f < n_out && kk < kseg) ? w[(long long)f * sf + (long long)kk * sk] : 0.f;
       }
-    } else {        // (pack_linear_bf16_kernel's order, gw_bf16.hip)
+    } else {        // (pack_linear_bf16_kernel's order, gw_bf16.hip; bf16 == 2: the split stream of gw_split.hip - per K-step the hi
+                    // fragments of all tiles, then their lo fragments)
       __bf16* __restrict__ out = (__bf16*)a.m[it].out;
       const size_t total = (size_t)a.nsteps[it] * ntq * 512;
+      const bool x3 = a.bf16 == 2;
       for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e & 7);
         const int lane = (int)((e >> 3) & 63);
@@ -687,7 +689,15 @@ __global__ void pack_many_kernel(const PackManyArgs a) {
         const int s = (int)((e >> 9) / ntq);
         const int f = 16 * tile + (lane & 15);
         const int kx = 32 * s + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
-        out[e] = (__bf16)((f < n_out && kx < kseg) ? w[(long long)f * sf + (long long)kx * sk] : 0.f);
+        const float v = (f < n_out && kx < kseg) ? w[(long long)f * sf + (long long)kx * sk] : 0.f;
+        if (x3) {
+          const __bf16 h = (__bf16)v;
+          const size_t o = ((size_t)s * 2 * ntq + tile) * 512 + (size_t)lane * 8 + i;
+          out[o] = h;
+          out[o + (size_t)ntq * 512] = (__bf16)(v - (float)h);
+        } else {
+          out[e] = (__bf16)v;
+        }
       }
     }
   } else {
@@ -893,8 +903,7 @@ int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats,
   memset(&a, 0, sizeof(a));
   a.n_mats = n_mats;
   a.n_vecs = n_vecs;
-  a.bf16 = is16(weight_dtype);
-  const bool x3 = weight_dtype == GW_DTYPE_BF16X3;
+  a.bf16 = weight_dtype == GW_DTYPE_BF16X3 ? 2 : (weight_dtype == GW_DTYPE_BF16 ? 1 : 0);
   for (int i = 0; i < n_mats; ++i) {
     const gw_pack_item& m = mats[i];
     if (!m.w || !m.out || m.n_out <= 0 || m.kseg <= 0) return fail(GW_E_BADARG, "gw_pack_many: bad matrix item");
@@ -912,15 +921,6 @@ int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats,
   for (int i = 0; i < n_vecs; ++i) {
     if (!vecs[i].v || !vecs[i].out || vecs[i].n <= 0) return fail(GW_E_BADARG, "gw_pack_many: bad vector item");
     a.v[i] = vecs[i];
-  }
-  if (x3) {  // split streams (gw_split.hip): one launch per matrix, the vectors through the shared kernel
-    for (int i = 0; i < n_mats; ++i)
-      gw::pack_x3_item(a.m[i].w, a.m[i].stride_f, a.m[i].stride_k, a.m[i].n_out, a.m[i].kseg, a.ntq[i], a.nsteps[i], a.m[i].out, stream);
-    if (int rc = check_launch("pack_linear_x3_kernel launch")) return rc;
-    if (n_vecs == 0) return GW_OK;
-    a.n_mats = 0;
-    hipLaunchKernelGGL(pack_many_kernel, dim3(64, 1), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch("pack_many_kernel launch");
   }
   hipLaunchKernelGGL(pack_many_kernel, dim3(64, n_mats + (n_vecs > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("pack_many_kernel launch");
@@ -969,7 +969,8 @@ int gw_pad_vector(const float* v, int n, float* out, void* stream) {
 namespace {
 int fill_save(ChainArgs& a, const gw_activation_save* save, const gw_mlp_weights* w, const char* who) {
   if (!save) return GW_OK;
-  if (w->weight_dtype != GW_DTYPE_F32) return fail(GW_E_UNSUPPORTED, "activation saving (training) is implemented for fp32 weights only");
+  if (w->weight_dtype == GW_DTYPE_BF16)
+    return fail(GW_E_UNSUPPORTED, "activation saving (training) is implemented for fp32 and bf16x3 weights (the saves are fp32 rows)");
   if (!save->hidden || save->hidden_ld < w->hidden || save->hidden_ld % 4 != 0 || (w->ln_gamma && !save->pre_norm)) {
     snprintf(g_err, sizeof(g_err), "%s: bad gw_activation_save", who);
     return GW_E_BADARG;
@@ -1319,8 +1320,8 @@ int gw_project_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand*
   a.proj_half = out_layout == GW_LAYOUT_ROWS_F16;
   a.out_ld = out_ld;
   a.out_cols = 256;
-  if (relu_mask && (weight_dtype != GW_DTYPE_F32 || n_slices != 1))
-    return fail(GW_E_UNSUPPORTED, "gw_project_forward: relu_mask needs fp32 weights and a single slice");
+  if (relu_mask && (weight_dtype == GW_DTYPE_BF16 || n_slices != 1))
+    return fail(GW_E_UNSUPPORTED, "gw_project_forward: relu_mask needs fp32 or bf16x3 weights and a single slice");
   a.relu_mask = relu_mask;
   if (zero_rows && weight_dtype != GW_DTYPE_F32) return fail(GW_E_UNSUPPORTED, "gw_project_forward: zero_rows needs fp32 weights");
   a.zero_rows = zero_rows;

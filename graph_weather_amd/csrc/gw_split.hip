@@ -303,6 +303,19 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     kk[g] = cc[g] - bb[g] * a.cols_per_batch;
   }
 
+  // training (gw_activation_save): the relu output of hidden layer l of every column, as the fp32 kernels store it - the
+  // backward's weight-gradient GEMMs and ReLU masks read these rows (fp32; only the products are split)
+  auto save_hidden = [&](int l, const f32x4 (&h)[NG][HT]) {
+    if (a.save_h == nullptr) return;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (valid[g]) {
+        float* srow = a.save_h + (size_t)l * (size_t)a.save_stride + (size_t)cc[g] * (size_t)a.save_ld;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) stg4(srow + 16 * t + 4 * q, relu4(h[g][t]));
+      }
+  };
+
   bool on[3], prj[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -428,6 +441,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     // ---- middle layers (hidden -> hidden) ----
 #pragma unroll 1
     for (int l = 0; l < a.n_mid; ++l) {
+      save_hidden(l, acc);
 #pragma unroll
       for (int g = 0; g < NG; ++g)
         acc_to_b<HT, true>(reinterpret_cast<bf16x8(&)[HKS]>(bh[g]), reinterpret_cast<bf16x8(&)[HKS]>(bl[g]), acc[g]);
@@ -440,6 +454,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     }
     X3_STAMP(2)
     // ---- output layer ----
+    save_hidden(a.n_mid, acc);
 #pragma unroll
     for (int g = 0; g < NG; ++g)
       acc_to_b<HT, true>(reinterpret_cast<bf16x8(&)[HKS]>(bh[g]), reinterpret_cast<bf16x8(&)[HKS]>(bl[g]), acc[g]);
@@ -452,6 +467,15 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
   X3_STAMP(3)
   // ---- LayerNorm over the OT*16 features of each column (eps 1e-5, biased variance), fp32 ----
   if (!SINGLE && a.gamma != nullptr) {
+    if (a.save_y != nullptr) {  // training: the pre-LayerNorm rows
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (valid[g]) {
+          float* srow = a.save_y + (size_t)cc[g] * (size_t)(OT * 16);
+#pragma unroll
+          for (int t = 0; t < OT; ++t) stg4(srow + 16 * t + 4 * q, o[g][t]);
+        }
+    }
     constexpr float inv_n = 1.0f / (OT * 16);
     float mean[NG], rstd[NG];
 #pragma unroll
@@ -512,6 +536,16 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
     for (int g = 0; g < NG; ++g) {
       if (valid[g]) {
         float* orow = outp + (size_t)cc[g] * (size_t)a.out_ld;
+        if (SINGLE && a.relu_mask != nullptr) {  // ReLU backward fused into an input-gradient product: rows [n_cols, 256]
+          const float* mrow = a.relu_mask + (size_t)cc[g] * 256;
+#pragma unroll
+          for (int t = 0; t < OT; ++t) {
+            const f32x4 mv = ldg4(mrow + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (!(mv[r] > 0.f)) o[g][t][r] = 0.f;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
           const int f0 = 16 * t + 4 * q;

@@ -49,9 +49,9 @@ def _autograd_on(module: nn.Module, *inputs: Optional[torch.Tensor]) -> bool:
                                       or any(t is not None and t.requires_grad for t in inputs))
     if on:
         for m in module.modules():
-            if isinstance(m, MLP) and m.compute_dtype != torch.float32:
-                raise NotImplementedError("graph_weather_amd: the backward pass is implemented for float32 matrix products; "
-                                          "call the bfloat16 / bf16x3 modes under torch.no_grad() (inference)")
+            if isinstance(m, MLP) and m.compute_dtype == torch.bfloat16:
+                raise NotImplementedError("graph_weather_amd: the backward pass is implemented for float32 and bf16x3 matrix "
+                                          "products; call the bfloat16 mode under torch.no_grad() (inference)")
     return on
 
 
@@ -104,7 +104,9 @@ def set_compute_dtype(module: nn.Module, dtype) -> nn.Module:
     residuals and segment sums stay fp32) - what a reference user gets from ``torch.autocast(dtype=torch.bfloat16)`` - or
     ``"bf16x3"`` (``ops.BF16X3``): every product as three bf16 MFMAs on hi / lo operand pairs (16 significant bits per operand,
     fp32 accumulate, csrc/gw_split.hip) - the reference's fp32 outputs to a few 1e-5 of their scale, i.e. inside BASELINE.json's
-    1e-3, at several times the fp32 matrix rate; every tensor in HBM stays fp32 rows.  The 16-bit modes are inference only."""
+    1e-3, at several times the fp32 matrix rate; every tensor in HBM stays fp32 rows.  bfloat16 is inference only; bf16x3 also
+    trains (mixed precision: forward and the backward's input-gradient products on split operands, activation saves, weight-
+    gradient GEMMs, LayerNorm / ReLU backward, master weights and the optimizer in fp32 - autograd.py)."""
     if isinstance(dtype, str):
         if dtype.lower() not in (BF16X3, "split"):
             raise RuntimeError("graph_weather_amd: compute dtype must be torch.float32, torch.bfloat16 or \"bf16x3\"")

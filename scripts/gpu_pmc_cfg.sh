@@ -1,6 +1,9 @@
 #!/bin/bash
 # PMC passes of one bench configuration (separate runs per counter group, kernel-trace only - no sys/hip tracing):
 #   scripts/gpu_pmc_cfg.sh TAG CONFIG [KERNEL_REGEX]      ->  gpurun_out/TAG/pmc_CONFIG.json  (per kernel instantiation and grid)
+#                                                           + gpurun_out/TAG/pmc_CONFIG_dominant.json: the edge-update instantiation with the
+#                                                             largest grid (the decoder edge update) in the flat form bench.pmc_traffic() reads
+#                                                             (copied to profiles/rNN_pmc_CONFIG.json by scripts/gpu_final.sh)
 # HBM bytes: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) and WRITE_SIZE, both in KiB; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /
 # 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); LDS array utilisation = SQ_LDS_IDX_ACTIVE / 256 CUs / (GRBM_GUI_ACTIVE / 8).
 TAG=${1:-pmc}; CFG=${2:-c2}; RX=${3:-"(chainx3_kernel|chain_kernel|edge_kernel|chain16_kernel|edge16[a-z_0-9]*kernel)<[^>]*>"}
@@ -47,6 +50,12 @@ for k, cs in agg.items():
         d["kernel_cycles"] = g / 8.0
     res[k] = d
 json.dump(res, open(os.path.join(out, f"pmc_{cfg}.json"), "w"), indent=1, sort_keys=True)
+# the dominant kernel of the forward = the edge-update kernel instantiation launched with the largest grid (decoder edge update)
+edge = [(float(k.split("grid=")[1]), k) for k in res if re.match(r"(edge_kernel<|chainx3_kernel<8, true, 3, 16, 16, 1,|edge16t_kernel<)", k)]
+if edge:
+    _, k = max(edge)
+    d = dict(res[k]); d["kernel"] = k.split(" grid=")[0]; d["grid_threads"] = int(float(k.split("grid=")[1])); d["config"] = cfg
+    json.dump(d, open(os.path.join(out, f"pmc_{cfg}_dominant.json"), "w"), indent=1, sort_keys=True)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1].get("launches_seen", 1)):
     print(k[:110], {c: (round(v, 3) if v < 100 else int(v)) for c, v in d.items() if c in ("mfma_busy_frac", "lds_array_frac", "kernel_cycles", "hbm_read_bytes", "hbm_write_bytes", "launches_seen", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INST_CYCLES_VMEM")})
 PY
