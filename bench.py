@@ -354,6 +354,8 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
     if traffic is not None:
         out["traffic"] = {"bytes_per_launch": traffic, "file": pmc_file, "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
                           "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "lds_array_frac_pmc": pmc.get("lds_array_frac")}
+    if parity and cfg["batch"] <= 2 and cfg["grid"] >= 1.0:
+        out["cold_ms_per_step"] = cold_step_ms(model, feats)  # forward right after a weight update (every cache misses)
     if parity and cfg["precision"] != "fp32":
         with torch.no_grad():
             y = model(feats)
