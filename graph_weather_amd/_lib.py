@@ -30,7 +30,7 @@ EXPORTS = [
     "gw_linear_forward", "gw_linear_gather_forward", "gw_layernorm_forward", "gw_add_rows", "gw_gather_rows_wide", "gw_segment_sum_rows_wide",
 ]
 
-GEMM_NN, GEMM_TN = 0, 1
+GEMM_NN, GEMM_TN, GEMM_TN_BF16X3 = 0, 1, 2
 
 
 class GwOperand(Structure):

@@ -41,10 +41,17 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, n: int, b_col0: int = 0, out: Opti
     return out
 
 
-def gemm_tn_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, c_col0: int = 0, colsum: Optional[torch.Tensor] = None) -> None:
-    """c[:ma, c_col0:c_col0+nb] += a^T @ b   (a [rows, ma], b [rows, nb]);  colsum[:ma] += column sums of a."""
+def _x3(mlp) -> bool:
+    """The MLP's matrix products run on split operands (bf16x3): its weight-gradient GEMMs do too."""
+    return mlp is not None and getattr(mlp, "compute_dtype", None) == ops.BF16X3
+
+
+def gemm_tn_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, c_col0: int = 0, colsum: Optional[torch.Tensor] = None,
+                x3: bool = False) -> None:
+    """c[:ma, c_col0:c_col0+nb] += a^T @ b   (a [rows, ma], b [rows, nb]);  colsum[:ma] += column sums of a.  ``x3``: products on
+    split operands (include/gw_amd.h: GW_GEMM_TN_BF16X3; 128-multiples only - other shapes run the fp32 kernel)."""
     rows, ma, nb = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
-    _lib.check(_L().gw_gemm_f32(_lib.GEMM_TN, ma, nb, rows, a.data_ptr(), int(a.stride(0)), b.data_ptr(), int(b.stride(0)),
+    _lib.check(_L().gw_gemm_f32(_lib.GEMM_TN_BF16X3 if x3 else _lib.GEMM_TN, ma, nb, rows, a.data_ptr(), int(a.stride(0)), b.data_ptr(), int(b.stride(0)),
                                 c.data_ptr() + 4 * c_col0, int(c.stride(0)), None if colsum is None else colsum.data_ptr(), _st(a)),
                "gw_gemm_f32 TN")
 
@@ -215,7 +222,7 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         ds = [d] + fused  # ds[i]: gradient at the output of Linear_{n_lin-1-i}
         for i, l in enumerate(range(n_lin - 1, 0, -1)):
             gW, gb = zs[2 * l], zs[2 * l + 1]
-            gemm_tn_acc(ds[i], saved.hidden[l - 1], gW, colsum=gb)
+            gemm_tn_acc(ds[i], saved.hidden[l - 1], gW, colsum=gb, x3=_x3(mlp))
             grads[2 * l], grads[2 * l + 1] = gW, gb
         d = ds[-1]
         grads[1] = zs[1]
@@ -231,7 +238,7 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         W = weights[2 * l]
         h_prev = saved.hidden[l - 1]  # relu output feeding Linear_l, [rows, in_l]
         gW, gb = zs[2 * l], zs[2 * l + 1]
-        gemm_tn_acc(d, h_prev, gW, colsum=gb)
+        gemm_tn_acc(d, h_prev, gW, colsum=gb, x3=_x3(mlp))
         grads[2 * l], grads[2 * l + 1] = gW, gb
         d = (input_grad(mlp, l, d, W, 0, int(W.shape[1]), relu_of=h_prev) if mlp is not None
              else relu_backward(gemm_nn(d, W, int(W.shape[1])), h_prev, None))
@@ -270,7 +277,7 @@ class MLPRowsFunction(torch.autograd.Function):
         dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
                                      ctx.mlp.out_dim, fan=fan, fan_out=fo)
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
-        gemm_tn_acc(dz0, x2, gW0)
+        gemm_tn_acc(dz0, x2, gW0, x3=_x3(ctx.mlp))
         grads[0] = gW0
         dx = fo[fan[0]] if fan else None
         dres = None
@@ -357,7 +364,7 @@ class ProjectFunction(torch.autograd.Function):
                 continue
             lo, hi = ctx.mlp.native_splits()[s]
             d = d.contiguous()
-            gemm_tn_acc(d, x, gW, c_col0=lo)  # dW[:, lo:hi] += d^T x
+            gemm_tn_acc(d, x, gW, c_col0=lo, x3=_x3(ctx.mlp))  # dW[:, lo:hi] += d^T x
             if ctx.needs_input_grad[2]:
                 part = input_grad(ctx.mlp, 0, d, W, lo, hi)
                 dx = part if dx is None else dx.add_(part)
@@ -446,7 +453,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
             else:  # raw rows multiplied by W0[:, lo:hi]
                 idx = (plan.src, plan.dst, None)[i]
                 g = t if (idx is None and sp.rows_pb > 0) else gather_rows(t, sp.rows_pb, idx, B, E)
-                gemm_tn_acc(dz0, g, gW0, c_col0=lo)
+                gemm_tn_acc(dz0, g, gW0, c_col0=lo, x3=_x3(mlp))
                 if ctx.needs_input_grad[5 + i]:
                     dg = fo[(lo, hi)]
                     dts[i] = _scatter_rows(dg, i, plan, B, sp.rows_pb, n_rows_tab[i])
@@ -496,7 +503,7 @@ class NodeUpdateFunction(torch.autograd.Function):
                                      fan=fan, fan_out=fo)
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
-        gemm_tn_acc(dz0, agg, gW0, c_col0=alo)
+        gemm_tn_acc(dz0, agg, gW0, c_col0=alo, x3=_x3(ctx.mlp))
         dagg = fo[(alo, ahi)] if ctx.needs_input_grad[7] else None
         dx = None
 
@@ -506,7 +513,7 @@ class NodeUpdateFunction(torch.autograd.Function):
 
         if sp.mode == "raw":
             xg = x if sp.rows_pb > 0 else gather_rows(x, 0, None, batch, rpb)
-            gemm_tn_acc(dz0, xg, gW0, c_col0=xlo)
+            gemm_tn_acc(dz0, xg, gW0, c_col0=xlo, x3=_x3(ctx.mlp))
             if ctx.needs_input_grad[5]:
                 dx = fo[(xlo, xhi)]
                 if sp.rows_pb == 0:

@@ -236,6 +236,134 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(int K, const float* __
     }
 }
 
+// TN on split operands (GW_GEMM_TN_BF16X3; mixed-precision training): the same tile and slab scheme, but
+// C += A_hi^T B_hi + A_hi^T B_lo + A_lo^T B_hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; v = hi + lo, hi = bf16(v),
+// lo = bf16(v - hi): 16 significant bits per operand).  Both operands are k-strided in memory ([rows][features]), so the fp32
+// tiles go to LDS as they lie and every lane builds its fragments from eight 4-byte reads - rows 4 e + (lane >> 4), e = 0..7,
+// of its column (the same permutation of the stage's 32 rows for A and B; LDS row stride 144: the 4 rows of a read hit
+// disjoint banks) - split in registers.  A stage is 32 rows: 64 reads + 64 splits for 48 MFMAs per wave.
+constexpr int kTx3KC = 32;   // k rows per stage (one bf16 MFMA K-step)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8_tn(const float (&v)[8], bf16x8_t& h, bf16x8_t& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hv = (__bf16)v[e];
+    h[e] = hv;
+    l[e] = (__bf16)(v[e] - (float)hv);
+  }
+}
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                            int k_slab, float* __restrict__ colsum_a) {
+  extern __shared__ __attribute__((aligned(16))) float smx[];  // [stage 2][A|B][32 * 144]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int mB = blockIdx.x * 128, nB = blockIdx.y * 128;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int k_begin = blockIdx.z * k_slab;
+  const int k_end = k_begin + k_slab < K ? k_begin + k_slab : K;
+  const int lrow = threadIdx.x >> 5;        // 0..7 (+ 8 h): k row inside a stage
+  const int lcol = (threadIdx.x & 31) * 4;  // float offset inside the 128-wide tile
+  constexpr int kTile = kTx3KC * kTnLd;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = colsum_a != nullptr && blockIdx.y == 0 && (wave & 1) == 0;
+  float asum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int k = k0 + lrow + 8 * h;
+      if (k < k_end) {
+        ra[h] = ldg4(A + (size_t)k * lda + mB + lcol);
+        rb[h] = ldg4(B + (size_t)k * ldb + nB + lcol);
+      } else {
+        ra[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto stash = [&](int st) {
+    float* sa = smx + (size_t)st * 2 * kTile;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      *(f32x4*)(&sa[(lrow + 8 * h) * kTnLd + lcol]) = ra[h];
+      *(f32x4*)(&sa[kTile + (lrow + 8 * h) * kTnLd + lcol]) = rb[h];
+    }
+  };
+  fetch(k_begin);
+  stash(0);
+  __syncthreads();
+  int st = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += kTx3KC) {
+    const bool more = k0 + kTx3KC < k_end;
+    if (more) fetch(k0 + kTx3KC);  // global loads of the next stage fly under this stage's MFMAs
+    const float* as = smx + (size_t)st * 2 * kTile + kq * kTnLd + wm + i;
+    const float* bs = smx + (size_t)st * 2 * kTile + kTile + kq * kTnLd + wn + i;
+    bf16x8_t ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        va[e] = as[4 * e * kTnLd + 16 * t];
+        vb[e] = bs[4 * e * kTnLd + 16 * t];
+        asum[t] += va[e];
+      }
+      split8_tn(va, ah[t], al[t]);
+      split8_tn(vb, bh[t], bl[t]);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+      }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      }
+    if (more) stash(st ^ 1);
+    __syncthreads();
+    st ^= 1;
+  }
+  if (do_sum) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = asum[t];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (kq == 0) __hip_atomic_fetch_add((GW_AS1 float*)(colsum_a + mB + wm + 16 * t + i), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // D layout of the 16x16 MFMAs (fp32 and bf16 alike): column = lane & 15, rows 4 (lane >> 4) + r.  Here the A operand carries the
+  // M index in its row slot (lane & 15 of the A fragment = m) and B the N index: D[row = m][col = n]
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = nB + wn + 16 * tn + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = mB + wm + 16 * tm + 4 * kq + r;
+        __hip_atomic_fetch_add((GW_AS1 float*)(C + (size_t)mm * ldc + n), acc[tm][tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+}
+
 // ---- ReLU backward + bias gradient ----------------------------------------------------------------------------------
 // thread t owns column t of a strip of rows: dz = dh * (h > 0) (h == nullptr: no mask), db[t] += sum of dz over the strip
 __global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t rows, int width, const float* __restrict__ dh, int ld_dh,
@@ -623,8 +751,10 @@ extern "C" {
 
 int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
                 float* c, int32_t ldc, float* colsum_a, void* stream) {
-  if (!a || !b || !c || m < 0 || n < 0 || k < 0 || (mode != GW_GEMM_NN && mode != GW_GEMM_TN))
+  if (!a || !b || !c || m < 0 || n < 0 || k < 0 || (mode != GW_GEMM_NN && mode != GW_GEMM_TN && mode != GW_GEMM_TN_BF16X3))
     return fail(GW_E_BADARG, "gw_gemm_f32: bad arguments");
+  const bool x3 = mode == GW_GEMM_TN_BF16X3;
+  if (x3) mode = GW_GEMM_TN;
   if (m == 0 || n == 0) return GW_OK;
   if (m >= ((int64_t)1 << 31) || k >= ((int64_t)1 << 31)) return fail(GW_E_UNSUPPORTED, "gw_gemm_f32: dimension exceeds int32");
   if (colsum_a && mode != GW_GEMM_TN) return fail(GW_E_UNSUPPORTED, "gw_gemm_f32: colsum_a is a TN-mode extra");
@@ -640,6 +770,13 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     if (k_slab > 4096) k_slab = 4096;
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
     if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
+      if (x3) {  // split-operand products (the unaligned / narrow cases below compute the same sums in fp32)
+        constexpr int lds = 2 * 2 * kTx3KC * kTnLd * 4;
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)gemm_tn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(gemm_tn_x3_kernel, grid, block, lds, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
+        return check_launch("gemm_tn_x3_kernel launch");
+      }
       hipLaunchKernelGGL(gemm_tn_lds_kernel, grid, block, 0, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
       return check_launch("gemm_tn_lds_kernel launch");
     }

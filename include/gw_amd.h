@@ -328,6 +328,10 @@ typedef struct gw_activation_save {
 
 #define GW_GEMM_NN 0 /* C[m][n]  = sum_k A[m][k] * B[k][n]   (input gradients:  dX = dZ . W)                         */
 #define GW_GEMM_TN 1 /* C[m][n] += sum_k A[k][m] * B[k][n]   (weight gradients: dW += dZ^T . X; C must hold the sum) */
+#define GW_GEMM_TN_BF16X3 2 /* (v16) GW_GEMM_TN with split-operand products (both operands as bf16 hi / lo pairs, three bf16 MFMAs per
+                               product, fp32 accumulate: the weight-gradient GEMMs of the mixed-precision training step); runs when
+                               m and n are multiples of 128 and the operands are 16-byte aligned, otherwise the fp32 kernel
+                               computes the same sums */
 int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
                 float* c, int32_t ldc, float* colsum_a /* TN only, may be NULL: colsum_a[m] += sum_k A[k][m] (bias gradient) */,
                 void* stream);

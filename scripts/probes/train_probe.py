@@ -11,6 +11,8 @@ dev = torch.device("cuda:0")
 cfg = bench.CONFIGS["c2"]
 model, lat_lons = bench.build_model(cfg, dev)
 model = model.to(dev).train()
+if os.environ.get("PRECISION"):
+    bench.set_precision(model, os.environ["PRECISION"])
 crit = gw.NormalizedMSELoss([1.0] * 78, lat_lons, normalize=False)
 flat = sh.FlatGradients(model.parameters())
 if os.environ.get("ATTACH", "0") == "1":

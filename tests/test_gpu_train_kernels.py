@@ -50,6 +50,34 @@ def test_gemm_tn_accumulates(m, n, k):
     assert _rel(cs, 1.0 + a.double().sum(0)) < 1e-5  # fused column sums of A (bias gradient)
 
 
+@pytest.mark.parametrize("m,n,k,ld_extra", [(256, 256, 5000, 0), (256, 128, 4097, 4), (128, 256, 31, 0), (256, 256, 100000, 0),
+                                            (256, 102, 4097, 0)])
+def test_gemm_tn_on_split_operands(m, n, k, ld_extra):
+    """GW_GEMM_TN_BF16X3 (weight gradients of the mixed-precision training step): the fp32 TN sums to ~1e-5 on operands of mixed
+    sign and magnitude (a transposed operand or a k permutation that differs between A and B would be an O(1) error); ragged k,
+    strided operands, a 768-wide destination written at a column offset; shapes that are not multiples of 128 take the fp32
+    kernel."""
+    rs = np.random.RandomState(k + n)
+    a = torch.from_numpy((rs.standard_normal((k, m + ld_extra)) * 10.0 ** rs.uniform(-2, 2, size=(k, 1))).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal((k, n + ld_extra)).astype(np.float32))
+    c0 = torch.from_numpy(rs.standard_normal((m, 768)).astype(np.float32))
+    c = c0.to(DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    L = _lib.lib()
+    cs = torch.ones(m, device=DEV)
+    col0 = 256
+    _lib.check(L.gw_gemm_f32(_lib.GEMM_TN_BF16X3, m, n, k, ad.data_ptr(), m + ld_extra, bd.data_ptr(), n + ld_extra,
+                             c.data_ptr() + 4 * col0, 768, cs.data_ptr(), _st()), "gemm x3")
+    prod = a[:, :m].double().t() @ b[:, :n].double()
+    ref = c0.double().clone()
+    ref[:, col0:col0 + n] += prod
+    err = (c.cpu().double() - ref).abs().max().item() / prod.abs().max().item()
+    print(f"[gemm tn x3] m={m} n={n} k={k}: max err / max |product sum| = {err:.2e}")
+    assert err < 5e-5
+    assert torch.equal(c.cpu()[:, :col0], c0[:, :col0]) and torch.equal(c.cpu()[:, col0 + n:], c0[:, col0 + n:])
+    assert _rel(cs, 1.0 + a[:, :m].double().sum(0)) < 1e-5
+
+
 def test_relu_backward_and_bias_grad():
     rs = np.random.RandomState(1)
     rows, w = 1000, 200
