@@ -1014,8 +1014,8 @@ int gw_mlp_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, 
     if (w->n_out == 256 && out_ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: out_ld must be a multiple of 4");
     if (x->k == 256 && x->ld % 4 != 0) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input ld must be a multiple of 4");
     if (x->k > 128 && x->k != 256) return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: input width must be <=128 or ==256");
-    if (w->ln_gamma && (w->n_out != 256 || (w->ln_width > 0 && w->ln_width != w->n_out)))
-      return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: LayerNorm over fewer than 256 features is implemented for float32 weights only");
+    if (w->weight_dtype == GW_DTYPE_BF16 && w->ln_gamma && (w->n_out != 256 || (w->ln_width > 0 && w->ln_width != w->n_out)))
+      return fail(GW_E_UNSUPPORTED, "gw_mlp_forward: LayerNorm over fewer than 256 features is implemented for float32 and bf16x3 weights");
     return launch16(w->weight_dtype, 0, a, x->k, w->hidden, w->n_out, 1, stream);
   }
   if (w->hidden == 256 && w->n_out == 256) {
@@ -1194,7 +1194,8 @@ int gw_edge_update_forward(int32_t batch, int32_t n_edges, const int32_t* src, c
   a.agg_rows_pb = n_dst;
   if (int rc = fill_save(a, save, w, "gw_edge_update_forward")) return rc;
   if (is16(w->weight_dtype)) {
-    if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
+    if (w->weight_dtype == GW_DTYPE_BF16 && w->ln_gamma && a.ln_width != 256)
+      return fail(GW_E_UNSUPPORTED, "gw_edge_update_forward: LayerNorm over fewer than 256 features needs float32 or bf16x3 weights");
     if (det) a.carry = (float*)workspace;
     if (int rc = launch16(w->weight_dtype, 1, a, 256, 256, 256, 1, stream)) return rc;
     return det ? gw::segment_fixup_launch(((int64_t)a.n_cols + 63) / 64, a.carry, agg, stream) : GW_OK;
@@ -1246,7 +1247,8 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   a.proj_half = post_layout == GW_LAYOUT_ROWS_F16;
   a.zero_rows = zero_rows;
   if (is16(w->weight_dtype)) {
-    if (w->ln_gamma && a.ln_width != 256) return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 weights");
+    if (w->weight_dtype == GW_DTYPE_BF16 && w->ln_gamma && a.ln_width != 256)
+      return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 or bf16x3 weights");
     return launch16(w->weight_dtype, n_post > 0 ? 4 : 2, a, 256, 256, 256, 1, stream);
   }
   if (n_post > 0) return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS, false, true>, a, stream, 1, 2);

@@ -476,7 +476,11 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
           for (int t = 0; t < OT; ++t) stg4(srow + 16 * t + 4 * q, o[g][t]);
         }
     }
-    constexpr float inv_n = 1.0f / (OT * 16);
+    // heads and zero-padded narrow models normalise over their ln_width <= OT*16 real features (gw_mlp_weights.ln_width): the
+    // padding rows of the last Linear are zero, so they drop out of the sum and are masked out of the variance
+    const int nfeat = a.ln_width;
+    const float inv_n = 1.0f / (float)nfeat;
+    const bool full = nfeat == OT * 16;
     float mean[NG], rstd[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, (NW * NG == 4 ? 2 : 1)) void chainx3_kerne
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float d = o[g][t][r] - mean[g];
-          v += d * d;
+          v += (full || 16 * t + 4 * q + r < nfeat) ? d * d : 0.f;
         }
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
