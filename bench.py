@@ -571,20 +571,21 @@ def run_train_extra(dev, steps=5, warmup=2, precision="fp32"):
     return out
 
 
-def _rank_entry(rank, world, port, argv, backend, device, model_factory, train_factories):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _rank_entry(rank, world, rendezvous, argv, backend, device, model_factory, train_factories):
+    # the self-launched ranks meet through a file store (a fresh path of this launch): no TCP port to pick, no window in which
+    # another process can take a port between "found free" and "bound by rank 0"
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), GW_BENCH_INIT_FILE=rendezvous)
     main(argv, backend=backend, device=device, model_factory=model_factory, train_factories=train_factories)
 
 
 def self_launch(args, argv, backend, device, model_factory, train_factories) -> None:
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): build the graphs ONCE here, then fork N ranks
-    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would) that each run main() - one
+    (RANK / LOCAL_RANK / WORLD_SIZE set as torch.distributed.run would; rendezvous through a file store of this launch) that each run main() - one
     process per GPU over RCCL, rank 0 prints the one JSON line on the inherited stdout.  The fork happens before this process
     has touched the HIP runtime, so every child creates its own context on its own device; the children find the index arrays
     of the three graphs in the forked memory (graphs.build_forecast_graphs keeps the last builds) instead of rebuilding them
     per rank.  Exits non-zero if any rank fails (the others are terminated: a dead peer would leave them in a collective)."""
     import multiprocessing as mp
-    import socket
 
     from graph_weather_amd.graphs import build_forecast_graphs
     from graph_weather_amd.utils import regular_lat_lons
@@ -596,13 +597,14 @@ def self_launch(args, argv, backend, device, model_factory, train_factories) -> 
         build_forecast_graphs(regular_lat_lons(cfg["grid"]), cfg["resolution"])  # memoised: the ranks inherit it
     else:
         model_factory(cfg, "cpu")  # a stand-in factory builds (and thereby memoises) whatever graphs it uses
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
+
+    rdv_dir = tempfile.mkdtemp(prefix="gw_bench_rdv_")
+    rendezvous = os.path.join(rdv_dir, "store")
     sys.stdout.flush()
     ctx = mp.get_context("fork")
     raw = list(sys.argv[1:] if argv is None else argv)
-    procs = [ctx.Process(target=_rank_entry, args=(r, args.gpus, port, raw, backend, device, model_factory, train_factories))
+    procs = [ctx.Process(target=_rank_entry, args=(r, args.gpus, rendezvous, raw, backend, device, model_factory, train_factories))
              for r in range(args.gpus)]
     for p in procs:
         p.start()
@@ -621,6 +623,10 @@ def self_launch(args, argv, backend, device, model_factory, train_factories) -> 
             procs[r].terminate()  # (exact children of this process)
         for p in procs:
             p.join(timeout=10)
+    import shutil
+
+    shutil.rmtree(rdv_dir, ignore_errors=True)
+    if failed is not None:
         raise SystemExit("bench.py: rank %d of %d exited with code %s" % (failed[0], args.gpus, failed[1]))
 
 
@@ -667,10 +673,13 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        init = {}
+        if os.environ.get("GW_BENCH_INIT_FILE"):  # ranks forked by self_launch: file store instead of MASTER_ADDR / MASTER_PORT
+            init = dict(init_method="file://" + os.environ["GW_BENCH_INIT_FILE"], world_size=world, rank=rank)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, **init)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, **init)
 
     from graph_weather_amd.utils import seeded_features
 
