@@ -485,3 +485,23 @@ def test_regional_forecaster_small_config():
         out = model(feats, lat_lons)
     assert out.shape == (2, 5, 12)
     _close(out - feats[..., :12], ref - feats[..., :12], "regional small config vs the fp32 kernels")
+
+
+@pytest.mark.parametrize("part", ["encoder", "processor", "decoder"])
+def test_one_stage_in_bf16x3_and_the_rest_in_fp32(part):
+    """``set_compute_dtype`` on a sub-module: the stages hand fp32 rows to each other in every mode, so any mix of fp32 and
+    bf16x3 stages is a valid model (the fused forward falls back to stage-by-stage hand-over where the dtypes differ)."""
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    model = model.to(DEV).eval()
+    fd = seeded_features(2, len(lat_lons), 102, seed=42).to(DEV)
+    with torch.no_grad():
+        ref = model(fd)
+        gw.set_compute_dtype(getattr(model, part), X3)
+        out = model(fd)
+        gw.set_compute_dtype(model, torch.float32)
+        back = model(fd)
+    _close(out - fd[..., :78], ref - fd[..., :78], f"{part} in bf16x3, the rest fp32")
+    assert not torch.equal(out, ref)
+    assert _rel(back, ref) <= 1e-5
