@@ -356,6 +356,8 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
                           "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "lds_array_frac_pmc": pmc.get("lds_array_frac")}
     if parity and cfg["batch"] <= 2 and cfg["grid"] >= 1.0:
         out["cold_ms_per_step"] = cold_step_ms(model, feats)  # forward right after a weight update (every cache misses)
+    if parity and cfg["grid"] >= 1.0:
+        out["graph"] = graph_replay_ms(model, feats, steps=steps)
     if parity and cfg["precision"] != "fp32":
         with torch.no_grad():
             y = model(feats)
@@ -371,6 +373,30 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def graph_replay_ms(model, feats, steps=20, repeats=3):
+    """The same forward replayed from ONE HIP graph (graph_weather_amd.ForwardGraph: every launch of every stream captured once;
+    the batch is copied into the graph's input buffer in front of each replay): median ms per step of `repeats` x `steps`."""
+    import graph_weather_amd as gw
+
+    fg = gw.ForwardGraph(model)
+    with torch.no_grad():
+        y = fg(feats)
+        ref = model(feats)
+        err = (y - ref).abs().max().item() / max((ref - feats[..., :78]).abs().max().item(), 1e-30)
+        ts = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fg(feats)
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0) / steps)
+    ts.sort()
+    return {"ms_per_step": ts[len(ts) // 2], "ms_per_step_all": ts, "value": feats.shape[0] / (ts[len(ts) // 2] * 1e-3), "unit": "forecasts/s",
+            "max_rel_vs_eager": err, "note": "whole forward as one HIP graph (same kernels, same arguments; input copied into the "
+                                             "graph's buffer each step); the eager figure above it is what `value` reports"}
 
 
 def set_precision(model, precision: str) -> None:
@@ -774,6 +800,7 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
             out["cold_note"] = ("forward right after every parameter changed: packed weights, edge / mesh embeddings and their layer-1 "
                                 "products are rebuilt (the reference recomputes the embeddings on every forward)")
         if world == 1 and not args.no_extra and args.config == "c2" and on_gpu:
+            out["graph"] = graph_replay_ms(model, feats, steps=args.steps)
             h2d = h2d_step_ms(model, feats)
             del model, feats
             gc.collect()

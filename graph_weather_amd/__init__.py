@@ -28,6 +28,7 @@ from .regional import (  # noqa: F401
     RegionalForecaster,
     RegionalForecasterConfig,
 )
+from .graphed import ForwardGraph  # noqa: F401  (the inference forward as one HIP graph)
 from .rollout import rollout  # noqa: F401
 from .optim import AdamW  # noqa: F401
 

@@ -104,6 +104,14 @@ class GraphWeatherForecaster(TopologyRecord, torch.nn.Module, PyTorchModelHubMix
         set_compute_dtype(self, dtype)
         return self
 
+    def graphed(self, warmup: int = 3):
+        """``fg = model.graphed(); y = fg(features)``: the inference forward replayed from one HIP graph (``graphed.ForwardGraph``;
+        re-captured by itself when weights, input shape or compute dtype change).  Pays off where the step is launch-bound: the
+        bf16x3 mode at small batch."""
+        from .graphed import ForwardGraph
+
+        return ForwardGraph(self, warmup=warmup)
+
     def set_deterministic(self, flag: bool = True) -> "GraphWeatherForecaster":
         """Bitwise reproducible inference forward - see ``layers.set_deterministic``."""
         from .layers import set_deterministic

@@ -31,6 +31,8 @@ class ForwardGraph:
         self.model = model
         self.warmup = int(warmup)
         self._key = None
+        self._params = None
+        self._mlps = None
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self.input: Optional[torch.Tensor] = None
         self.output: Optional[torch.Tensor] = None
@@ -39,9 +41,13 @@ class ForwardGraph:
     def _state_key(self, shape, device) -> tuple:
         from .layers import MLP
 
-        versions = tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self.model.parameters())
-        dtypes = tuple(str(m.compute_dtype) for m in self.model.modules() if isinstance(m, MLP))
-        det = tuple(bool(getattr(m, "deterministic", False)) for m in self.model.modules() if hasattr(m, "deterministic"))
+        if self._params is None:  # (module structure is fixed after construction: walk it once)
+            self._params = list(self.model.parameters())
+            self._mlps = [m for m in self.model.modules() if isinstance(m, MLP)]
+            self._dets = [m for m in self.model.modules() if hasattr(m, "deterministic")]
+        versions = tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self._params)
+        dtypes = tuple(str(m.compute_dtype) for m in self._mlps)
+        det = tuple(bool(m.deterministic) for m in self._dets)
         return (tuple(shape), str(device), versions, dtypes, det)
 
     def _capture(self, features: torch.Tensor) -> None:

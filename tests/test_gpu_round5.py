@@ -68,3 +68,46 @@ def test_bf16_forward_on_two_streams_builds_its_shared_tiles_before_the_fork():
         gp.streams = 1
         one = model(feats)
     assert _rel(steady, one) <= 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, "bf16x3", torch.bfloat16])
+def test_forward_graph_replays_the_eager_forward_and_follows_weight_updates(dtype):
+    """graph_weather_amd.ForwardGraph: the whole inference forward (every launch of both HIP streams) as one HIP graph.  Equal to the
+    eager forward (bitwise in deterministic mode); re-captured by itself after a weight update, a compute-dtype switch and a new
+    batch size - a stale graph would keep multiplying by the OLD packed weights."""
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=0)
+    model = model.to(DEV).eval()
+    model.set_compute_dtype(dtype)
+    tol = 5e-3 if dtype == torch.bfloat16 else 1e-5
+    feats = seeded_features(2, len(lat_lons), 102, seed=42).to(DEV)
+    fg = model.graphed()
+    with torch.no_grad():
+        y = fg(feats).clone()
+        assert fg.captures == 1
+        ref = model(feats)
+        assert _rel(y - feats[..., :78], ref - feats[..., :78]) <= tol
+        other = seeded_features(2, len(lat_lons), 102, seed=7).to(DEV)
+        y2 = fg(other).clone()  # same shape: replay only
+        assert fg.captures == 1
+        assert _rel(y2 - other[..., :78], model(other) - other[..., :78]) <= tol
+        assert not torch.equal(y2, y)
+        for p in model.parameters():  # an optimizer step's worth of change
+            p.mul_(1.01)
+        y3 = fg(feats).clone()
+        assert fg.captures == 2
+        ref3 = model(feats)
+        assert _rel(y3 - feats[..., :78], ref3 - feats[..., :78]) <= tol
+        assert _rel(y3, y) > 1e-4  # (the new weights really are in the graph)
+        y4 = fg(feats[:1].contiguous()).clone()  # new batch size
+        assert fg.captures == 3 and y4.shape[0] == 1
+        assert _rel(y4 - feats[:1, :, :78], ref3[:1] - feats[:1, :, :78]) <= tol
+        if dtype != torch.bfloat16:
+            model.set_deterministic(True)
+            a = fg(feats).clone()
+            assert fg.captures == 4
+            assert torch.equal(a, model(feats)) and torch.equal(a, fg(feats))
+    model.train()
+    with pytest.raises(RuntimeError, match="inference"):
+        fg(feats)
