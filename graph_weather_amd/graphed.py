@@ -38,7 +38,7 @@ class ForwardGraph:
         self.output: Optional[torch.Tensor] = None
         self.captures = 0
 
-    def _state_key(self, shape, device) -> tuple:
+    def _state_key(self, shape, device, dtype) -> tuple:
         from .layers import MLP
 
         if self._params is None:  # (module structure is fixed after construction: walk it once)
@@ -48,7 +48,7 @@ class ForwardGraph:
         versions = tuple((p.data_ptr(), -1 if p.is_inference() else p._version) for p in self._params)
         dtypes = tuple(str(m.compute_dtype) for m in self._mlps)
         det = tuple(bool(m.deterministic) for m in self._dets)
-        return (tuple(shape), str(device), versions, dtypes, det)
+        return (tuple(shape), str(device), str(dtype), versions, dtypes, det)
 
     def _capture(self, features: torch.Tensor) -> None:
         from . import ops
@@ -84,7 +84,7 @@ class ForwardGraph:
             features = self.input
         if not features.is_cuda:
             raise RuntimeError("graph_weather_amd: features must be on a HIP device - there is no CPU path")
-        key = self._state_key(features.shape, features.device)
+        key = self._state_key(features.shape, features.device, features.dtype)
         if self._graph is None or key != self._key:
             self._capture(features)
             self._key = key
