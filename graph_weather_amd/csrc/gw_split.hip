@@ -23,8 +23,10 @@
 // fragment ring.  What does not move it either way is what a pass is made of: 8 chunk hand-overs (DMA landing + barrier: ~25 % of
 // the pass), 256 KiB of fragment reads per wave (LDS array 25-40 % busy) and an MFMA pipe shared by two waves (33-43 % busy over the
 // kernel, SQ_VALU_MFMA_BUSY_CYCLES).  Nor does the order of the instructions inside a unit or the register file of the accumulators.
-// What all variants share is the weight stream: every 64-column workgroup pulls both 256 KB matrices of a tile out of L2 - 9.0 GB
-// of L2 requests per decoder launch for 1.0 GB of HBM reads, 10.8 TB/s averaged over the launch (profiles/r05_pmc_l2_c2x3.json).
+// Nor is it the weight stream out of L2 (9.0 GB of L2 requests per decoder launch = 10.8 TB/s, a third of what the same
+// double-buffered LDS-DMA stream reaches with nothing else going on: profiles/r05_pmc_l2_c2x3.json, r05_l2_stream_probe.log): every
+// resource of a pass is about half busy and the pass is the serial skeleton of its 8 one-K-step chunks (DMA landing, barrier,
+// restart of the fragment ring behind the barrier, 48 MFMAs, 8 DMA issues per wave).
 // DESIGN.md "bf16x3" lists the experiments.
 
 #include <hip/hip_runtime.h>
