@@ -1,0 +1,54 @@
+"""Host logic of graph_weather_amd.ForwardGraph that needs no GPU: what makes a captured graph stale (tests/test_gpu_round5.py
+replays real captures on the device)."""
+import pytest
+import torch
+
+import graph_weather_amd as gw
+from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons
+
+
+def _model():
+    model = gw.GraphWeatherForecaster(regular_lat_lons(30.0))
+    deterministic_fill_(model, seed=0)
+    return model.eval()
+
+
+def test_capture_key_follows_weights_dtype_flags_and_input():
+    model = _model()
+    fg = gw.ForwardGraph(model)
+    shape = (2, 72, 102)
+    k0 = fg._state_key(shape, "cuda:0", torch.float32)
+    assert k0 == fg._state_key(shape, "cuda:0", torch.float32)  # nothing changed: the same graph is replayed
+    assert k0 != fg._state_key((1, 72, 102), "cuda:0", torch.float32)  # another batch size
+    assert k0 != fg._state_key(shape, "cuda:1", torch.float32)
+    assert k0 != fg._state_key(shape, "cuda:0", torch.float64)
+    with torch.no_grad():
+        next(model.parameters()).add_(0)  # what an optimizer step does to the version counter
+    k1 = fg._state_key(shape, "cuda:0", torch.float32)
+    assert k1 != k0
+    model.set_compute_dtype("bf16x3")  # the packed weights the launches point at are others
+    k2 = fg._state_key(shape, "cuda:0", torch.float32)
+    assert k2 != k1
+    model.set_deterministic(True)  # other kernels' arguments (carry records instead of atomics)
+    assert fg._state_key(shape, "cuda:0", torch.float32) != k2
+
+
+def test_load_state_dict_invalidates_the_capture_key():
+    a, b = _model(), _model()
+    fg = gw.ForwardGraph(a)
+    k0 = fg._state_key((1, 72, 102), "cuda:0", torch.float32)
+    a.load_state_dict(b.state_dict())
+    assert fg._state_key((1, 72, 102), "cuda:0", torch.float32) != k0
+
+
+def test_refuses_cpu_tensors_training_mode_and_a_first_call_without_input():
+    model = _model()
+    fg = model.graphed()
+    assert isinstance(fg, gw.ForwardGraph) and fg.captures == 0
+    with pytest.raises(RuntimeError, match="first call"):
+        fg()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fg(torch.zeros(1, 72, 102))
+    model.train()
+    with pytest.raises(RuntimeError, match="inference"):
+        fg(torch.zeros(1, 72, 102))
