@@ -90,6 +90,11 @@ int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
 // one matrix item of gw_pack_many into the split stream (strides in floats)
 void pack_x3_item(const float* w, long long stride_f, long long stride_k, int n_out, int kseg, int ntp, int nsteps, void* out, void* stream);
 
+// row-split node update for mesh-sized launches (gw_noders.hip): CG column groups x 4 row quarters per workgroup
+int node_rs_groups(int64_t n_cols);             // column groups per workgroup, 0 = not mesh-sized
+bool node_rs_eligible(const ChainArgs& a);      // aggregate raw fp32 rows, node operand raw / projected / absent, one middle layer, inference
+int node_rs_launch(ChainArgs& a, bool x3 /* GW_DTYPE_BF16X3 packs, else fp32 */, void* stream);
+
 // debug timestamp hook (gw_debug_timestamps) and tuning overrides, defined in gw_kernels.hip
 extern unsigned long long* g_dbg;
 extern int g_dbg_cap;

@@ -1246,6 +1246,10 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
     return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: fp16 post products come with bf16 weights");
   a.proj_half = post_layout == GW_LAYOUT_ROWS_F16;
   a.zero_rows = zero_rows;
+  // mesh-sized launches (at most one round of 48-column workgroups): row tiles split over the waves of a column group
+  // (gw_noders.hip; fp32 and bf16x3 - the modes whose tables are all fp32 rows)
+  if (w->weight_dtype != GW_DTYPE_BF16 && GW_TUNE("GW_NODE_RS", 1) != 0 && gw::node_rs_eligible(a))
+    return gw::node_rs_launch(a, w->weight_dtype == GW_DTYPE_BF16X3, stream);
   if (is16(w->weight_dtype)) {
     if (w->weight_dtype == GW_DTYPE_BF16 && w->ln_gamma && a.ln_width != 256)
       return fail(GW_E_UNSUPPORTED, "gw_node_update_forward: LayerNorm over fewer than 256 features needs float32 or bf16x3 weights");

@@ -1,0 +1,150 @@
+"""Round-6 GPU tests: the row-split node update of mesh-sized launches (csrc/gw_noders.hip) - NodeProcessor.forward behind
+scatter_sum, graph_net_block.py:184-193 - against a float64 statement of the same MLP and against the 64-column kernels on
+the same rows."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import graph_weather_amd as gw  # noqa: E402
+from graph_weather_amd import ops  # noqa: E402
+from graph_weather_amd.ops import Operand  # noqa: E402
+from graph_weather_amd.utils import deterministic_fill_  # noqa: E402
+
+DEV = "cuda:0"
+X3 = ops.BF16X3
+
+
+def _rel(a, ref):
+    a, ref = a.detach().cpu().double(), ref.detach().cpu().double()
+    return (a - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+
+
+def _node_mlp_fp64(blk, x, agg, x_res):
+    """graph_net_block.py:189-191 in float64: LayerNorm(MLP(cat[x, agg])) + x."""
+    m = blk.node_model.node_mlp
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    h = torch.cat([x, agg], dim=1).cpu().double()
+    h = torch.relu(h @ sd["model.0.weight"].T + sd["model.0.bias"])
+    h = torch.relu(h @ sd["model.2.weight"].T + sd["model.2.bias"])
+    h = h @ sd["model.4.weight"].T + sd["model.4.bias"]
+    h = torch.nn.functional.layer_norm(h, (256,), sd["model.5.weight"], sd["model.5.bias"], eps=1e-5)
+    return h + x_res.cpu().double()
+
+
+def _blocks(dtype):
+    torch.manual_seed(0)
+    blk = gw.build_graph_processor_block(256, 256, 256, 256, 2, 2, "LayerNorm")
+    nxt = gw.build_graph_processor_block(256, 256, 256, 256, 2, 2, "LayerNorm")
+    deterministic_fill_(blk, seed=13)
+    deterministic_fill_(nxt, seed=14)
+    gw.set_compute_dtype(blk, dtype)
+    gw.set_compute_dtype(nxt, dtype)
+    return blk.to(DEV), nxt.to(DEV)
+
+
+# rows per batch element x batch: 1, 2 and 3 column groups per workgroup (<= 4 096, <= 8 192, <= 12 288 columns), ragged
+# against 16 / 32 / 48, one column, the mesh itself at batch 1 and 2
+SIZES = [(1, 1), (15, 1), (777, 3), (4096, 1), (4097, 1), (5882, 1), (2731, 3), (5882, 2), (12288, 1), (6143, 2)]
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 2e-6), (X3, 3e-5)])
+@pytest.mark.parametrize("n,B", SIZES)
+def test_row_split_node_update_against_float64(dtype, bar, n, B):
+    blk, nxt = _blocks(dtype)
+    g = torch.Generator(device="cpu").manual_seed(n * 7 + B)
+    x = torch.randn(B * n, 256, generator=g).to(DEV)
+    agg = (2.0 * torch.randn(B * n, 256, generator=g)).to(DEV)
+    pm_n, pm_e = blk.node_model.node_mlp.packed(), nxt.edge_model.edge_mlp.packed()
+    ref = _node_mlp_fp64(blk, x, agg, x)
+    out = ops.node_update_forward(pm_n, B * n, n, Operand(x, n, 256), Operand(x, n, 256), Operand(agg, n, 256))
+    zero = torch.full((B * n, 256), 7.0, device=DEV)
+    out2, (ps, pd) = ops.node_update_forward(pm_n, B * n, n, Operand(x, n, 256), Operand(x, n, 256), Operand(agg, n, 256),
+                                             post_w=[pm_e.w1[0], pm_e.w1[1]], zero_rows=zero)
+    torch.cuda.synchronize()
+    r = _rel(out, ref)
+    print(f"[row-split node update {dtype} n={n} B={B}] max-rel vs float64 {r:.2e}")
+    assert r <= bar
+    assert torch.equal(out, out2)
+    assert (zero == 0).all()
+    w1 = nxt.edge_model.edge_mlp.state_dict()["model.0.weight"].detach().cpu().double()
+    ps_ref = out.cpu().double() @ w1[:, 0:256].T
+    pd_ref = out.cpu().double() @ w1[:, 256:512].T
+    assert _rel(ps, ps_ref) <= bar and _rel(pd, pd_ref) <= bar
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 1e-6), (X3, 1e-6)])
+def test_row_split_node_update_equals_the_64_column_kernel_on_the_same_rows(dtype, bar):
+    """The same rows as the head of a launch too large for the row-split form (> 12 288 columns: chain_kernel / chainx3_kernel,
+    64 columns per workgroup): the matrix products are summed in the same order, only the LayerNorm partial sums meet in a
+    different one."""
+    blk, nxt = _blocks(dtype)
+    n_small, n_big = 5882, 12288 + 640
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(n_big, 256, generator=g).to(DEV)
+    agg = torch.randn(n_big, 256, generator=g).to(DEV)
+    pm_n, pm_e = blk.node_model.node_mlp.packed(), nxt.edge_model.edge_mlp.packed()
+    big, (ps_b, pd_b) = ops.node_update_forward(pm_n, n_big, n_big, Operand(x, n_big, 256), Operand(x, n_big, 256),
+                                                Operand(agg, n_big, 256), post_w=[pm_e.w1[0], pm_e.w1[1]])
+    xs, as_ = x[:n_small].contiguous(), agg[:n_small].contiguous()
+    small, (ps_s, pd_s) = ops.node_update_forward(pm_n, n_small, n_small, Operand(xs, n_small, 256), Operand(xs, n_small, 256),
+                                                  Operand(as_, n_small, 256), post_w=[pm_e.w1[0], pm_e.w1[1]])
+    torch.cuda.synchronize()
+    r = max(_rel(small, big[:n_small]), _rel(ps_s, ps_b[:n_small]), _rel(pd_s, pd_b[:n_small]))
+    print(f"[row-split vs 64-column kernel {dtype}] max-rel {r:.2e}")
+    assert r <= bar
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, X3])
+def test_row_split_node_update_without_layernorm_and_with_indexed_rows(dtype):
+    """norm_type=None (graph_net_block.py:50-59) and operands addressed through an index (rows of a larger table)."""
+    torch.manual_seed(1)
+    blk = gw.build_graph_processor_block(256, 256, 256, 256, 2, 2, None)
+    deterministic_fill_(blk, seed=21)
+    gw.set_compute_dtype(blk, dtype)
+    blk = blk.to(DEV)
+    n = 1000
+    table = torch.randn(3 * n, 256, device=DEV)
+    idx = torch.randperm(3 * n, device=DEV)[:n].to(torch.int32)
+    agg = torch.randn(n, 256, device=DEV)
+    pm = blk.node_model.node_mlp.packed()
+    xi = Operand(table, 0, 256, index=idx)
+    out = ops.node_update_forward(pm, n, n, xi, xi, Operand(agg, n, 256))
+    x = table[idx.long()]
+    sd = {k: v.detach().cpu().double() for k, v in blk.node_model.node_mlp.state_dict().items()}
+    h = torch.cat([x, agg], dim=1).cpu().double()
+    h = torch.relu(h @ sd["model.0.weight"].T + sd["model.0.bias"])
+    h = torch.relu(h @ sd["model.2.weight"].T + sd["model.2.bias"])
+    ref = h @ sd["model.4.weight"].T + sd["model.4.bias"] + x.cpu().double()
+    assert _rel(out, ref) <= (2e-6 if dtype == torch.float32 else 3e-5)
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 2e-6), (X3, 3e-5)])
+@pytest.mark.parametrize("n,B", [(5882, 2), (900, 1)])
+def test_row_split_node_update_with_a_projected_or_absent_node_operand(dtype, bar, n, B):
+    """The encoder's mesh rows enter their node update as a cached, batch-shared product x . Wx^T (``projected``: a gather-add,
+    no matrix pass, encoder.py:235-241 through the layer-1 split) and the decoder's grid rows are zeros
+    (assimilator_decoder.py:84: operand absent)."""
+    blk, _ = _blocks(dtype)
+    g = torch.Generator(device="cpu").manual_seed(n + B)
+    x = torch.randn(n, 256, generator=g).to(DEV)  # shared by the batch
+    agg = torch.randn(B * n, 256, generator=g).to(DEV)
+    sd = {k: v.detach().cpu().double() for k, v in blk.node_model.node_mlp.state_dict().items()}
+    px = (x.cpu().double() @ sd["model.0.weight"][:, :256].T).float().to(DEV)  # the cached product rows
+
+    def ref(xin, with_res):
+        h = torch.relu(xin @ sd["model.0.weight"][:, :256].T + agg.cpu().double() @ sd["model.0.weight"][:, 256:].T + sd["model.0.bias"])
+        h = torch.relu(h @ sd["model.2.weight"].T + sd["model.2.bias"])
+        h = h @ sd["model.4.weight"].T + sd["model.4.bias"]
+        h = torch.nn.functional.layer_norm(h, (256,), sd["model.5.weight"], sd["model.5.bias"], eps=1e-5)
+        return h + (xin if with_res else 0.0)
+
+    pm = blk.node_model.node_mlp.packed()
+    xb = x.cpu().double().repeat(B, 1)
+    out_p = ops.node_update_forward(pm, B * n, n, Operand(px, 0, 256, projected=True), Operand(x, 0, 256), Operand(agg, n, 256))
+    out_z = ops.node_update_forward(pm, B * n, n, ops.ZERO, ops.ZERO, Operand(agg, n, 256))
+    torch.cuda.synchronize()
+    rp, rz = _rel(out_p, ref(xb, True)), _rel(out_z, ref(torch.zeros_like(xb), False))
+    print(f"[row-split node update {dtype} n={n} B={B}] projected x {rp:.2e}, absent x {rz:.2e}")
+    assert rp <= bar and rz <= bar
