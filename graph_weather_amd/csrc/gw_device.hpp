@@ -61,6 +61,36 @@ __device__ __forceinline__ void glds16_asm_s(const float* g_uniform, unsigned la
       : "memory");
 }
 
+// L2 prefetch of a weight stream.  Workgroups of a mesh-sized launch start together and walk the same packed stream in step:
+// every 32 KiB chunk is then a first touch for all of them at once, and with the other matrices of the forward (20+ MB) between
+// two uses of a block's weights in a 4 MiB L2 it comes from the Infinity Cache / HBM - one miss latency per chunk, 48 chunks
+// deep, where the chunk's MFMAs are shorter than the miss (bf16x3) nothing hides it.  One wave instruction touches one
+// 128-byte line per lane (64 lines = 8 KiB); the 4 bytes per lane land in a scratch area of LDS (lds_byte_addr .. + 256), so no
+// register is written and the request is counted by vmcnt like any DMA piece: issue before the first chunk barrier, into a
+// region nothing reads before a later barrier.
+__device__ __forceinline__ void l2_touch_lds(const char* lane_ptr, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_ptr), "s"(lds_byte_addr)
+               : "memory");
+}
+// The workgroups of one XCD (blockIdx.x % 8 - observed placement, used for speed only) share the chunks of `n_mats` packed
+// matrices of 8 x 32 KiB among themselves: chunk g is touched by the workgroup whose index within the XCD is g mod (workgroups
+// per XCD).  Waves 0-3 issue one instruction per chunk each; chunk 0 of the first matrix is being fetched by everybody anyway.
+__device__ __forceinline__ void l2_prefetch_stream(const char* const* mats, int n_mats, int lane, int wave, unsigned scratch_lds) {
+  if (wave >= 4) return;
+  const int per_xcd = (int)(gridDim.x >> 3) > 0 ? (int)(gridDim.x >> 3) : 1;
+  const int me = (int)(blockIdx.x >> 3) % per_xcd;
+  for (int mi = 0; mi < n_mats; ++mi) {
+    const char* p = mats[mi];
+    if (p == nullptr) continue;
+    for (int c = (mi == 0 ? 1 : 0); c < 8; ++c)
+      if ((mi * 8 + c) % per_xcd == me)
+        l2_touch_lds(p + (size_t)c * 32768 + (size_t)(wave * 64 + lane) * 128, __builtin_amdgcn_readfirstlane(scratch_lds + (unsigned)wave * 256u));
+  }
+}
+
 // Each wave DMAs its share of `nfloats` (multiple of 256) from the packed weight stream into an LDS buffer.
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
   const int npieces = nfloats >> 8;

@@ -12,10 +12,11 @@
 // row tiles: one ds_read_b128 per K-step in fp32) and issues a quarter of the MFMAs.  Between layers the four waves of a group
 // exchange their quarter of the new activations through 16 KiB of LDS - in the transposed scheme a lane's accumulator registers
 // ARE its B-operand registers of the next layer, so the exchange is lane-to-lane (conflict-free 16-byte accesses, no shuffles).
-// LayerNorm statistics are combined through LDS in a fixed order.  A workgroup is CG column groups (CG = 1, 2, 3 -> 4, 8, 12
+// Before LayerNorm the whole row is exchanged once more: every wave computes the statistics in the order of the 64-column
+// kernels (bitwise their rows).  A workgroup is CG column groups (CG = 1, 2, 3 -> 4, 8, 12
 // waves sharing ONE weight stream): 736 column groups of a batch-2 mesh become 246 workgroups of 48 columns - every CU of the chip
 // carries three waves per SIMD and streams the 1.5 MB of weights once, instead of 184 CUs carrying one wave per SIMD.
-// The products are summed in the order of chain_kernel (bitwise the same MLP outputs before LayerNorm).
+// Products and LayerNorm sums are added in the order of chain_kernel / chainx3_kernel: bitwise the same rows.
 //
 // Launch kinds: node update (+ POST products of the next block's layer-1 slices, + zero fill of the next aggregate); the
 // aggregate a raw 256-wide fp32 table, the node operand raw, already projected (a cached product: gather-add) or absent; one
@@ -23,9 +24,7 @@
 // bf16x3 weights (node_rs3_kernel, arithmetic of gw_split.hip).  Anything else stays on chain_kernel / chainx3_kernel
 // (gw_node_update_forward decides).
 //
-// LDS: the two 32 KiB weight buffers; the exchange buffer (16 KiB per column group) lies OVER the weight buffer that is free
-// between two passes when it fits (CG <= 2: 65 KiB per workgroup, so a 64-column edge-update workgroup of the other sample's
-// stream - or a second row-split workgroup - shares the CU), behind them for CG = 3 (113 KiB).
+// LDS: two 64 KiB weight buffers; the exchange buffer (16 KiB per column group) lies OVER the one that is free between two passes.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,18 +37,100 @@ using namespace gw;
 
 namespace {
 
+// phase clocks and A/B switches: tuning builds only (gw_debug_timestamps, scripts/gpu_timeline_rs.py; GW_RS_TUNE bit 0 = no L2 prefetch)
+#ifdef GW_TUNING
+#define RS_STAMP(i) \
+  if (a.dbg != nullptr) { ts[i] = gw::gw_clock(); }
+#define RS_TUNE(a) ((a).tune16)
+#define RS_CLOCKS                                           \
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};      \
+  unsigned long long waited_[2] = {0, 0};
+#define RS_WAITED (a.dbg != nullptr ? waited_ : nullptr)
+#define RS_RECORD                                                                   \
+  if (a.dbg != nullptr) {                                                           \
+    ts[6] = gw::gw_clock();                                                         \
+    if (threadIdx.x == 0 && (int)blockIdx.x < a.dbg_cap) {                          \
+      unsigned long long* rec = a.dbg + (size_t)blockIdx.x * 16;                    \
+      for (int i = 0; i < 7; ++i) rec[i] = ts[i];                                   \
+      rec[10] = blockIdx.x;                                                         \
+      rec[11] = waited_[0]; /* middle + output passes: own DMA pieces landing */    \
+      rec[12] = waited_[1]; /* ... and the workgroup barrier */                     \
+    }                                                                               \
+  }
+#else
+#define RS_STAMP(i)
+#define RS_TUNE(a) 0
+#define RS_CLOCKS
+#define RS_WAITED nullptr
+#define RS_RECORD
+#endif
+
+// the chunk hand-over: own DMA pieces landed, then the workgroup barrier (tuning builds clock the two waits per wave)
+#ifdef GW_TUNING
+#define RS_WAIT_BARRIER()                                      \
+  {                                                            \
+    unsigned long long t0w = 0, t1w = 0;                       \
+    if (waited != nullptr) t0w = gw::gw_clock();               \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
+    if (waited != nullptr) t1w = gw::gw_clock();               \
+    __syncthreads();                                           \
+    if (waited != nullptr) {                                   \
+      waited[0] += t1w - t0w;                                  \
+      waited[1] += gw::gw_clock() - t1w;                       \
+    }                                                          \
+  }
+#else
+#define RS_WAIT_BARRIER()                            \
+  {                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+    __syncthreads();                                 \
+  }
+#endif
+
 constexpr int kXbufFloats = 16 * 64 * 4;  // exchange buffer of one column group: 16 row tiles x 64 lanes x 4 floats = 16 KiB
 constexpr int kStepFloats = 4 * 256;      // one fp32 K-step of 16 row tiles in the packed stream (gw_pack_linear)
 
-constexpr bool rs_overlay(int cg) { return cg * kXbufFloats <= kLdsBufFloats; }
-constexpr int rs_lds_bytes(int cg) { return (2 * kLdsBufFloats + (rs_overlay(cg) ? 0 : cg * kXbufFloats) + 2 * cg * 64) * 4; }
+// Weight chunks: 64 KiB (16 fp32 K-steps / 2 bf16x3 K-steps of all 16 row tiles), double buffered - half the hand-overs of the
+// 32 KiB chunks of the 64-column kernels: with 12 waves behind one barrier every hand-over idles the matrix pipes for ~1.5 k
+// cycles (barrier, LDS latency of the first fragments, the oldest wave of a SIMD finishing first), and a bf16x3 chunk of one
+// K-step is only 576 cycles of MFMAs per SIMD.  The exchange buffer always lies over the buffer that is free between two passes.
+constexpr int kRsBufFloats = 2 * kLdsBufFloats;  // 64 KiB
+constexpr int kRsSteps = 2 * kChunkSteps;        // fp32 K-steps per chunk
+constexpr int rs_lds_bytes(int) { return 2 * kRsBufFloats * 4; }
 
+// round i of a wave's DMA pieces of a 64 KiB chunk (piece wave + i NW of 64), issued from between the MFMA groups of a pass;
+// src == nullptr: nothing follows.  Only a last, partial round tests the wave index (12 waves: pieces 60 .. 63).
+constexpr int rs_rounds(int nw) { return (64 + nw - 1) / nw; }
 template <int NW>
-__device__ __forceinline__ void issue_chunk_nw(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
-  const int npieces = nfloats >> 8;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf;
-  for (int p = wave; p < npieces; p += NW)
-    glds16_asm_s(g + (size_t)p * 256, (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)p * 1024u));
+__device__ __forceinline__ void issue_piece64(const char* __restrict__ src, unsigned lds0, int i, int lane, int wave) {
+  const int pc = wave + i * NW;
+  if ((i + 1) * NW <= 64 || pc < 64)
+    glds16_asm_s((const float*)(src + (size_t)pc * 1024), (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)pc * 1024u));
+}
+// the rounds due behind unit u of a chunk whose first `span` units carry the DMA (compile-time after unrolling)
+template <int NW>
+__device__ __forceinline__ void issue_due(const char* __restrict__ src, bool go, unsigned lds0, int u, int span, int lane, int wave) {
+  constexpr int R = rs_rounds(NW);
+  if (u >= span) return;
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (i >= u * R / span && i < (u + 1) * R / span)
+      if (go) issue_piece64<NW>(src, lds0, i, lane, wave);
+}
+
+// Every wave DMAs its share of one 64 KiB chunk (64 pieces of 1 KiB) of a packed weight stream into an LDS buffer.  The trip
+// count is a compile-time constant and only a last, partial round tests the wave index (12 waves: pieces 60 .. 63) - no loop
+// branch inside the matrix passes.
+template <int NW>
+__device__ __forceinline__ void issue_chunk64(const char* __restrict__ g, const void* ldsbuf, int lane, int wave) {
+  constexpr int NP = 64;
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)ldsbuf;
+#pragma unroll
+  for (int i = 0; i < (NP + NW - 1) / NW; ++i) {
+    const int pc = wave + i * NW;
+    if ((i + 1) * NW <= NP || pc < NP)
+      glds16_asm_s((const float*)(g + (size_t)pc * 1024), (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)pc * 1024u));
+  }
 }
 
 __device__ __forceinline__ const float* operand_row(const float* ptr, const int* idx, int rows_pb, int ld, int b, int k) {
@@ -79,36 +160,50 @@ __device__ __forceinline__ RsWave rs_wave(const ChainArgs& a) {
   return w;
 }
 
-// LayerNorm over the 256 features of each column (eps 1e-5, biased variance), residual, store of this wave's quarter, zero fill
-// of the next aggregate: the quarter sums of a column meet in LDS and are added in the order r = 0 .. 3 by every wave
-template <int CG>
-__device__ __forceinline__ void rs_epilogue(const ChainArgs& a, const RsWave& w, f32x4 (&o)[4], const f32x4 (&rres)[4], float* stat) {
-  const int r = w.r, q = w.q, j = w.j;
+// LayerNorm (eps 1e-5, biased variance) + residual + store of this wave's quarter (+ zero fill of the next aggregate).
+// `full` holds the pre-LayerNorm row of ALL sixteen row tiles (exchanged through LDS): every wave of a column group computes
+// the statistics itself, in the order of the 64-column kernels (X3: chainx3_kernel's expressions, else chain_kernel's) - the new
+// rows are bitwise those of the other kernel form, so a checkpointed segment replayed on it sees the values of its first run.
+// Returns mean / rstd for rs_full_tile (the B operand of the POST products).
+template <bool X3>
+__device__ __forceinline__ void rs_epilogue(const ChainArgs& a, const RsWave& w, f32x4 (&o)[4], const f32x4 (&rres)[4], const float (&full)[64],
+                                            float& mean_out, float& rstd_out) {
+  const int r = w.r, q = w.q;
+  float mean = 0.f, rstd = 1.f;
   if (a.gamma != nullptr) {
+    const int nfeat = a.ln_width;
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s += (o[t].x + o[t].y) + (o[t].z + o[t].w);
+    for (int t = 0; t < 16; ++t) s += (full[4 * t] + full[4 * t + 1]) + (full[4 * t + 2] + full[4 * t + 3]);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    float* st0 = stat + (w.g * 4) * 16;
-    float* st1 = stat + (CG * 4 + w.g * 4) * 16;
-    if (q == 0) st0[r * 16 + j] = s;
-    __syncthreads();
-    const float mean = ((st0[j] + st0[16 + j]) + (st0[32 + j] + st0[48 + j])) * (1.0f / 256.0f);
-    float v = 0.f;
+    float v = 0.f, inv_n;
+    if (X3) {
+      inv_n = 1.0f / (float)nfeat;
+      const bool all = nfeat == 256;
+      mean = s * inv_n;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 16; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float d = o[t][i] - mean;
-        v += d * d;
-      }
+        for (int i = 0; i < 4; ++i) {
+          const float d = full[4 * t + i] - mean;
+          v += (all || 16 * t + 4 * q + i < nfeat) ? d * d : 0.f;
+        }
+    } else {
+      const bool narrow = nfeat != 256;
+      inv_n = narrow ? 1.0f / (float)nfeat : 1.0f / 256;
+      mean = s * inv_n;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = (narrow && 16 * t + 4 * q + i >= nfeat) ? 0.f : full[4 * t + i] - mean;
+          v += d * d;
+        }
+    }
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (q == 0) st1[r * 16 + j] = v;
-    __syncthreads();
-    const float var = ((st1[j] + st1[16 + j]) + (st1[32 + j] + st1[48 + j])) * (1.0f / 256.0f);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x4 gm = ldg4(a.gamma + 16 * (4 * r + t) + 4 * q);
@@ -131,14 +226,30 @@ __device__ __forceinline__ void rs_epilogue(const ChainArgs& a, const RsWave& w,
       for (int t = 0; t < 4; ++t) stg4(zrow + 16 * (4 * r + t) + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
     }
   }
+  mean_out = mean;
+  rstd_out = rstd;
+}
+
+// Row tile t of the whole new row (LayerNorm + residual of the pre-LayerNorm values every wave holds): the B operand of the POST
+// products, recomputed by each wave from the same values with the same expressions as the quarter's owner - bitwise its row.
+__device__ __forceinline__ f32x4 rs_full_tile(const ChainArgs& a, const RsWave& w, f32x4 v, int t, float mean, float rstd, const float* rrow) {
+  if (a.gamma != nullptr) {
+    const f32x4 gm = ldg4(a.gamma + 16 * t + 4 * w.q);
+    const f32x4 bt = ldg4(a.beta + 16 * t + 4 * w.q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gm[i] + bt[i];
+  }
+  if (rrow != nullptr) v += ldg4(rrow + 16 * t + 4 * w.q);
+  return v;
 }
 
 // ================================================ fp32 (arithmetic of chain_kernel) ================================================
 
-// in[8c .. 8c+7] <- row[k(s, q)] for the K-steps of chunk c (k(s, q) = 16 (s >> 2) + 4 q + (s & 3))
-__device__ __forceinline__ void load_slice(float (&in)[64], const float* __restrict__ row, int c, int q) {
+// (k(s, q) = 16 (s >> 2) + 4 q + (s & 3))
+// in[16c .. 16c+15] <- row[k(s, q)] for the K-steps of chunk c
+__device__ __forceinline__ void load_slice16(float (&in)[64], const float* __restrict__ row, int c, int q) {
 #pragma unroll
-  for (int i = 2 * c; i < 2 * c + 2; ++i) {
+  for (int i = 4 * c; i < 4 * c + 4; ++i) {
     const f32x4 v = ldg4(row + 16 * i + 4 * q);
     in[4 * i + 0] = v.x;
     in[4 * i + 1] = v.y;
@@ -147,41 +258,44 @@ __device__ __forceinline__ void load_slice(float (&in)[64], const float* __restr
   }
 }
 
-// One 256-deep pass of this wave's four row tiles: acc[t] += W[16 (4r + t) .., k] . in[k].  Protocol of chain_kernel's mma_pass:
-// the first chunk of the pass is already on its way into buffer `parity`; the first chunk of the next pass is issued while the
-// last one computes.  RELOAD: the 8 operand registers a chunk has consumed are refilled, one chunk later, with the same K slice
-// of the next layer-1 operand (`next_row`); the slice the previous pass consumed last is refilled during chunk 0 (`tail_row`).
+// One 256-deep pass of this wave's four row tiles: acc[t] += W[16 (4r + t) .., k] . in[k], four chunks of 16 K-steps.
+// Protocol of chain_kernel's mma_pass: the first chunk of the pass is already on its way into buffer `parity`; the first chunk
+// of the next pass is issued while the last one computes.  Behind the barrier a wave first requests its first fragment, THEN
+// issues its DMA pieces (each blocks the wave for 60 - 180 cycles: the fragment's LDS latency hides under them).
+// RELOAD: the 16 operand registers a chunk has consumed are refilled, one chunk later, with the same K slice of the next
+// layer-1 operand (`next_row`); the slice the previous pass consumed last is refilled during chunk 0 (`tail_row`).
 template <int NW, bool RELOAD>
 __device__ __forceinline__ void rs_pass(f32x4 (&acc)[4], float (&in)[64], const float* __restrict__ gw, const float* __restrict__ next_gw,
                                         float* lds, int& parity, int lane, int wave, int r, const float* __restrict__ tail_row, bool do_tail,
-                                        const float* __restrict__ next_row, bool do_next, int q) {
+                                        const float* __restrict__ next_row, bool do_next, int q, unsigned long long* waited = nullptr) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // chunk c has landed for every wave; nobody still reads the other buffer (weights or exchanged rows)
-    float* other = lds + (parity ^ 1) * kLdsBufFloats;
-    if (c + 1 < 8)
-      issue_chunk_nw<NW>(gw + (size_t)(c + 1) * kChunkSteps * kStepFloats, kChunkSteps * kStepFloats, other, lane, wave);
-    else if (next_gw != nullptr)
-      issue_chunk_nw<NW>(next_gw, kChunkSteps * kStepFloats, other, lane, wave);
+  for (int c = 0; c < 4; ++c) {
+    RS_WAIT_BARRIER();  // chunk c has landed for every wave; nobody still reads the other buffer (weights or exchanged rows)
+    const float* buf = lds + parity * kRsBufFloats + r * 256 + lane * 4;
+    f32x4 a_cur = *(const f32x4*)buf;
+    const char* nsrc = c + 1 < 4 ? (const char*)(gw + (size_t)(c + 1) * kRsSteps * kStepFloats) : (const char*)next_gw;
+    const bool go = c + 1 < 4 || next_gw != nullptr;  // (inside a pass: a compile-time constant, no branch)
+    const unsigned nlds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + (parity ^ 1) * kRsBufFloats);
     if (RELOAD) {
       if (c == 0) {
-        if (do_tail) load_slice(in, tail_row, 7, q);
+        if (do_tail) load_slice16(in, tail_row, 3, q);
       } else if (do_next) {
-        load_slice(in, next_row, c - 1, q);
+        load_slice16(in, next_row, c - 1, q);
       }
     }
-    const float* buf = lds + parity * kLdsBufFloats + r * 256 + lane * 4;
-    f32x4 a_cur = *(const f32x4*)buf;
 #pragma unroll
-    for (int s = 0; s < kChunkSteps; ++s) {
+    for (int s = 0; s < kRsSteps; ++s) {
       f32x4 a_nxt = a_cur;
-      if (s + 1 < kChunkSteps) a_nxt = *(const f32x4*)(buf + (s + 1) * kStepFloats);
-      const float b = in[c * kChunkSteps + s];
+      if (s + 1 < kRsSteps) a_nxt = *(const f32x4*)(buf + (s + 1) * kStepFloats);
+      const float b = in[c * kRsSteps + s];
       __builtin_amdgcn_sched_barrier(0);  // the LDS read of step s + 1 stays ahead of the MFMAs of step s
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b, acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // this wave's DMA pieces of the next chunk, spread over the first three quarters of the chunk's K-steps: an issue blocks
+      // the wave for 60 - 180 cycles - spread out, the other waves of the SIMD own the matrix pipe meanwhile (all pieces right
+      // behind the barrier: every wave of the SIMD blocked at once, ~800 idle cycles per chunk)
+      issue_due<NW>(nsrc, go, nlds, s, 12, lane, wave);
       a_cur = a_nxt;
     }
     parity ^= 1;
@@ -190,10 +304,10 @@ __device__ __forceinline__ void rs_pass(f32x4 (&acc)[4], float (&in)[64], const 
 
 // The four waves of a column group publish their quarter of a layer's output (RELU: its relu) and every wave reads the
 // whole 256-feature B operand of the next layer back: in[4 T + i] = value of row tile T, register i of this lane.
-// OVERLAY: xg lies in the weight buffer the pass has just finished with - slower waves may still be reading its last chunk.
-template <bool RELU, bool OVERLAY>
+// xg lies in the weight buffer the pass has just finished with - slower waves may still be reading its last chunk.
+template <bool RELU>
 __device__ __forceinline__ void exchange(float (&in)[64], const f32x4 (&acc)[4], float* xg, int r, int lane) {
-  if (OVERLAY) __syncthreads();
+  __syncthreads();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     f32x4 v = acc[t];
@@ -214,19 +328,24 @@ __device__ __forceinline__ void exchange(float (&in)[64], const f32x4 (&acc)[4],
 template <int CG>
 __global__ __launch_bounds__(CG * 256, CG) void node_rs_kernel(const ChainArgs a) {
   constexpr int NW = 4 * CG;
-  constexpr bool OV = rs_overlay(CG);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xfix = lds + 2 * kLdsBufFloats;                       // the exchange buffer when it has its own LDS (CG = 3)
-  float* stat = xfix + (OV ? 0 : CG * kXbufFloats);            // [2][CG][4][16]: partial LayerNorm sums of the row quarters
   const RsWave w = rs_wave<CG>(a);
   const int lane = w.lane, wave = w.wave, r = w.r, q = w.q;
   int parity = 0;
-  // exchange buffer of this wave's column group: over the weight buffer the finished pass consumed last (OV), or its own
-  auto xg = [&]() -> float* { return (OV ? lds + (parity ^ 1) * kLdsBufFloats : xfix) + w.g * kXbufFloats; };
+  RS_CLOCKS
+  RS_STAMP(0)
+  // exchange buffer of this wave's column group: over the weight buffer the finished pass consumed last
+  auto xg = [&]() -> float* { return lds + (parity ^ 1) * kRsBufFloats + w.g * kXbufFloats; };
 
   const bool raw0 = a.seg_k[0] > 0 && a.seg_proj[0] == 0;  // x . Wx^T is a matrix pass
   const bool prj0 = a.seg_k[0] > 0 && a.seg_proj[0] != 0;  // ... or a cached product row (gather-add); neither: x == 0
-  issue_chunk_nw<NW>(raw0 ? a.w1[0] : a.w1[1], kChunkSteps * kStepFloats, lds, lane, wave);
+  issue_chunk64<NW>((const char*)(raw0 ? a.w1[0] : a.w1[1]), lds, lane, wave);
+  if (!(RS_TUNE(a) & 1)) {  // the rest of the stream into this XCD's L2 (gw_device.hpp); scratch: the second weight buffer, free until the first barrier
+    const char* mats[8] = {(const char*)(raw0 ? a.w1[0] : a.w1[1]), (const char*)(raw0 ? a.w1[1] : nullptr), (const char*)a.w_mid,
+                           (const char*)a.w_out, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < a.n_post && i < 4; ++i) mats[4 + i] = (const char*)a.proj_w[i];
+    l2_prefetch_stream(mats, 8, lane, wave, (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + kRsBufFloats));
+  }
 
   const float* arow = operand_row(a.seg_ptr[1], a.seg_idx[1], a.seg_rows_pb[1], a.seg_ld[1], w.b, w.k);
   float in[64];
@@ -238,28 +357,35 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs_kernel(const ChainArgs a
   if (raw0) {  // the aggregate rows stream in under the pass of x
     const float* xrow = operand_row(a.seg_ptr[0], a.seg_idx[0], a.seg_rows_pb[0], a.seg_ld[0], w.b, w.k);
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) load_slice(in, xrow, cc, q);
+    for (int cc = 0; cc < 4; ++cc) load_slice16(in, xrow, cc, q);
     rs_pass<NW, true>(acc, in, a.w1[0], a.w1[1], lds, parity, lane, wave, r, nullptr, false, arow, true, q);
     rs_pass<NW, true>(acc, in, a.w1[1], a.w_mid, lds, parity, lane, wave, r, arow, true, nullptr, false, q);
   } else {
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) load_slice(in, arow, cc, q);
-    if (prj0) {
+    for (int cc = 0; cc < 4; ++cc) load_slice16(in, arow, cc, q);
+    f32x4 pr[4];
+    if (prj0) {  // the cached product rows: requested under the pass, added behind it as chain_kernel does ((b1 + agg . Wa^T) + P)
       const float* prow = operand_row(a.seg_ptr[0], a.seg_idx[0], a.seg_rows_pb[0], a.seg_ld[0], w.b, w.k);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] += ldg4(prow + 16 * (4 * r + t) + 4 * q);
+      for (int t = 0; t < 4; ++t) pr[t] = ldg4(prow + 16 * (4 * r + t) + 4 * q);
     }
     rs_pass<NW, false>(acc, in, a.w1[1], a.w_mid, lds, parity, lane, wave, r, nullptr, false, nullptr, false, q);
+    if (prj0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] += pr[t];
+    }
   }
 
+  RS_STAMP(1)
   // ---- middle layer ----
-  exchange<true, OV>(in, acc, xg(), r, lane);
+  exchange<true>(in, acc, xg(), r, lane);
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = ldg4(a.b_mid + 16 * (4 * r + t) + 4 * q);
-  rs_pass<NW, false>(acc, in, a.w_mid, a.w_out, lds, parity, lane, wave, r, nullptr, false, nullptr, false, q);
+  rs_pass<NW, false>(acc, in, a.w_mid, a.w_out, lds, parity, lane, wave, r, nullptr, false, nullptr, false, q, RS_WAITED);
+  RS_STAMP(2)
 
   // ---- output layer (the residual rows are requested underneath it) ----
-  exchange<true, OV>(in, acc, xg(), r, lane);
+  exchange<true>(in, acc, xg(), r, lane);
   f32x4 o[4], rres[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) o[t] = ldg4(a.b_out + 16 * (4 * r + t) + 4 * q);
@@ -268,13 +394,29 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs_kernel(const ChainArgs a
 #pragma unroll
     for (int t = 0; t < 4; ++t) rres[t] = ldg4(rrow + 16 * (4 * r + t) + 4 * q);
   }
-  rs_pass<NW, false>(o, in, a.w_out, a.n_post > 0 ? a.proj_w[0] : nullptr, lds, parity, lane, wave, r, nullptr, false, nullptr, false, q);
+  rs_pass<NW, false>(o, in, a.w_out, a.n_post > 0 ? a.proj_w[0] : nullptr, lds, parity, lane, wave, r, nullptr, false, nullptr, false, q,
+                     RS_WAITED);
+  RS_STAMP(3)
 
-  rs_epilogue<CG>(a, w, o, rres, stat);
+  // ---- LayerNorm + residual + store; the whole pre-LayerNorm row travels through LDS once (statistics, POST operand) ----
+  if (a.gamma != nullptr || a.n_post > 0) exchange<false>(in, o, xg(), r, lane);
+  float mean, rstd;
+  rs_epilogue<false>(a, w, o, rres, in, mean, rstd);
+  if (a.n_post > 0) {  // the whole new row in registers
+    const float* rrow = a.res_ptr != nullptr ? operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, w.b, w.k) : nullptr;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const f32x4 v = rs_full_tile(a, w, f32x4{in[4 * t], in[4 * t + 1], in[4 * t + 2], in[4 * t + 3]}, t, mean, rstd, rrow);
+      in[4 * t + 0] = v.x;
+      in[4 * t + 1] = v.y;
+      in[4 * t + 2] = v.z;
+      in[4 * t + 3] = v.w;
+    }
+  }
+  RS_STAMP(4)
 
   // ---- POST: the next block's layer-1 products of the new rows (ChainArgs) ----
   if (a.n_post > 0) {
-    exchange<false, OV>(in, o, xg(), r, lane);
 #pragma unroll 1
     for (int sl = 0; sl < a.n_post; ++sl) {
       f32x4 pacc[4];
@@ -289,6 +431,8 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs_kernel(const ChainArgs a
       }
     }
   }
+  RS_STAMP(5)
+  RS_RECORD
 }
 
 // ============================== bf16x3: split operands on v_mfma_f32_16x16x32_bf16 (arithmetic of gw_split.hip) ==============================
@@ -297,14 +441,8 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs_kernel(const ChainArgs a
 // split(acc[2s], acc[2s + 1]) of the layer before, so row quarter r owns K-steps 2r, 2r + 1 of the next operand.
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kStepBytes3 = 32768;
-
-template <int NW>
-__device__ __forceinline__ void issue_bytes_nw(const char* __restrict__ g, char* ldsbuf, int lane, int wave) {
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsbuf;
-  for (int p = wave; p < 32; p += NW)
-    glds16_asm_s((const float*)(g + (size_t)p * 1024), (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)p * 1024u));
-}
+constexpr int kStepBytes3 = 32768;       // one K-step: hi + lo fragments of the 16 row tiles
+constexpr int kChunkBytes3 = 2 * kStepBytes3;  // one chunk buffer
 
 __device__ __forceinline__ void split8(f32x4 a, f32x4 b, bf16x8& h, bf16x8& l) {
 #pragma unroll
@@ -324,67 +462,60 @@ __device__ __forceinline__ void load_slice3(bf16x8& h, bf16x8& l, const float* _
   split8(ldg4(row + 32 * s + 4 * q), ldg4(row + 32 * s + 16 + 4 * q), h, l);
 }
 
-// One 256-deep pass: 8 chunks of one K-step; this wave reads the hi / lo fragments of its four row tiles (8 x 1 KiB) and issues
-// 12 MFMAs per chunk, term-major (hi.hi, hi.lo, lo.hi: two other tiles' MFMAs between two on the same accumulator).
-// RELOAD as in rs_pass: K-step c - 1 of the next raw operand replaces the registers chunk c - 1 consumed.
-template <int NW, bool RELOAD>
-__device__ __forceinline__ void rs3_pass(f32x4 (&acc)[4], bf16x8 (&bh)[8], bf16x8 (&bl)[8], const char* __restrict__ gw,
+// One 256-deep pass: 4 chunks of two K-steps (64 KiB); per K-step this wave reads the hi / lo fragments of its four row tiles
+// (8 x 1 KiB) and issues 12 MFMAs, term-major (hi.hi, hi.lo, lo.hi: the other tiles' MFMAs between two on one accumulator).
+// Behind the barrier the first K-step's fragments are requested BEFORE the wave's DMA pieces of the next chunk are issued.
+template <int NW>
+__device__ __forceinline__ void rs3_pass(f32x4 (&acc)[4], const bf16x8 (&bh)[8], const bf16x8 (&bl)[8], const char* __restrict__ gw,
                                          const char* __restrict__ next_gw, char* lds, int& parity, int lane, int wave, int r,
-                                         const float* __restrict__ tail_row, bool do_tail, const float* __restrict__ next_row, bool do_next,
-                                         int q) {
+                                         unsigned long long* waited = nullptr) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    char* other = lds + (parity ^ 1) * kStepBytes3;
-    if (c + 1 < 8)
-      issue_bytes_nw<NW>(gw + (size_t)(c + 1) * kStepBytes3, other, lane, wave);
-    else if (next_gw != nullptr)
-      issue_bytes_nw<NW>(next_gw, other, lane, wave);
-    f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
-    const float* rrow = nullptr;
-    int slot = 0;
-    if (RELOAD) {
-      if (c == 0) {
-        if (do_tail) { rrow = tail_row; slot = 7; }
-      } else if (do_next) {
-        rrow = next_row;
-        slot = c - 1;
-      }
-      if (rrow != nullptr) {
-        t0 = ldg4(rrow + 32 * slot + 4 * q);
-        t1 = ldg4(rrow + 32 * slot + 16 + 4 * q);
-      }
-    }
-    const char* buf = lds + parity * kStepBytes3 + (4 * r) * 1024 + lane * 16;
-    bf16x8 ah[4], al[4];
+  for (int c = 0; c < 4; ++c) {
+    RS_WAIT_BARRIER();
+    const char* buf = lds + parity * kChunkBytes3 + (4 * r) * 1024 + lane * 16;
+    // fragments in flight: hi + lo of this K-step and hi of the next (48 registers); lo of the next follows once hi is spent.
+    // The wave's DMA pieces of the next chunk go out behind the first four of the six MFMA groups (see rs_pass).
+    const char* nsrc = c + 1 < 4 ? gw + (size_t)(c + 1) * kChunkBytes3 : next_gw;
+    const bool go = c + 1 < 4 || next_gw != nullptr;
+    const unsigned nlds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + (parity ^ 1) * kChunkBytes3);
+    bf16x8 h0[4], l0[4], h1[4], l1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ah[t] = *(const bf16x8*)(buf + t * 1024);
+    for (int t = 0; t < 4; ++t) h0[t] = *(const bf16x8*)(buf + t * 1024);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) al[t] = *(const bf16x8*)(buf + 16384 + t * 1024);
+    for (int t = 0; t < 4; ++t) l0[t] = *(const bf16x8*)(buf + 16384 + t * 1024);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = *(const bf16x8*)(buf + kStepBytes3 + t * 1024);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh[c], acc[t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0[t], bh[2 * c], acc[t], 0, 0, 0);
+    issue_due<NW>(nsrc, go, nlds, 0, 4, lane, wave);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl[c], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh[c], acc[t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0[t], bl[2 * c], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (RELOAD) {
-      if (rrow != nullptr) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-          if (s == slot) split8(t0, t1, bh[s], bl[s]);
-      }
-    }
+    for (int t = 0; t < 4; ++t) l1[t] = *(const bf16x8*)(buf + kStepBytes3 + 16384 + t * 1024);
+    issue_due<NW>(nsrc, go, nlds, 1, 4, lane, wave);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0[t], bh[2 * c], acc[t], 0, 0, 0);
+    issue_due<NW>(nsrc, go, nlds, 2, 4, lane, wave);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1[t], bh[2 * c + 1], acc[t], 0, 0, 0);
+    issue_due<NW>(nsrc, go, nlds, 3, 4, lane, wave);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1[t], bl[2 * c + 1], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1[t], bh[2 * c + 1], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     parity ^= 1;
   }
 }
 
 // exchange of the split activations: row quarter r publishes K-steps 2r, 2r + 1 (hi, lo), every wave reads all eight back
-template <bool RELU, bool OVERLAY>
+// (xg lies over the weight buffer the finished pass consumed last: slower waves may still be reading it)
+template <bool RELU>
 __device__ __forceinline__ void exchange3(bf16x8 (&bh)[8], bf16x8 (&bl)[8], const f32x4 (&acc)[4], char* xg, int r, int lane) {
-  if (OVERLAY) __syncthreads();
+  __syncthreads();
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     bf16x8 h, l;
@@ -407,14 +538,13 @@ __device__ __forceinline__ void exchange3(bf16x8 (&bh)[8], bf16x8 (&bl)[8], cons
 template <int CG>
 __global__ __launch_bounds__(CG * 256, CG) void node_rs3_kernel(const ChainArgs a) {
   constexpr int NW = 4 * CG;
-  constexpr bool OV = rs_overlay(CG);
   extern __shared__ __attribute__((aligned(16))) char lds3[];
-  char* xfix = lds3 + 2 * kStepBytes3;
-  float* stat = (float*)(xfix + (OV ? 0 : CG * kXbufFloats * 4));
   const RsWave w = rs_wave<CG>(a);
   const int lane = w.lane, wave = w.wave, r = w.r, q = w.q;
   int parity = 0;
-  auto xg = [&]() -> char* { return (OV ? lds3 + (parity ^ 1) * kStepBytes3 : xfix) + w.g * (kXbufFloats * 4); };
+  RS_CLOCKS
+  RS_STAMP(0)
+  auto xg = [&]() -> char* { return lds3 + (parity ^ 1) * kChunkBytes3 + w.g * (kXbufFloats * 4); };
 
   const bool raw0 = a.seg_k[0] > 0 && a.seg_proj[0] == 0;
   const bool prj0 = a.seg_k[0] > 0 && a.seg_proj[0] != 0;
@@ -422,7 +552,12 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs3_kernel(const ChainArgs 
   const char* w1a = (const char*)a.w1[1];
   const char* w_mid = (const char*)a.w_mid;
   const char* w_out = (const char*)a.w_out;
-  issue_bytes_nw<NW>(raw0 ? w1x : w1a, lds3, lane, wave);
+  issue_chunk64<NW>(raw0 ? w1x : w1a, lds3, lane, wave);
+  if (!(RS_TUNE(a) & 1)) {  // the rest of the stream into this XCD's L2 (gw_device.hpp); scratch: the second weight buffer, free until the first barrier
+    const char* mats[8] = {raw0 ? w1x : w1a, raw0 ? w1a : nullptr, w_mid, w_out, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < a.n_post && i < 4; ++i) mats[4 + i] = (const char*)a.proj_w[i];
+    l2_prefetch_stream(mats, 8, lane, wave, (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds3 + kChunkBytes3));
+  }
 
   const float* arow = operand_row(a.seg_ptr[1], a.seg_idx[1], a.seg_rows_pb[1], a.seg_ld[1], w.b, w.k);
   bf16x8 bh[8], bl[8];
@@ -434,47 +569,61 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs3_kernel(const ChainArgs 
     const float* xrow = operand_row(a.seg_ptr[0], a.seg_idx[0], a.seg_rows_pb[0], a.seg_ld[0], w.b, w.k);
 #pragma unroll
     for (int s = 0; s < 8; ++s) load_slice3(bh[s], bl[s], xrow, s, q);
-    rs3_pass<NW, true>(acc, bh, bl, w1x, w1a, lds3, parity, lane, wave, r, nullptr, false, arow, true, q);
-    rs3_pass<NW, true>(acc, bh, bl, w1a, w_mid, lds3, parity, lane, wave, r, arow, true, nullptr, false, q);
-  } else {
+    rs3_pass<NW>(acc, bh, bl, w1x, w1a, lds3, parity, lane, wave, r);
+  } else if (prj0) {  // chainx3_kernel adds the product rows in front of the matrix passes: (b1 + P) + agg . Wa^T
+    const float* prow = operand_row(a.seg_ptr[0], a.seg_idx[0], a.seg_rows_pb[0], a.seg_ld[0], w.b, w.k);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) load_slice3(bh[s], bl[s], arow, s, q);
-    if (prj0) {
-      const float* prow = operand_row(a.seg_ptr[0], a.seg_idx[0], a.seg_rows_pb[0], a.seg_ld[0], w.b, w.k);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] += ldg4(prow + 16 * (4 * r + t) + 4 * q);
-    }
-    rs3_pass<NW, false>(acc, bh, bl, w1a, w_mid, lds3, parity, lane, wave, r, nullptr, false, nullptr, false, q);
+    for (int t = 0; t < 4; ++t) acc[t] += ldg4(prow + 16 * (4 * r + t) + 4 * q);
   }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) load_slice3(bh[s], bl[s], arow, s, q);
+  rs3_pass<NW>(acc, bh, bl, w1a, w_mid, lds3, parity, lane, wave, r);
 
-  exchange3<true, OV>(bh, bl, acc, xg(), r, lane);
+  RS_STAMP(1)
+  exchange3<true>(bh, bl, acc, xg(), r, lane);
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = ldg4(a.b_mid + 16 * (4 * r + t) + 4 * q);
-  rs3_pass<NW, false>(acc, bh, bl, w_mid, w_out, lds3, parity, lane, wave, r, nullptr, false, nullptr, false, q);
+  rs3_pass<NW>(acc, bh, bl, w_mid, w_out, lds3, parity, lane, wave, r, RS_WAITED);
+  RS_STAMP(2)
 
-  exchange3<true, OV>(bh, bl, acc, xg(), r, lane);
+  exchange3<true>(bh, bl, acc, xg(), r, lane);
   f32x4 o[4], rres[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) o[t] = ldg4(a.b_out + 16 * (4 * r + t) + 4 * q);
-  if (a.res_ptr != nullptr) {
+  rs3_pass<NW>(o, bh, bl, w_out, a.n_post > 0 ? (const char*)a.proj_w[0] : nullptr, lds3, parity, lane, wave, r, RS_WAITED);
+  RS_STAMP(3)
+  if (a.res_ptr != nullptr) {  // (requested here, not under the pass: 16 registers the pass does not have at three waves per SIMD)
     const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, w.b, w.k);
 #pragma unroll
     for (int t = 0; t < 4; ++t) rres[t] = ldg4(rrow + 16 * (4 * r + t) + 4 * q);
   }
-  rs3_pass<NW, false>(o, bh, bl, w_out, a.n_post > 0 ? (const char*)a.proj_w[0] : nullptr, lds3, parity, lane, wave, r, nullptr, false,
-                      nullptr, false, q);
 
-  rs_epilogue<CG>(a, w, o, rres, stat);
+  {
+    float full[64];
+    if (a.gamma != nullptr || a.n_post > 0) exchange<false>(full, o, (float*)xg(), r, lane);
+    float mean, rstd;
+    rs_epilogue<true>(a, w, o, rres, full, mean, rstd);
+    if (a.n_post > 0) {  // the whole new row as the split B operand of the POST products, one K-step (two row tiles) at a time
+      const float* rrow = a.res_ptr != nullptr ? operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, w.b, w.k) : nullptr;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const f32x4 v0 = rs_full_tile(a, w, f32x4{full[8 * s8], full[8 * s8 + 1], full[8 * s8 + 2], full[8 * s8 + 3]}, 2 * s8, mean, rstd, rrow);
+        const f32x4 v1 =
+            rs_full_tile(a, w, f32x4{full[8 * s8 + 4], full[8 * s8 + 5], full[8 * s8 + 6], full[8 * s8 + 7]}, 2 * s8 + 1, mean, rstd, rrow);
+        split8(v0, v1, bh[s8], bl[s8]);
+      }
+    }
+  }
+  RS_STAMP(4)
 
   if (a.n_post > 0) {
-    exchange3<false, OV>(bh, bl, o, xg(), r, lane);
 #pragma unroll 1
     for (int sl = 0; sl < a.n_post; ++sl) {
       f32x4 pacc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const char* nx = sl + 1 < a.n_post ? (const char*)a.proj_w[sl + 1] : nullptr;
-      rs3_pass<NW, false>(pacc, bh, bl, (const char*)a.proj_w[sl], nx, lds3, parity, lane, wave, r, nullptr, false, nullptr, false, q);
+      rs3_pass<NW>(pacc, bh, bl, (const char*)a.proj_w[sl], nx, lds3, parity, lane, wave, r);
       if (w.valid) {
         float* prow = a.proj_out[sl] + (size_t)w.c * 256;
 #pragma unroll
@@ -482,6 +631,8 @@ __global__ __launch_bounds__(CG * 256, CG) void node_rs3_kernel(const ChainArgs 
       }
     }
   }
+  RS_STAMP(5)
+  RS_RECORD
 }
 
 template <int CG, bool X3>
@@ -531,6 +682,14 @@ bool node_rs_eligible(const ChainArgs& a) {
 
 int node_rs_launch(ChainArgs& a, bool x3, void* stream) {
   const int cg = node_rs_groups(a.n_cols);
+#ifdef GW_TUNING
+  if (g_dbg != nullptr && (g_dbg_kind == 2 || g_dbg_kind == 4)) {  // gw_debug_timestamps: node updates
+    a.dbg = g_dbg;
+    a.dbg_cap = g_dbg_cap;
+  }
+  static const int rs_tune = GW_TUNE("GW_RS_TUNE", 0);
+  a.tune16 = rs_tune;
+#endif
   if (x3) {
     switch (cg) {
       case 1: return launch_rs<1, true>(a, stream);
