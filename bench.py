@@ -50,6 +50,8 @@ CONFIGS = {
     "c3x3": dict(grid=1.0, resolution=2, batch=16, precision="bf16x3"),  # c3's batch with split-operand products
     "c4": dict(grid=1.0, resolution=2, batch=64, precision="fp32"),  # global batch, sharded over the ranks
     "c5": dict(grid=0.25, resolution=3, batch=1, precision="fp32"),
+    "c4g": dict(grid=1.0, resolution=2, batch=8, precision="fp32"),      # what ONE GPU carries of c4 at N = 8
+    "c4gx3": dict(grid=1.0, resolution=2, batch=8, precision="bf16x3"),
 }
 
 
@@ -178,6 +180,29 @@ def pmc_traffic(cfg="c2"):
     return None, None, None
 
 
+def pmc_kernel_traffic(cfg, name_prefixes, grid_threads):
+    """HBM bytes per launch of ONE kernel instantiation at ONE grid size from the newest committed per-kernel PMC summary of the
+    workload (profiles/rNN_pmc_<cfg>_all_kernels.json, scripts/gpu_pmc_cfg.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes).
+    Returns (bytes, file name, mfma_busy_frac) or (None, None, None)."""
+    import glob
+
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s_all_kernels.json" % cfg)), reverse=True):
+        try:
+            d = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            name, _, grid = k.rpartition(" grid=")
+            try:
+                g = int(float(grid))
+            except ValueError:
+                continue
+            if g == grid_threads and name.startswith(tuple(name_prefixes)) and v.get("hbm_read_bytes") is not None \
+                    and v.get("hbm_write_bytes") is not None:
+                return v["hbm_read_bytes"] + v["hbm_write_bytes"], os.path.basename(p), v.get("mfma_busy_frac")
+    return None, None, None
+
+
 def pmc_c3_traffic():
     """Counter traffic (bytes per launch) of the bf16 kernels at C3 from the tracked per-kernel PMC summary: the newest of
     profiles/r04_pmc_c3.json / r03_pmc_c3.json / r02_pmc_c3_edge16_v2.json.  Returns ({"processor_block": bytes, "decoder": bytes}, file)."""
@@ -211,8 +236,14 @@ def build_model(cfg, dev):
     return model, lat_lons
 
 
+DEFAULT_PATH_NOTE = ("model(features) in eval() under torch.no_grad(), as a caller writes it: from the third call of a shape on "
+                     "graph_weather_amd replays the forward from one HIP graph (graphed.AutoGraph; same kernels, same arguments, "
+                     "output cloned); kernel durations are HIP-event timed in a separate eager pass of the same process")
+
+
 def time_forward(model, feats, steps, warmup, barrier, kernel_timer=True):
-    """W untimed steps, then exactly K steps between barrier + synchronise; HIP events around the tagged edge launches."""
+    """W untimed steps, then exactly K steps between barrier + synchronise.  ``kernel_timer``: HIP events around the tagged edge
+    launches (an active timer keeps every call eager: events cannot be recorded into a HIP graph)."""
     from graph_weather_amd import ops
 
     with torch.no_grad():
@@ -236,6 +267,7 @@ def cold_step_ms(model, feats, n=3):
     from graph_weather_amd.optim import _bump_versions
 
     ts = []
+    auto, model.auto_graph = getattr(model, "auto_graph", None), False  # eager: a re-capture per weight version is not the cold step
     with torch.no_grad():
         for _ in range(n):
             _bump_versions(model.parameters())  # what an optimizer step does to Tensor._version (no kernel launched)
@@ -244,7 +276,29 @@ def cold_step_ms(model, feats, n=3):
             model(feats)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
+    if auto is not None:
+        model.auto_graph = auto
     return 1e3 * sum(ts) / len(ts)
+
+
+def eager_ms(model, feats, steps=20, repeats=3):
+    """The same forward with the automatic HIP graph switched off (every launch issued from Python): median ms per step."""
+    auto, model.auto_graph = getattr(model, "auto_graph", None), False
+    ts = []
+    with torch.no_grad():
+        model(feats)
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(feats)
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0) / steps)
+    if auto is not None:
+        model.auto_graph = auto
+    ts.sort()
+    return {"ms_per_step": ts[len(ts) // 2], "ms_per_step_all": ts, "value": feats.shape[0] / (ts[len(ts) // 2] * 1e-3), "unit": "forecasts/s",
+            "note": "model.auto_graph = False: ~50 launches per forward issued from Python (host-bound below ~3.5 ms of GPU work)"}
 
 
 def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=None):
@@ -281,10 +335,15 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
     gs_bytes_fp32 = proc_b * (2 * e_lat * D * 4 + 2 * graphs.num_mesh * D * 4)
     gs_bytes_halved = proc_b * (2 * e_lat * D * 2 + 2 * graphs.num_mesh * D * 2)  # SURVEY 8(d) "halve for bf16 storage", node tables too
     ach = executed / (dec_ms * 1e-3) / 1e12
-    gs_traffic, gs_traffic_file = (None, None)
+    gs_traffic, gs_traffic_file, gs_busy = (None, None, None)
     if precision == "bf16" and proc_b == 16 and graphs.num_grid == 64800:
         t, gs_traffic_file = pmc_c3_traffic()
         gs_traffic = None if t is None else t["processor_block"]
+    elif precision in ("fp32", "bf16x3") and graphs.num_grid == 64800 and proc_b:
+        # the processor's edge-update instantiation at the grid of this launch (64 edges x 256 threads per workgroup)
+        grid = ((int(round(proc_b)) * e_lat + 63) // 64) * 256
+        pref = ("edge_kernel<true, 2>",) if precision == "fp32" else ("chainx3_kernel<8, true, 3, 16, 16, 1,",)
+        gs_traffic, gs_traffic_file, gs_busy = pmc_kernel_traffic("c2" if precision == "fp32" else "c2x3", pref, grid)
     return {
         "bound": "mfma", "kernel": "decoder edge update (gw_edge_update_forward on the mesh->grid graph)",
         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
@@ -311,6 +370,8 @@ def kernel_report(graphs, batch, precision, timer, ms_per_step, stanza_timer=Non
                                          "frac_fully_halved_basis = SURVEY 8(d) bytes with every table halved; frac_fp32_basis = the "
                                          "reference's fp32 bytes",
                            "traffic": gs_traffic, "traffic_file": gs_traffic_file,
+                           "traffic_over_algorithmic": None if gs_traffic is None else gs_traffic / gs_bytes,
+                           "mfma_busy_frac_pmc": gs_busy,
                            "traffic_tbs": None if gs_traffic is None else gs_traffic / (proc_ms * 1e-3) / 1e12,
                            "executed_tflops": 3 * LAYER * e_lat * proc_b / (proc_ms * 1e-3) / 1e12},
     }
@@ -336,16 +397,18 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
     set_precision(model, cfg["precision"])
     feats = seeded_features(cfg["batch"], len(lat_lons), 102, seed=42).to(dev)
     gc.collect()
-    runs = [time_forward(model, feats, steps, warmup if i == 0 else 1, torch.cuda.synchronize) for i in range(max(1, repeats))]
+    runs = [time_forward(model, feats, steps, max(3, warmup) if i == 0 else 1, torch.cuda.synchronize, kernel_timer=False)
+            for i in range(max(1, repeats))]
     runs.sort(key=lambda r: r[0])
-    elapsed, timer = runs[len(runs) // 2]
+    elapsed, _ = runs[len(runs) // 2]
     ms = 1e3 * elapsed / steps
+    _, timer = time_forward(model, feats, min(steps, 5), 1, torch.cuda.synchronize)  # eager pass: HIP events on the edge launches
     r = kernel_report(graphs, cfg["batch"], cfg["precision"], timer, ms)
     traffic, pmc, pmc_file = pmc_traffic(name) if name in ("c2x3",) else (None, None, None)
     out = {"workload": f"{cfg['grid']:g}deg grid ({len(lat_lons)} nodes), mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), "
                        f"batch {cfg['batch']}, {cfg['precision']}",
            "value": cfg["batch"] * steps / elapsed, "unit": "forecasts/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
-           "repeats": len(runs), "ms_per_step_all": [1e3 * e / steps for e, _ in runs],
+           "repeats": len(runs), "ms_per_step_all": [1e3 * e / steps for e, _ in runs], "path": DEFAULT_PATH_NOTE,
            "graph_build_s": build_s, "dominant_kernel": r["kernel"], "launch_ms": r["launch_ms"], "frac": r["frac"], "peak": r["peak"],
            "step_frac": r["step_frac"], "other_kernels_ms": r["other_kernels_ms"], "gather_scatter_frac": r["gather_scatter"]["frac"],
            "gather_scatter": r["gather_scatter"],
@@ -357,7 +420,10 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
     if parity and cfg["batch"] <= 2 and cfg["grid"] >= 1.0:
         out["cold_ms_per_step"] = cold_step_ms(model, feats)  # forward right after a weight update (every cache misses)
     if parity and cfg["grid"] >= 1.0:
+        out["eager"] = eager_ms(model, feats, steps=steps)
         out["graph"] = graph_replay_ms(model, feats, steps=steps)
+    if parity and cfg["batch"] <= 2 and cfg["grid"] >= 1.0 and cfg["precision"] != "fp32":
+        out["h2d"] = h2d_step_ms(model, feats)  # the batch handed over from pinned host memory every step (PCIe), this mode
     if parity and cfg["precision"] != "fp32":
         with torch.no_grad():
             y = model(feats)
@@ -372,6 +438,21 @@ def run_extra(name, dev, steps, warmup, repeats=1, parity=False):
     del model, feats
     gc.collect()
     torch.cuda.empty_cache()
+    return out
+
+
+def c4_per_gpu(dev):
+    """BASELINE configs[3] (global batch 64 over 8 GPUs) as far as one GPU can show it: the per-GPU load - batch 8 at 1 degree -
+    on this GPU, fp32 and bf16x3.  The forward has no collective, so the stated prediction for the 8-GPU
+    node is 8 x this figure; the driver's SCALE record is the measurement."""
+    out = {}
+    for name, cfg in (("fp32", "c4g"), ("bf16x3", "c4gx3")):
+        r = run_extra(cfg, dev, steps=10, warmup=3, repeats=3)
+        out[name] = {k: r[k] for k in ("workload", "value", "unit", "ms_per_step", "ms_per_step_all", "step_frac", "launch_ms", "frac",
+                                       "peak_memory_gb")}
+        out[name]["predicted_8gpu_forecasts_per_s"] = 8.0 * r["value"]
+    out["note"] = ("per-GPU shard of c4 (8 of 64 samples); prediction = 8 x the one-GPU rate: batch elements never interact and the "
+                   "forward issues no collective, so the only multi-GPU costs are launch skew between ranks and host contention")
     return out
 
 
@@ -395,8 +476,9 @@ def graph_replay_ms(model, feats, steps=20, repeats=3):
             ts.append(1e3 * (time.perf_counter() - t0) / steps)
     ts.sort()
     return {"ms_per_step": ts[len(ts) // 2], "ms_per_step_all": ts, "value": feats.shape[0] / (ts[len(ts) // 2] * 1e-3), "unit": "forecasts/s",
-            "max_rel_vs_eager": err, "note": "whole forward as one HIP graph (same kernels, same arguments; input copied into the "
-                                             "graph's buffer each step); the eager figure above it is what `value` reports"}
+            "max_rel_vs_eager": err, "note": "whole forward as one HIP graph (same kernels, same arguments; the caller's input buffer is "
+                                             "read in place once it has been handed over three times in a row); an explicit ForwardGraph object returning its own output buffer - `value` is model(features) itself, which replays the same way "
+                                             "and clones the output)"}
 
 
 def set_precision(model, precision: str) -> None:
@@ -448,7 +530,7 @@ def h2d_step_ms(model, feats, steps=20):
     return res
 
 
-def run_wide(dev, steps=3, warmup=2):
+def run_wide(dev, steps=3, warmup=3):
     """The reference training script's model widths (train/run.py:493-497: nodes, edges, hidden layers and decoder 1024 wide) on
     the 1 degree grid, batch 1: the layer-by-layer path of graph_weather_amd/wide.py (generic fp32-MFMA kernels, nothing fused).
     FLOPs are the reference's own arithmetic for those widths (no layer-1 split there; the decoder's zero operand is skipped)."""
@@ -744,7 +826,11 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
 
     gc.collect()
     gc.freeze()
-    elapsed, timer = time_forward(model, feats, args.steps, args.warmup, barrier, kernel_timer=on_gpu)
+    # The timed region is model(features) as a caller writes it (from the third call on a HIP-graph replay, DEFAULT_PATH_NOTE);
+    # the per-kernel HIP events need eager launches: a separate pass right after it, in this process, on rank 0.
+    elapsed, timer = time_forward(model, feats, args.steps, args.warmup, barrier, kernel_timer=False)
+    if on_gpu and rank == 0:
+        _, timer = time_forward(model, feats, 5, 1, torch.cuda.synchronize)
     # The kernel stanzas of the mesh stack: when the timed region ran it as per-sample chains on several HIP streams, an edge
     # launch's event time includes whatever the other stream ran beside it - time those launches again on ONE stream
     # (5 extra steps outside the timed region) so that bytes / FLOPs / duration belong to the same launch.
@@ -791,7 +877,7 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
             "config": {"workload": f"{args.config}: GraphWeatherForecaster {cfg['grid']:g}deg grid ({len(lat_lons)} nodes), 102->78 feat, "
                                    f"batch={batch} on rank 0, {prec}, mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), random-init weights",
                        "global_batch": total_batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
-            "roofline": roof,
+            "roofline": roof, "path": DEFAULT_PATH_NOTE if on_gpu else None,
             "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
             "per_rank_ms_per_step": per_rank_ms, "dist_world_size": dist_world,
         }
@@ -800,6 +886,7 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
             out["cold_note"] = ("forward right after every parameter changed: packed weights, edge / mesh embeddings and their layer-1 "
                                 "products are rebuilt (the reference recomputes the embeddings on every forward)")
         if world == 1 and not args.no_extra and args.config == "c2" and on_gpu:
+            out["eager"] = eager_ms(model, feats, steps=args.steps)
             out["graph"] = graph_replay_ms(model, feats, steps=args.steps)
             h2d = h2d_step_ms(model, feats)
             del model, feats
@@ -811,7 +898,9 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
                             "c5": run_extra("c5", dev, steps=5, warmup=2),
                             "c5_split": run_extra("c5x3", dev, steps=5, warmup=2, parity=True),
                             "wide1024": run_wide(dev), "train": run_train_extra(dev), "train_split": run_train_extra(dev, precision="bf16x3"),
-                            "h2d": h2d}
+                            "h2d": h2d, "c4_per_gpu": c4_per_gpu(dev)}
+            out["extra"]["c3"]["status"] = ("plain bf16 operands: OUTSIDE the 1e-3 parity bar (parity_vs_fp32_kernels); a frozen budget "
+                                            "mode - kernels unchanged since round 4, no new work is routed through it")
         if world == 1 and not args.no_cpu_baseline and cfg["grid"] == 1.0:
             out["cpu_baseline"] = cpu_baseline(lat_lons, cpu_state, graphs)
         else:

@@ -193,11 +193,14 @@ class ForecastGraphs:
     def topology_hash(self) -> str:
         """Digest of the three edge lists: equal hashes = same mesh numbering and topology.  A checkpoint is only meaningful on
         the topology it was trained on (real h3 for reference-trained weights); ``check_topology`` compares."""
-        h = getattr(self, "_topo_hash", None)
-        if h is None:  # (memoised: the arrays are immutable by convention; 0.25 degree hashes 116 MB)
-            h = topology_hash(self.enc_edge_index, self.lat_edge_index, self.dec_edge_index)
-            object.__setattr__(self, "_topo_hash", h)
-        return h
+        # memoised per content identity of the three index tensors (0.25 degree hashes 116 MB): the dataclass is mutable, so a
+        # replaced or in-place edited edge list must not be answered with the digest of the old one
+        ident = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.enc_edge_index, self.lat_edge_index, self.dec_edge_index))
+        memo = self.__dict__.get("_topo_hash")
+        if memo is None or memo[0] != ident:
+            memo = (ident, topology_hash(self.enc_edge_index, self.lat_edge_index, self.dec_edge_index))
+            object.__setattr__(self, "_topo_hash", memo)
+        return memo[1]
 
     def as_oracle_dict(self) -> dict:
         return {
@@ -318,6 +321,7 @@ class TopologyRecord:
     def load_state_dict(self, state_dict, *args, **kwargs):
         import warnings
 
+        global _WARNED_NO_RECORD
         res = super().load_state_dict(state_dict, *args, **kwargs)
         graphs = getattr(getattr(self, "encoder", None), "graphs", None)
         if graphs is None:
@@ -326,13 +330,55 @@ class TopologyRecord:
         expected = md.get("", {}).get("gw_topology") if isinstance(md.get("", {}), dict) else None
         if expected is not None:
             check_topology(self, expected)
-        elif graphs.provider != "h3":
+        elif graphs.provider != "h3" and not _HUB_LOADING and not _WARNED_NO_RECORD:
+            # (once per process: plain {name: tensor} dicts - own round trips through dict comprehensions - carry no record either)
+            _WARNED_NO_RECORD = True
             warnings.warn("graph_weather_amd: this checkpoint carries no mesh-topology record (e.g. it was written by the reference, "
                           "whose mesh cells are numbered by h3) and this model runs on the built-in mesh provider (%r, topology %s): "
                           "the tensors load, but parity with the weights' original mesh numbering is unverified - see "
-                          "graphs.check_topology" % (graphs.provider, graphs.topology_hash()))
+                          "graphs.check_topology (said once per process)" % (graphs.provider, graphs.topology_hash()))
         return res
 
+    # Hub round trip (PyTorchModelHubMixin.save_pretrained / from_pretrained, forecast.py:61): safetensors carries no
+    # ``_metadata``, so the record travels as gw_topology.json beside model.safetensors and is checked after the load.
+    def _save_pretrained(self, save_directory) -> None:
+        import json
+        import os
+
+        super()._save_pretrained(save_directory)
+        graphs = getattr(getattr(self, "encoder", None), "graphs", None)
+        if graphs is not None:
+            with open(os.path.join(str(save_directory), TOPOLOGY_FILE), "w") as f:
+                json.dump({"gw_topology": graphs.topology_hash(), "gw_provider": graphs.provider}, f)
+
+    @classmethod
+    def _from_pretrained(cls, *, model_id, **kwargs):
+        import json
+        import os
+        import warnings
+
+        global _HUB_LOADING, _WARNED_NO_RECORD
+        _HUB_LOADING = True  # (the safetensors loader hands load_state_dict a plain dict: the record is checked below instead)
+        try:
+            model = super()._from_pretrained(model_id=model_id, **kwargs)
+        finally:
+            _HUB_LOADING = False
+        graphs = getattr(getattr(model, "encoder", None), "graphs", None)
+        path = os.path.join(str(model_id), TOPOLOGY_FILE)
+        if graphs is not None and os.path.isfile(path):
+            with open(path) as f:
+                check_topology(model, json.load(f).get("gw_topology"))
+        elif graphs is not None and graphs.provider != "h3" and not _WARNED_NO_RECORD:
+            _WARNED_NO_RECORD = True
+            warnings.warn("graph_weather_amd: %s holds no %s (a checkpoint written by the reference, or fetched from the hub without "
+                          "it): the tensors load, parity with the weights' original mesh numbering is unverified (provider %r, "
+                          "topology %s; said once per process)" % (model_id, TOPOLOGY_FILE, graphs.provider, graphs.topology_hash()))
+        return model
+
+
+TOPOLOGY_FILE = "gw_topology.json"
+_HUB_LOADING = False
+_WARNED_NO_RECORD = False
 
 _BUILT: list = []  # the last few (key, ForecastGraphs, provider): see build_forecast_graphs
 

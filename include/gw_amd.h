@@ -44,7 +44,11 @@ extern "C" {
  * (csrc/gw_split.hip): ~1e-5 per product - inside BASELINE.json's 1e-3 - at 3 bf16 MFMAs per product.  Streams from
  * gw_pack_linear_bf16x3 (4 bytes per weight).  Every table this mode reads or writes is fp32 rows (GW_LAYOUT_ROWS_F32): none of
  * the bf16 mode's 16-bit formats (edge tiles, fp16 product rows, bf16 K-order aggregates, segment-aligned tiles) applies.
- * Inference only, like GW_DTYPE_BF16. */
+ * Trains: the forward entry points accept gw_activation_save with these weights (fp32 saves: relu outputs of every Linear,
+ * pre-LayerNorm rows), the backward's masked input-gradient products run through gw_project_forward (relu_mask) on transposed
+ * split packs and its weight-gradient GEMMs through gw_gemm_f32 with GW_GEMM_TN_BF16X3; only GW_DTYPE_BF16 is inference-only.
+ * Mesh-sized node updates (gw_node_update_forward with at most 12 288 rows, fp32 and bf16x3 weights alike) run on the row-split
+ * kernels of csrc/gw_noders.hip - same arguments, bitwise the rows of the 64-column kernels. */
 #define GW_DTYPE_BF16X3 2
 
 /* Memory layout of a per-edge table handed to / produced by gw_edge_update_forward.

@@ -7,6 +7,7 @@
 #   smoke                  __graft_entry__.smoke()
 #   bench[:ARGS]           python bench.py ARGS (default: the driver's command, --steps 20 --warmup 5); ARGS with '+' for spaces
 #   prof:CONFIG            rocprofv3 --kernel-trace --stats of bench.py --config CONFIG --steps 5 (kernel_stats csv copied)
+#   proftrain[:PRECISION]  rocprofv3 --kernel-trace --stats of the training step (bench.py --mode train --steps 3; fp32 or bf16x3)
 #   pmc:c3 | pmc:c2        the multi-pass PMC scripts (scripts/gpu_pmc_c3.sh, scripts/gpu_pmc.sh): summary json under gpurun_out/TAG
 #   py:SCRIPT[:ARGS]       python SCRIPT ARGS (probes under scripts/probes)
 # Tuning builds: GW_TUNING=1 in the environment of the call rebuilds the library with the A/B knobs.
@@ -35,6 +36,11 @@ for STEP in "$@"; do
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $R/bench.py --config $ARG --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $R/$OUT/rocprof_$ARG.log 2>&1)
       find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $OUT/${ARG}_kernel_stats.csv \; 2>/dev/null
       tail -n 1 $OUT/rocprof_$ARG.log | cut -c1-600; head -n 16 $OUT/${ARG}_kernel_stats.csv | cut -c1-200 ;;
+    proftrain)
+      P=${ARG:-fp32}; rm -rf /tmp/prof && mkdir -p /tmp/prof
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $R/bench.py --mode train --precision $P --steps 3 --warmup 2 > $R/$OUT/rocprof_train_$P.log 2>&1)
+      find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $OUT/train_${P}_kernel_stats.csv \; 2>/dev/null
+      tail -n 1 $OUT/rocprof_train_$P.log | cut -c1-400; head -n 12 $OUT/train_${P}_kernel_stats.csv | cut -c1-200 ;;
     pmc)  # pmc:c3 = HBM traffic / MFMA activity of the bf16 edge kernels per position in the forward; pmc:c2 = the fp32 decoder edge kernel
       if [ "$ARG" = "c3" ]; then bash scripts/gpu_pmc_c3.sh $TAG; else bash scripts/gpu_pmc.sh $TAG; fi ;;
     py)

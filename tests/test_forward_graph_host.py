@@ -52,3 +52,51 @@ def test_refuses_cpu_tensors_training_mode_and_a_first_call_without_input():
     model.train()
     with pytest.raises(RuntimeError, match="inference"):
         fg(torch.zeros(1, 72, 102))
+
+
+def test_capture_key_follows_launch_shaping_attributes_and_invalidate_rewalks():
+    """state that changes the launches but not the weights - streams of the mesh stack, checkpoint segments, efficient
+    batching - is part of the key; modules swapped in after the first call are picked up by ``invalidate()``."""
+    model = _model()
+    fg = gw.ForwardGraph(model)
+    shape = (2, 72, 102)
+    k0 = fg._state_key(shape, "cuda:0", torch.float32)
+    gp = model.processor.graph_processor
+    keep = gp.streams
+    gp.streams = 1 if keep != 1 else 2
+    k1 = fg._state_key(shape, "cuda:0", torch.float32)
+    assert k1 != k0
+    gp.streams = keep
+    assert fg._state_key(shape, "cuda:0", torch.float32) == k0
+    model.processor.set_checkpoint_segments(3)
+    assert fg._state_key(shape, "cuda:0", torch.float32) != k0
+    model.processor.set_checkpoint_segments(0)
+    # a parameter swapped in behind the cached module walk is invisible until invalidate()
+    blk = model.processor.graph_processor.blocks[0].node_model.node_mlp
+    lin = next(m for m in blk.modules() if isinstance(m, torch.nn.Linear))
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone() * 2)
+    assert fg._state_key(shape, "cuda:0", torch.float32) == k0
+    fg.invalidate()
+    assert fg._state_key(shape, "cuda:0", torch.float32) != k0
+
+
+def test_auto_graph_policy_on_the_host():
+    """graphed.AutoGraph: which calls may be replayed (eval + no_grad + small CUDA input, nothing that forbids a capture) - the
+    decisions that need no GPU; the replays themselves are tests/test_gpu_round6.py."""
+    from graph_weather_amd.graphed import AutoGraph
+
+    model = _model()
+    auto = AutoGraph(model)
+    x = torch.zeros(1, 72, 102)
+    with torch.no_grad():
+        assert not auto.usable(x)  # a CPU tensor: the ordinary path raises "no CPU path"
+    assert model.auto_graph is True
+    import copy
+    import pickle
+
+    model.__dict__["_auto"] = auto  # (what forward() stores on first use): not copied, not pickled
+    assert "_auto" not in copy.deepcopy(model).__dict__
+    assert "_auto" not in pickle.loads(pickle.dumps(model)).__dict__
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        with torch.no_grad():
+            model(x)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 import graph_weather_amd as gw  # noqa: E402
 from graph_weather_amd import ops  # noqa: E402
 from graph_weather_amd.ops import Operand  # noqa: E402
-from graph_weather_amd.utils import deterministic_fill_  # noqa: E402
+from graph_weather_amd.utils import deterministic_fill_, regular_lat_lons, seeded_features  # noqa: E402
 
 DEV = "cuda:0"
 X3 = ops.BF16X3
@@ -155,3 +155,93 @@ def test_row_split_node_update_with_a_projected_or_absent_node_operand(dtype, ba
     rp, rz = _rel(out_p, ref(xb, True)), _rel(out_z, ref(torch.zeros_like(xb), False))
     print(f"[row-split node update {dtype} n={n} B={B}] projected x {rp:.2e}, absent x {rz:.2e}")
     assert rp <= bar and rz <= bar
+
+
+def _forecaster(deg=10.0, seed=0):
+    lat_lons = regular_lat_lons(deg)
+    model = gw.GraphWeatherForecaster(lat_lons)
+    deterministic_fill_(model, seed=seed)
+    return model.to(DEV).eval(), lat_lons
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, X3])
+def test_eval_forward_replays_itself_from_a_hip_graph_and_follows_weight_updates(dtype):
+    """graphed.AutoGraph behind ``GraphWeatherForecaster.forward``: in eval() under no_grad() the third call of a shape is the
+    first replay.  A replay returns its own tensor (nothing a later call overwrites), equals the eager forward (bitwise in
+    deterministic mode), and a weight update between two calls is followed - eager again for two calls, then a new capture;
+    grad mode, training mode and ``auto_graph = False`` stay eager."""
+    model, lat_lons = _forecaster()
+    model.set_compute_dtype(dtype)
+    model.set_deterministic(True)
+    a = seeded_features(2, len(lat_lons), 102, seed=1).to(DEV)
+    b = seeded_features(2, len(lat_lons), 102, seed=2).to(DEV)
+    with torch.no_grad():
+        ref_a, ref_b = model._forward_eager(a), model._forward_eager(b)
+        ys = [model(a), model(b), model(a), model(b), model(a)]
+        auto = model.__dict__["_auto"]
+        assert auto._fg is not None and auto._fg.captures == 1  # calls 3-5 replayed one capture
+        for y, ref in zip(ys, (ref_a, ref_b, ref_a, ref_b, ref_a)):
+            assert torch.equal(y, ref)
+        assert ys[2].data_ptr() != ys[4].data_ptr()  # clones, not the graph's buffer
+        for p in model.parameters():
+            p.mul_(1.01)
+        new_a = model._forward_eager(a)
+        assert not torch.equal(new_a, ref_a)
+        outs = [model(a) for _ in range(4)]  # 2 eager calls, capture, replay
+        assert all(torch.equal(o, new_a) for o in outs)
+        assert auto._fg.captures >= 2  # (one more if the fourth call pinned the graph on the caller's buffer)
+        c = seeded_features(1, len(lat_lons), 102, seed=3).to(DEV)  # another shape: counted afresh
+        assert torch.equal(model(c), model._forward_eager(c))
+        model.auto_graph = False
+        n = auto._fg.captures
+        assert torch.equal(model(a), new_a) and auto._fg.captures == n
+        model.auto_graph = True
+    # grad mode: the autograd path, untouched by the graph
+    model.set_deterministic(False)
+    x = a.clone().requires_grad_(True)
+    model(x).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_forward_graph_reads_a_stable_caller_buffer_in_place():
+    """graphed.ForwardGraph: a caller that hands over one and the same buffer (a rollout's input, a staging buffer) gets a graph
+    captured ON that buffer after ``pin_after`` calls - no copy of the batch per step; another buffer sends the graph back to
+    its own input for good (it never writes into a caller's tensor)."""
+    model, lat_lons = _forecaster()
+    model.set_deterministic(True)
+    fg = gw.ForwardGraph(model, pin_after=3)
+    buf = seeded_features(2, len(lat_lons), 102, seed=5).to(DEV)
+    other = seeded_features(2, len(lat_lons), 102, seed=6).to(DEV)
+    with torch.no_grad():
+        fg(buf)
+        fg(buf)
+        assert not fg.pinned and fg.captures == 1
+        y = fg(buf).clone()
+        assert fg.pinned and fg.captures == 2 and fg.input is buf
+        assert torch.equal(y, model._forward_eager(buf))
+        buf.copy_(other)  # the next step's data written into the same buffer: read in place
+        keep = other.clone()
+        y2 = fg(buf).clone()
+        assert fg.captures == 2 and torch.equal(y2, model._forward_eager(other)) and not torch.equal(y2, y)
+        y3 = fg(other).clone()  # a different buffer: back to an own input buffer, the caller's tensors untouched
+        assert not fg.pinned and fg.captures == 3 and torch.equal(y3, y2)
+        assert torch.equal(buf, keep) and torch.equal(other, keep)
+        for _ in range(4):
+            fg(buf)
+        assert not fg.pinned and fg.captures == 3  # no second attempt
+
+
+def test_rollout_through_the_automatic_graph_equals_the_eager_rollout():
+    """rollout.py (train/run.py:506-528 loop shape): step t's output becomes step t + 1's input in ONE reused buffer - the
+    automatic graph pins that buffer; every step equals the eager rollout."""
+    from graph_weather_amd.rollout import rollout
+
+    model, lat_lons = _forecaster()
+    model.set_deterministic(True)
+    feats = seeded_features(1, len(lat_lons), 102, seed=9).to(DEV)
+    model.auto_graph = False
+    ref = rollout(model, feats, 6)
+    model.auto_graph = True
+    out = rollout(model, feats, 6)
+    assert len(out) == 6 and all(torch.equal(o, r) for o, r in zip(out, ref))
+    assert model.__dict__["_auto"]._fg.pinned
