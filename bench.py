@@ -829,8 +829,11 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
     # The timed region is model(features) as a caller writes it (from the third call on a HIP-graph replay, DEFAULT_PATH_NOTE);
     # the per-kernel HIP events need eager launches: a separate pass right after it, in this process, on rank 0.
     elapsed, timer = time_forward(model, feats, args.steps, args.warmup, barrier, kernel_timer=False)
+    timer_pass_ms = None
     if on_gpu and rank == 0:
-        _, timer = time_forward(model, feats, 5, 1, torch.cuda.synchronize)
+        # a second timed region of the same K steps, same bracket, with HIP events on the stream each edge launch runs on
+        t_el, timer = time_forward(model, feats, args.steps, 1, torch.cuda.synchronize)
+        timer_pass_ms = 1e3 * t_el / args.steps
     # The kernel stanzas of the mesh stack: when the timed region ran it as per-sample chains on several HIP streams, an edge
     # launch's event time includes whatever the other stream ran beside it - time those launches again on ONE stream
     # (5 extra steps outside the timed region) so that bytes / FLOPs / duration belong to the same launch.
@@ -878,6 +881,7 @@ def main(argv=None, backend="nccl", device=None, model_factory=None, train_facto
                                    f"batch={batch} on rank 0, {prec}, mesh res {cfg['resolution']} ({graphs.num_mesh} nodes), random-init weights",
                        "global_batch": total_batch, "parallelism": f"batch-sharded x{world}, no collective in forward"},
             "roofline": roof, "path": DEFAULT_PATH_NOTE if on_gpu else None,
+            "kernel_timer_pass_ms_per_step": timer_pass_ms,  # the K-step region the roofline's launch durations were HIP-event timed in
             "algorithmic_gflop_per_forecast": algorithmic_flops_per_forecast(graphs) / 1e9,
             "per_rank_ms_per_step": per_rank_ms, "dist_world_size": dist_world,
         }

@@ -12,7 +12,7 @@ scripts/gpu_run.sh $TAG build
 case " $STEPS " in *" test "*) scripts/gpu_run.sh $TAG test;; esac
 case " $STEPS " in *" smoke "*) scripts/gpu_run.sh $TAG smoke;; esac
 case " $STEPS " in *" bench "*) scripts/gpu_run.sh $TAG bench | cut -c1-6000;; esac
-case " $STEPS " in *" prof "*) scripts/gpu_run.sh $TAG prof:c2 prof:c2x3 prof:c3 > $OUT/prof_summary.log 2>&1; tail -n 40 $OUT/prof_summary.log | cut -c1-200;; esac
+case " $STEPS " in *" prof "*) scripts/gpu_run.sh $TAG prof:c2 prof:c2x3 prof:c3 proftrain:fp32 proftrain:bf16x3 > $OUT/prof_summary.log 2>&1; tail -n 40 $OUT/prof_summary.log | cut -c1-200;; esac
 case " $STEPS " in *" pmc "*)
   PMC_LDS=0 bash scripts/gpu_pmc_cfg.sh $TAG c2 > $OUT/pmc_c2_summary.log 2>&1
   bash scripts/gpu_pmc_cfg.sh $TAG c2x3 > $OUT/pmc_c2x3_summary.log 2>&1
@@ -23,4 +23,5 @@ case " $STEPS " in *" clocks "*)
   python -c "import __graft_entry__ as g; g.build()" > $OUT/build_tuning.log 2>&1
   for W in decoder processor node dechead nodeenc; do python scripts/gpu_timeline_x3.py 2 $W 2>&1 | grep -v "amdgpu.ids"; done > $OUT/x3_timeline_b2.log
   for W in decoder processor; do python scripts/gpu_timeline_x3.py 16 $W 2>&1 | grep -v "amdgpu.ids"; done > $OUT/x3_timeline_b16.log
+  for P in fp32 bf16x3; do python scripts/gpu_timeline_rs.py 2 $P 2>&1 | grep -v "amdgpu.ids"; done > $OUT/rs_timeline_b2.log
   tail -n 10 $OUT/x3_timeline_b2.log;; esac

@@ -33,7 +33,7 @@ for STEP in "$@"; do
       timeout 1200 python bench.py ${A//+/ } > $OUT/bench_$N.log 2>&1; echo "bench rc=$?" >> $OUT/bench_$N.log; tail -n 2 $OUT/bench_$N.log | cut -c1-3500 ;;
     prof)
       rm -rf /tmp/prof && mkdir -p /tmp/prof
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $R/bench.py --config $ARG --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $R/$OUT/rocprof_$ARG.log 2>&1)
+      (cd /tmp && GW_AUTO_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o gw -- python $R/bench.py --config $ARG --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $R/$OUT/rocprof_$ARG.log 2>&1)  # (eager launches: the same kernels the HIP graph replays)
       find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} $OUT/${ARG}_kernel_stats.csv \; 2>/dev/null
       tail -n 1 $OUT/rocprof_$ARG.log | cut -c1-600; head -n 16 $OUT/${ARG}_kernel_stats.csv | cut -c1-200 ;;
     proftrain)
