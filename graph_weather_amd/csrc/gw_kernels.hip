@@ -1259,6 +1259,8 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
   return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS>, a, stream, 1, 2);
 }
 
+int gw_node_update_row_split_groups(int64_t n_rows) { return gw::node_rs_groups(n_rows); }
+
 int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
                                 const gw_mlp_weights* w, const gw_mlp_weights* head, const gw_operand* residual, float* out,
                                 int32_t out_ld, void* stream) {

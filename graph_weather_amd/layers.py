@@ -22,6 +22,7 @@ from torch import nn
 
 from . import autograd as ag
 from . import ops
+from . import routes
 from . import wide
 from .autograd import OperandSpec
 from .graphs import ForecastGraphs, GraphPlan, build_forecast_graphs
@@ -53,6 +54,14 @@ def _autograd_on(module: nn.Module, *inputs: Optional[torch.Tensor]) -> bool:
                 raise NotImplementedError("graph_weather_amd: the backward pass is implemented for float32 and bf16x3 matrix "
                                           "products; call the bfloat16 mode under torch.no_grad() (inference)")
     return on
+
+
+def _form(mlp: "MLP") -> routes.MlpForm:
+    """routes.MlpForm of an MLP.  Only the bf16 routes read the packed shape facts: the other modes are told apart by dtype
+    alone, so their weights are not packed just to answer a route question (host-only callers, CPU tests)."""
+    if mlp.compute_dtype == torch.bfloat16:
+        return routes.MlpForm.of(mlp)
+    return routes.MlpForm(mlp.compute_dtype, -1, -1, False)
 
 
 class Feed:
@@ -489,10 +498,7 @@ class GraphProcessor(nn.Module):
         """Streams the fused inference forward runs this stack on: ``self.streams`` if set, else 2 for fp32 / bf16x3 matrix products
         and batch >= 2 (their mesh-sized launches of 64-column workgroups leave workgroup slots idle in the last round; the bf16
         kernels are persistent and occupy every CU by themselves), else 1."""
-        if self.streams > 0:
-            return max(1, min(int(self.streams), batch))
-        tiled = all(b.edge_model.edge_mlp.compute_dtype in (torch.float32, BF16X3) for b in self.blocks)  # (64-column workgroups)
-        return 2 if (tiled and batch >= 2) else 1
+        return routes.mesh_streams(self.streams, [b.edge_model.edge_mlp.compute_dtype for b in self.blocks], batch)
 
     def side_streams(self, device, n: int):
         key = (str(device), n)
@@ -519,15 +525,13 @@ class GraphProcessor(nn.Module):
         every block, atomics mode, at most 16 destinations per tile: csrc/gw_edge16p.hip), else None."""
         if len(self.blocks) == 0 or plan.num_edges == 0:
             return None
-        for blk in self.blocks:
-            m = blk.edge_model.edge_mlp
-            if m.compute_dtype != torch.bfloat16 or blk.node_model.node_mlp.compute_dtype != torch.bfloat16 or blk.deterministic:
-                return None
-            pm = m.packed()
-            if pm.n_mid != 1 or pm.ln_width != 0 or pm.gamma is None:
-                return None
+        if any(b.edge_model.edge_mlp.compute_dtype != torch.bfloat16 for b in self.blocks):  # (no packing of other modes' weights)
+            return None
+        forms = [(_form(b.edge_model.edge_mlp), b.node_model.node_mlp.compute_dtype, bool(b.deterministic)) for b in self.blocks]
+        if not routes.stack_on_segment_tiles(forms, plan.num_edges, 0):  # (everything but the tiling itself, which is built lazily)
+            return None
         seg = plan.seg_tiles()
-        return seg if (seg is not None and seg.max_slots <= 16) else None
+        return seg if routes.stack_on_segment_tiles(forms, plan.num_edges, None if seg is None else seg.max_slots) else None
 
     def _shared_e0_seg(self, blk, e_cur: torch.Tensor, seg):
         """(We . e in padded order, e as one shared set of bf16 edge tiles over the padded list) of batch-independent edge
@@ -545,8 +549,7 @@ class GraphProcessor(nn.Module):
         ``tiles=False``: the caller reads only the product (the segment-tile route keeps its own padded tile set)."""
         mlp_e = blk.edge_model.edge_mlp
         pm_e = mlp_e.packed()
-        tiled = (mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None
-                 and n_edges > 0)
+        tiled = routes.resident_bf16(routes.MlpForm.of(mlp_e, pm_e), n_edges)
         key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key())
         if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
             pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
@@ -567,7 +570,13 @@ class GraphProcessor(nn.Module):
         # segment-aligned tiles: the running aggregate of that route starts from the cached segment sums of the BATCH-SHARED edge
         # features of block 0 (csrc/gw_edge16p.hip: agg += sum(LN(.)) on top of sum(e)); per-sample edge features handed in by a
         # caller (Processor.forward without efficient batching) take the tile route without segment alignment
-        seg = None if (train or want_edges or lo != 0 or not shared) else self._seg_for(plan)
+        seg = self._seg_for(plan) if routes.segment_route_allowed(train, bool(want_edges), lo, shared) else None
+
+        def route_of(j: int) -> Optional[str]:  # the edge-update route of block j of this call (None past the stack)
+            if j >= len(self.blocks):
+                return None
+            m = self.blocks[j].edge_model.edge_mlp
+            return routes.EDGE_AUTOGRAD if train else routes.edge_route(_form(m), n_edges, False)
         for i in range(lo, hi):
             blk = self.blocks[i]
             last = i == hi - 1
@@ -587,8 +596,8 @@ class GraphProcessor(nn.Module):
                     ps, pd = ops.project_forward([pm_e.w1[0], pm_e.w1[1]], Operand(x, n, 256), batch * n, n, zero_rows=agg_buf)
             # bf16 mode (inference): between blocks the per-sample edge features live as bf16 "edge tiles" - the MFMA B-operand
             # order the next block's layer-1 product consumes directly (csrc/gw_edge16.hip); only what crosses the API is rows
-            tiled = ((not train) and mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0
-                     and pm_e.gamma is not None and n_edges > 0)
+            route = route_of(i)
+            tiled = route == routes.EDGE_TILES_BF16
             if shared:
                 if train:
                     pe = ag.project(mlp_e, (2,), e_cur, n_edges, n_edges)[0]
@@ -606,13 +615,7 @@ class GraphProcessor(nn.Module):
             need_e = want_edges or not last
             # e' stays in the bf16 tile format only when the block that consumes it reads tiles too (same compute dtype and
             # shape: set_compute_dtype applied to a sub-module can leave neighbours in different modes)
-            nxt_tiled = False
-            if i + 1 < len(self.blocks) and not last:
-                nm = self.blocks[i + 1].edge_model.edge_mlp
-                npk = nm.packed() if not train else None
-                nxt_tiled = (npk is not None and nm.compute_dtype == torch.bfloat16 and npk.n_mid == 1 and npk.ln_width == 0
-                             and npk.gamma is not None)
-            out_kind = "tiles" if (tiled and need_e and nxt_tiled) else need_e
+            out_kind = routes.edge_out_kind(route, bool(need_e), route_of(i + 1) if not last else None)
             if seg is not None and shared:
                 e_res = self._shared_e0_seg(blk, e_cur, seg)[1]
             elif shared and tiled:
@@ -631,8 +634,7 @@ class GraphProcessor(nn.Module):
                         post_w, post_zero = [nxt.w1[0], nxt.w1[1]], seg is None
                         # block i + 1 >= 1 reads per-sample edge tiles, i.e. runs its layer 1 in the bf16 layer-1 kernel, which
                         # gathers these products once per edge: hand them over as fp16 rows
-                        post_half = (nxt_mlp.compute_dtype == torch.bfloat16 and nxt.n_mid == 1 and nxt.ln_width == 0
-                                     and nxt.gamma is not None and n_edges > 0)
+                        post_half = routes.post_products_half(route_of(i + 1))
                 elif tail_w is not None and all(w_.dtype == pm_n.w_out.dtype for w_ in tail_w):
                     post_w = list(tail_w)
                     post_half = bool(tail_half)
@@ -804,23 +806,23 @@ class Encoder(nn.Module):
         """Inference in bf16 with everything the team-pipelined edge kernel needs (see ``AssimilatorDecoder.team_path``).
         ``features``: the call's input - an input that requires grad keeps the call on the differentiable path (which raises
         for bf16: no silent drop of d/d(features) through the non-differentiable fused launches)."""
+        return self._block_route(features) == routes.BLOCK_TEAM
+
+    def _block_route(self, features: Optional[torch.Tensor] = None) -> str:
+        """routes.block_route of the encoder's bipartite block for this call."""
         blk = self.graph_processor.blocks[0]
         mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
-        if wide.encoder_is_wide(self) or _autograd_on(self, features) or blk.deterministic:
-            return False
-        if mlp_e.compute_dtype != torch.bfloat16 or mlp_n.compute_dtype != torch.bfloat16:
-            return False
-        pm_e = mlp_e.packed()
-        return pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and self.graphs.enc_plan.num_edges > 0
+        is_wide = wide.encoder_is_wide(self)
+        auto = False if is_wide else _autograd_on(self, features)
+        if is_wide or auto:
+            return routes.BLOCK_ROWS
+        return routes.block_route(_form(mlp_e), mlp_n.compute_dtype, self.graphs.enc_plan.num_edges, False, False,
+                                  bool(blk.deterministic))
 
     def split_path(self, features: Optional[torch.Tensor] = None) -> bool:
         """Inference with bf16x3 (split-operand) products in both MLPs of the encoder block: the edge update then runs with every
         layer-1 operand projected and without residual, like the bf16 team path, on fp32 rows (csrc/gw_split.hip)."""
-        blk = self.graph_processor.blocks[0]
-        mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
-        if wide.encoder_is_wide(self) or _autograd_on(self, features):
-            return False
-        return mlp_e.compute_dtype == BF16X3 and mlp_n.compute_dtype == BF16X3 and self.graphs.enc_plan.num_edges > 0
+        return self._block_route(features) == routes.BLOCK_SPLIT
 
     def _team_node_product(self, blk, plan: GraphPlan, e: torch.Tensor, px_xm: torch.Tensor) -> torch.Tensor:
         """Wx.xm + Wa.S with S[dst] = the sum of the (batch-independent) edge features e over the destination's edges: the
@@ -967,22 +969,22 @@ class AssimilatorDecoder(nn.Module):
         """Inference in bf16 with everything the team-pipelined edge kernel needs (csrc/gw_edge16t.hip): one middle layer,
         LayerNorm over all 256 features, atomics mode, node and edge MLP of the block in the same dtype.  Then the decoder's edge
         update runs without residual (the sums of e enter the node update) and takes its layer-1 node products as fp16 rows."""
+        return self._block_route() == routes.BLOCK_TEAM
+
+    def _block_route(self) -> str:
+        """routes.block_route of the decoder's bipartite block."""
         blk = self.graph_processor.blocks[0]
         mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
-        if wide.decoder_is_wide(self) or _autograd_on(self) or blk.deterministic:
-            return False
-        if mlp_e.compute_dtype != torch.bfloat16 or mlp_n.compute_dtype != torch.bfloat16:
-            return False
-        pm_e = mlp_e.packed()
-        return pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None and self.graphs.dec_plan.num_edges > 0
+        is_wide = wide.decoder_is_wide(self)
+        auto = False if is_wide else _autograd_on(self)
+        if is_wide or auto:
+            return routes.BLOCK_ROWS
+        return routes.block_route(_form(mlp_e), mlp_n.compute_dtype, self.graphs.dec_plan.num_edges, False, False,
+                                  bool(blk.deterministic))
 
     def split_path(self) -> bool:
         """Inference with bf16x3 (split-operand) products in both MLPs of the decoder block (see ``Encoder.split_path``)."""
-        blk = self.graph_processor.blocks[0]
-        mlp_e, mlp_n = blk.edge_model.edge_mlp, blk.node_model.node_mlp
-        if wide.decoder_is_wide(self) or _autograd_on(self):
-            return False
-        return mlp_e.compute_dtype == BF16X3 and mlp_n.compute_dtype == BF16X3 and self.graphs.dec_plan.num_edges > 0
+        return self._block_route() == routes.BLOCK_SPLIT
 
     def decode(self, processor_features: torch.Tensor, batch_size: int,
                residual: Optional[torch.Tensor] = None, ps: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 16
+#define GW_ABI_VERSION 17
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -294,6 +294,13 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
  * products of the NEXT block's edge MLP over the node table (see gw_project_forward), so that GraphProcessor's loop
  * (graph_net_block.py:293-301) needs no projection launch between blocks.  zero_rows: [n_rows, 256] filled with zeros on the
  * side (the next block's aggregate buffer).  Inference only (save must be NULL), out_ld 256. */
+
+/* (v17) Which kernel form gw_node_update_forward gives a launch of n_rows rows with fp32 / bf16x3 weights (fp32 row tables,
+ * one middle layer, LayerNorm over 256 features or none, no activation saves): 1, 2 or 3 = the row-split kernels of
+ * csrc/gw_noders.hip with that many 16-column groups per workgroup (mesh-sized launches: at most one round of 48-column
+ * workgroups on the 256 CUs), 0 = the 64-column kernels.  Pure host logic (no GPU needed): graph_weather_amd/routes.py keeps the
+ * same table and tests/test_routes.py compares the two. */
+int gw_node_update_row_split_groups(int64_t n_rows);
 
 /* ---- NodeProcessor.forward followed by the output head, one launch (bf16 or bf16x3 weights) ---------------------------
  * AssimilatorDecoder.forward after its edge update (assimilator_decoder.py:195-200) + the Decoder residual (decoder.py:93):
