@@ -1030,8 +1030,7 @@ class AssimilatorDecoder(nn.Module):
                 pe = self._cache["dec_pe_pad"][1]
             x_node = FEED_ZERO
             x3 = self.split_path()
-            if x3 or (mlp_e.compute_dtype == torch.bfloat16 and pm_e.n_mid == 1 and pm_e.ln_width == 0 and pm_e.gamma is not None
-                      and n_e > 0):
+            if x3 or routes.resident_bf16(_form(mlp_e), n_e):
                 pm_n = blk.node_model.node_mlp.packed()
                 if not (team or x3):
                     # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles

@@ -10,7 +10,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 { date; rocm-smi --showproductname --showmeminfo vram 2>/dev/null | head -20; lscpu | grep -E "Model name|Socket|Core|Thread|^CPU\(s\)"; python -c "import torch; print(torch.__version__, torch.version.hip)"; } > $OUT/env.log 2>&1
 scripts/gpu_run.sh $TAG build
 case " $STEPS " in *" test "*) scripts/gpu_run.sh $TAG test;; esac
-case " $STEPS " in *" smoke "*) scripts/gpu_run.sh $TAG smoke;; esac
+case " $STEPS " in *" smoke "*) scripts/gpu_run.sh $TAG smoke; scripts/gpu_run.sh $TAG py:scripts/probes/graph_rccl_probe.py | tail -n 6;; esac
 case " $STEPS " in *" bench "*) scripts/gpu_run.sh $TAG bench | cut -c1-6000;; esac
 case " $STEPS " in *" prof "*) scripts/gpu_run.sh $TAG prof:c2 prof:c2x3 prof:c3 proftrain:fp32 proftrain:bf16x3 > $OUT/prof_summary.log 2>&1; tail -n 40 $OUT/prof_summary.log | cut -c1-200;; esac
 case " $STEPS " in *" pmc "*)

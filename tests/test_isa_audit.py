@@ -300,3 +300,47 @@ def test_split_kernels_fit_two_workgroups_per_cu_and_issue_three_mfmas_per_fragm
         assert 2 * n_mfma <= 3 * n_frag, (name, n_mfma, n_frag)
         assert n_mfma >= 0.9 * 1.5 * n_frag, (name, n_mfma, n_frag)
         assert not any(ln.startswith(("v_mfma_f32_16x16x4", "v_mfma_f32_32x32")) for ln in lines), name
+
+
+@pytest.mark.timeout(600)
+def test_row_split_node_update_kernels_fit_three_waves_per_simd_without_scratch(tmp_path):
+    """csrc/gw_noders.hip: a 12-wave workgroup (CG = 3) needs <= 168 registers per wave (three waves per SIMD) and no scratch in any
+    instantiation - a spill would sit in front of the exchange / LayerNorm of every workgroup (round 6: a first bf16x3 form kept
+    64 registers of fragments in flight and spilled 376 bytes per lane).  The matrix work is all there: fp32 6 passes x 64
+    K-steps x 4 row tiles of straight-line code per wave, bf16x3 5 x 8 x 12 = 480 (counted below); and no scalar branch per MFMA group inside the passes
+    (profiles/r05_x3_ablation.log: one branch per unit doubled a pass) - at most a handful per 64 KiB chunk."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graph_weather_amd", "csrc", "gw_noders.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "n.o", "-save-temps"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
+    text = (tmp_path / "gw_noders-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
+    names = re.findall(r"^(_Z\w*node_rs3?_kernelILi\d+E\w*):", text, re.M)
+    assert len(names) == 6, names  # fp32 / bf16x3 x 1, 2, 3 column groups per workgroup
+    for name in names:
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", meta).group(1))
+        cg = int(re.search(r"kernelILi(\d+)E", name).group(1))
+        x3 = "node_rs3_kernel" in name
+        assert scratch == 0, (name, scratch)
+        assert vgpr <= (168 if cg == 3 else 256), (name, vgpr)
+        assert lds == 0, (name, lds)  # dynamic LDS only (128 KiB at launch: two 64 KiB weight buffers)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", "."))]
+        mfma = [ln for ln in lines if ln.startswith("v_mfma_f32_16x16x32_bf16" if x3 else "v_mfma_f32_16x16x4_f32")]
+        # straight-line passes.  fp32: layer 1 with a raw node operand (2, the second refilling its registers) + layer 1 without (1)
+        # + middle + output + the POST loop body = 6; bf16x3: node-operand pass + aggregate pass (shared by both modes) + 3 = 5
+        assert len(mfma) == (5 * 96 if x3 else 6 * 256), (name, len(mfma))
+        # branches between the first and the last MFMA: per-chunk partial DMA round (12 waves), pass hand-overs, operand-mode tests
+        first = next(i for i, ln in enumerate(lines) if ln.startswith("v_mfma"))
+        last = max(i for i, ln in enumerate(lines) if ln.startswith("v_mfma"))
+        branches = sum(1 for ln in lines[first:last] if ln.startswith("s_cbranch"))
+        # (the last chunk of a pass tests "is there a next pass" once per DMA round: 16 rounds with 4 waves, 6 with 12; a branch per
+        # K-step / MFMA group in EVERY chunk would be >= 384 (fp32: 24 chunks x 16 K-steps) / >= 120 (bf16x3: 20 chunks x 6 groups))
+        print(name, "VGPRs", vgpr, "branches between first and last MFMA", branches)
+        assert branches <= (100 if x3 else 200), (name, branches)
