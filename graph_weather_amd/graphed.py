@@ -18,8 +18,8 @@ modules / parameters swapped into the model after the first call (the module wal
 
 Input: the graph reads a fixed address.  By default that is the graph's own buffer and each call copies the batch into it (a
 device-to-device copy, 53 MB at 1 degree / batch 2: ~20 us).  When the caller hands over the SAME buffer call after call (a
-rollout writing step t's output into step t + 1's input, a serving loop with a staging buffer) the graph is re-captured once on
-that buffer and replays with no copy at all; a different buffer later sends it back to its own.
+rollout writing step t's output into step t + 1's input, a serving loop with a staging buffer) the graph is captured on - or
+re-captured once onto - that buffer and replays with no copy at all; a different buffer later sends it back to its own.
 
 ``AutoGraph`` is how ``GraphWeatherForecaster.forward`` uses this by itself: in ``eval()`` under ``torch.no_grad()``, for small
 inputs, from the third call of one shape on the eager forward is replaced by the replay (output cloned out of the graph's buffer, so
@@ -114,7 +114,7 @@ class ForwardGraph:
         self._graph = g
         self.captures += 1
 
-    def __call__(self, features: Optional[torch.Tensor] = None, clone: bool = False) -> torch.Tensor:
+    def __call__(self, features: Optional[torch.Tensor] = None, clone: bool = False, pin_now: bool = False) -> torch.Tensor:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()) and self.model.training:
             raise RuntimeError("graph_weather_amd: ForwardGraph replays the inference forward - call it on model.eval() "
                                "(training steps go through autograd, which a static graph cannot follow)")
@@ -129,7 +129,9 @@ class ForwardGraph:
         self._same_ptr = self._same_ptr + 1 if ptr == self._last_ptr else 1
         self._last_ptr = ptr
         if self._graph is None or key != self._key:
-            self._capture(features, pin=self.pinned and ptr == self.input.data_ptr() and features.is_contiguous())
+            # (pin_now: the caller has already seen this buffer on its previous calls - AutoGraph counts them while it runs eager)
+            keep = self.pinned and self.input is not None and ptr == self.input.data_ptr()
+            self._capture(features, pin=(keep or (pin_now and self._pin_ok)) and features.is_contiguous())
             self._key = key
         elif ptr != self.input.data_ptr():
             if self.pinned:  # a pinned graph reads somebody's buffer: never write into that - back to an own buffer, for good
@@ -157,6 +159,8 @@ class AutoGraph:
         self.enabled = os.environ.get("GW_AUTO_GRAPH", "1") != "0"
         self._shape = None
         self._seen = 0
+        self._ptr = None
+        self._ptr_same = 0  # consecutive calls that handed over the same buffer
         self._fg: Optional[ForwardGraph] = None
 
     def usable(self, features: torch.Tensor) -> bool:
@@ -173,6 +177,9 @@ class AutoGraph:
         if shape != self._shape:
             self._shape, self._seen = shape, 0
         self._seen += 1
+        ptr = features.data_ptr()
+        self._ptr_same = self._ptr_same + 1 if ptr == self._ptr else 1
+        self._ptr = ptr
         if self._seen <= self.after:
             return None
         if self._fg is None:
@@ -184,7 +191,9 @@ class AutoGraph:
             self._seen = 1
             return None
         try:
-            return self._fg(features, clone=True)
+            # a buffer that came back on every call so far (a rollout's input, a staging buffer, a benchmark loop) is read in
+            # place from the first capture on; fresh tensors per call get the graph's own input buffer and a copy per call
+            return self._fg(features, clone=True, pin_now=self._ptr_same > self.after)
         except Exception as exc:  # a forward the capture cannot follow: say so once, stay eager from here on
             self.enabled = False
             self._fg = None
