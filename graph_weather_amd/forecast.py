@@ -11,6 +11,7 @@ from typing import Optional
 
 import torch
 
+from .graphed import AutoGraphModule
 from .graphs import TopologyRecord, build_forecast_graphs
 from .layers import Decoder, Encoder, Processor, fused_forward, set_compute_dtype
 
@@ -48,7 +49,7 @@ class GraphWeatherForecasterConfig:
         return GraphWeatherForecaster(**self.__dict__)
 
 
-class GraphWeatherForecaster(TopologyRecord, torch.nn.Module, PyTorchModelHubMixin):
+class GraphWeatherForecaster(AutoGraphModule, TopologyRecord, torch.nn.Module, PyTorchModelHubMixin):
     """forecast.py:61-247 (constraint layer and thermalizer are optional extras outside the hot path)."""
 
     def __init__(self, lat_lons: list, resolution: int = 2, feature_dim: int = 78, aux_dim: int = 24,
@@ -146,29 +147,12 @@ class GraphWeatherForecaster(TopologyRecord, torch.nn.Module, PyTorchModelHubMix
             graph[..., node_idx, :] = grid_tensor[..., row, col]
         return graph
 
-    # eval() + torch.no_grad() + a small input: after a few calls of one shape the forward is replayed from one HIP graph
-    # (graphed.AutoGraph; same launches, output cloned out of the graph's buffer).  ``model.auto_graph = False`` or
-    # GW_AUTO_GRAPH=0 keeps every call eager.
-    auto_graph = True
-
-    def __getstate__(self):
-        state = self.__dict__.copy()
-        state.pop("_auto", None)  # a captured HIP graph is neither copied nor pickled with the module
-        return state
-
     def forward(self, features: torch.Tensor, t: int = 0) -> torch.Tensor:
         """forecast.py:215-247 with constraint_type == "none".  Fused path: data stays in the native layouts
-        (dst-sorted shared graph, cached batch-independent embeddings) between encoder, processor and decoder."""
-        if self.auto_graph and features.is_cuda and features.dtype == torch.float32 and not self.training and not torch.is_grad_enabled():
-            auto = self.__dict__.get("_auto")
-            if auto is None:
-                from .graphed import AutoGraph
-
-                auto = self.__dict__["_auto"] = AutoGraph(self)
-            y = auto.step(features)
-            if y is not None:
-                return y
-        return self._forward_eager(features)
+        (dst-sorted shared graph, cached batch-independent embeddings) between encoder, processor and decoder.  In eval() under
+        no_grad() the call replays its own HIP graph from the third call of a shape on (graphed.AutoGraphModule)."""
+        y = self._auto_graph_step(features)
+        return y if y is not None else self._forward_eager(features)
 
     def _forward_eager(self, features: torch.Tensor) -> torch.Tensor:
         if not features.is_cuda:

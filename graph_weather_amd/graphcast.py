@@ -14,11 +14,12 @@ import torch
 
 from . import autograd as ag
 from . import wide
+from .graphed import AutoGraphModule
 from .graphs import TopologyRecord, build_forecast_graphs
 from .layers import Decoder, Encoder, Processor, fused_forward
 
 
-class GraphCast(TopologyRecord, torch.nn.Module):
+class GraphCast(AutoGraphModule, TopologyRecord, torch.nn.Module):
     def __init__(self, lat_lons: list, resolution: int = 2, input_dim: int = 78, output_dim: int = 78, hidden_dim: int = 256,
                  num_processor_blocks: int = 9, hidden_layers: int = 2, mlp_norm_type: str = "LayerNorm",
                  use_checkpointing: bool = False, efficient_batching: bool = False):
@@ -111,7 +112,12 @@ class GraphCast(TopologyRecord, torch.nn.Module):
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
         """graphcast/model.py:264-286: ``decoder(processor(encoder(features)), features)`` - the input itself is the residual,
-        so ``input_dim`` must equal ``output_dim`` as in the reference (decoder.py:93)."""
+        so ``input_dim`` must equal ``output_dim`` as in the reference (decoder.py:93).  In eval() under no_grad() the call
+        replays its own HIP graph from the third call of a shape on (graphed.AutoGraphModule)."""
+        y = self._auto_graph_step(features)
+        return y if y is not None else self._forward_eager(features)
+
+    def _forward_eager(self, features: torch.Tensor) -> torch.Tensor:
         if not features.is_cuda:
             raise RuntimeError("graph_weather_amd: features must be on a HIP device - there is no CPU path")
         if features.dim() != 3 or features.shape[2] != self.output_dim:

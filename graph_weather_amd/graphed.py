@@ -27,8 +27,10 @@ the module keeps the semantics of an ordinary call); anything the capture cannot
 """
 from __future__ import annotations
 
+import gc
 import os
 import warnings
+import weakref
 from typing import Optional
 
 import torch
@@ -46,8 +48,12 @@ class ForwardGraph:
     keep passing one and the same buffer (see the module docstring: ``pin_after`` consecutive calls with one address re-capture
     the graph on that buffer)."""
 
-    def __init__(self, model: nn.Module, warmup: int = 3, pin_after: int = 3):
-        self.model = model
+    def __init__(self, model: nn.Module, warmup: int = 3, pin_after: int = 3, weak: bool = False):
+        # ``weak`` (AutoGraph): the model owns this object, so this object must not own the model - a reference cycle would
+        # leave the captured HIP graph to the cyclic garbage collector, which may run in the middle of ANOTHER capture, where
+        # destroying a graph is "not permitted when stream is capturing" and the exception leaves a destructor (abort)
+        self._model_ref = weakref.ref(model) if weak else None
+        self._model = None if weak else model
         self.warmup = int(warmup)
         self.pin_after = int(pin_after)
         self._key = None
@@ -62,6 +68,13 @@ class ForwardGraph:
         self._pin_ok = True       # one unpin (a caller that alternates buffers) ends the attempts
         self._last_ptr = None
         self._same_ptr = 0
+
+    @property
+    def model(self) -> nn.Module:
+        m = self._model if self._model_ref is None else self._model_ref()
+        if m is None:
+            raise RuntimeError("graph_weather_amd: the model of this ForwardGraph no longer exists")
+        return m
 
     def invalidate(self) -> None:
         """Forget the capture and the cached module walk: the next call re-captures (after edits no version counter shows:
@@ -95,24 +108,42 @@ class ForwardGraph:
             raise RuntimeError("graph_weather_amd: a kernel timer is active (HIP events cannot be recorded into a graph)")
         dev = features.device
         self._graph = None  # (release the previous graph's memory pool before building the next)
-        if pin:
-            self.input = features  # the caller's buffer; the reference keeps its memory mapped for the graph's lifetime
-        else:
-            self.input = torch.empty_like(features)
-            self.input.copy_(features)
-        self.pinned = pin
-        # warm-up on the CURRENT stream: packed weights, cached embeddings, graph plans, side streams and every per-device kernel
-        # attribute exist before the capture starts (nothing of that may happen inside it), and every cache entry belongs to
-        # the stream that will read it later (a side-stream warm-up left them owned by a stream nobody synchronises with)
-        with torch.no_grad():
+        # Everything below runs with inference mode switched OFF locally (and no_grad on): torch.cuda.graph keeps the default
+        # generator's graph-safe seed / offset tensors alive across captures and updates them IN PLACE at the start of every
+        # later capture - created under a caller's torch.inference_mode() they would be inference tensors, the next capture outside
+        # inference mode would fail half-way ("Inplace update to inference tensor ...") and leave the generator in its
+        # capturing state, after which every torch.rand on the device raises.  The same goes for the graph's own buffers.
+        # ... and with the cyclic garbage collector held off: garbage that owns HIP graphs, events or streams (somebody's dropped
+        # model, a finished ForwardGraph) must be destroyed BEFORE the capture starts, never inside it (see __init__).
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            self._capture_locked(features, pin, dev)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        self.captures += 1
+
+    def _capture_locked(self, features: torch.Tensor, pin: bool, dev) -> None:
+        with torch.inference_mode(False), torch.no_grad():
+            if pin:
+                self.input = features  # the caller's buffer; the reference keeps its memory mapped for the graph's lifetime
+            else:
+                self.input = torch.empty_like(features)
+                self.input.copy_(features)
+            self.pinned = pin
+            # warm-up on the CURRENT stream: packed weights, cached embeddings, graph plans, side streams and every per-device
+            # kernel attribute exist before the capture starts (nothing of that may happen inside it), and every cache entry
+            # belongs to the stream that will read it later (a side-stream warm-up left them owned by a stream nobody
+            # synchronises with)
             for _ in range(max(1, self.warmup)):
                 self._eager(self.input)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
-            self.output = self._eager(self.input)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.output = self._eager(self.input)
         self._graph = g
-        self.captures += 1
 
     def __call__(self, features: Optional[torch.Tensor] = None, clone: bool = False, pin_now: bool = False) -> torch.Tensor:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()) and self.model.training:
@@ -154,7 +185,7 @@ class AutoGraph:
     # the graph's private pool (every intermediate of the forward, held for the graph's lifetime) is not worth it
 
     def __init__(self, model: nn.Module, after: int = 2):
-        self.model = model
+        self._model_ref = weakref.ref(model)  # (the model owns this object: no cycle, see ForwardGraph.__init__)
         self.after = int(after)
         self.enabled = os.environ.get("GW_AUTO_GRAPH", "1") != "0"
         self._shape = None
@@ -166,7 +197,8 @@ class AutoGraph:
     def usable(self, features: torch.Tensor) -> bool:
         from . import ops
 
-        return (self.enabled and not self.model.training and not torch.is_grad_enabled() and features.is_cuda
+        model = self._model_ref()
+        return (self.enabled and model is not None and not model.training and not torch.is_grad_enabled() and features.is_cuda
                 and features.numel() * features.element_size() <= self.MAX_INPUT_BYTES and ops.TIMER is None
                 and not torch.cuda.is_current_stream_capturing())
 
@@ -183,7 +215,7 @@ class AutoGraph:
         if self._seen <= self.after:
             return None
         if self._fg is None:
-            self._fg = ForwardGraph(self.model, warmup=1)
+            self._fg = ForwardGraph(self._model_ref(), warmup=1, weak=True)
         elif self._fg._graph is not None and self._fg._state_key(features.shape, features.device, features.dtype) != self._fg._key:
             # weights / dtype / flags changed under the graph: drop it and count afresh - a loop that alternates weight updates
             # and evaluation forwards must not pay a capture (three forwards' worth) per call
@@ -201,3 +233,27 @@ class AutoGraph:
                           "(%s: %s); the eager path is used" % (type(exc).__name__, exc))
             torch.cuda.synchronize(features.device)
             return None
+
+
+class AutoGraphModule:
+    """Mixin of the models whose eval forward may replay itself (``GraphWeatherForecaster``, ``GraphCast``): the class flag, the
+    per-instance policy object kept out of copies and pickles, and the one call ``forward`` makes before its eager path
+    (``_forward_eager``, which ``ForwardGraph`` calls for warm-up and capture)."""
+
+    # eval() + torch.no_grad() + a small input: from the third call of a shape on the forward is replayed from one HIP graph
+    # (same launches, output cloned out of the graph's buffer).  ``model.auto_graph = False`` or GW_AUTO_GRAPH=0: every call eager.
+    auto_graph = True
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_auto", None)  # a captured HIP graph is neither copied nor pickled with the module
+        return state
+
+    def _auto_graph_step(self, features: torch.Tensor) -> Optional[torch.Tensor]:
+        if not (self.auto_graph and features.is_cuda and features.dtype == torch.float32 and not self.training
+                and not torch.is_grad_enabled()):
+            return None
+        auto = self.__dict__.get("_auto")
+        if auto is None:
+            auto = self.__dict__["_auto"] = AutoGraph(self)
+        return auto.step(features)

@@ -100,3 +100,31 @@ def test_auto_graph_policy_on_the_host():
     with pytest.raises(RuntimeError, match="no CPU path"):
         with torch.no_grad():
             model(x)
+
+
+def test_a_model_with_an_automatic_graph_is_freed_by_reference_count():
+    """The model owns its AutoGraph (and through it the ForwardGraph and the captured HIP graph); neither may own the model back:
+    in a cycle the graph would be destroyed by the cyclic collector at an arbitrary moment - inside another capture that aborts
+    the process (round 6, `~CUDAGraph`: "operation not permitted when stream is capturing")."""
+    import gc
+    import weakref
+
+    from graph_weather_amd.graphed import AutoGraph
+
+    gc.collect()
+    gc.disable()
+    try:
+        model = _model()
+        auto = AutoGraph(model)
+        auto._fg = gw.ForwardGraph(model, warmup=1, weak=True)
+        auto._fg._state_key((1, 72, 102), "cuda:0", torch.float32)  # (the cached module walk holds sub-modules, not the model)
+        model.__dict__["_auto"] = auto
+        probe, fg_probe = weakref.ref(model), weakref.ref(auto._fg)
+        del auto
+        del model
+        assert probe() is None and fg_probe() is None  # gone without a collector pass
+    finally:
+        gc.enable()
+    fg = gw.ForwardGraph(_model(), weak=True)
+    with pytest.raises(RuntimeError, match="no longer exists"):
+        fg.model

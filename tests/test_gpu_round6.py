@@ -245,3 +245,49 @@ def test_rollout_through_the_automatic_graph_equals_the_eager_rollout():
     out = rollout(model, feats, 6)
     assert len(out) == 6 and all(torch.equal(o, r) for o, r in zip(out, ref))
     assert model.__dict__["_auto"]._fg.pinned
+
+
+def test_graphcast_wrapper_replays_itself_too():
+    """graphcast/model.py:264-286 behind the same policy: the reference's own fast entry point (its benchmark script times this
+    wrapper) replays one HIP graph in eval() under no_grad(); gradient mode keeps the checkpointed autograd path."""
+    lat_lons = regular_lat_lons(10.0)
+    model = gw.GraphCast(lat_lons, efficient_batching=True)
+    deterministic_fill_(model, seed=2)
+    model = model.to(DEV).eval()
+    gw.set_deterministic(model, True)
+    x = seeded_features(2, len(lat_lons), 78, seed=4).to(DEV)
+    with torch.no_grad():
+        ref = model._forward_eager(x)
+        ys = [model(x) for _ in range(5)]
+    auto = model.__dict__["_auto"]
+    assert auto._fg is not None and auto._fg.captures == 1 and auto._fg.pinned
+    assert all(torch.equal(y, ref) for y in ys)
+    gw.set_deterministic(model, False)
+    model.train()
+    xg = x.clone().requires_grad_(True)
+    model(xg).sum().backward()
+    assert torch.isfinite(xg.grad).all()
+
+
+def test_automatic_graph_under_inference_mode_leaves_the_generator_and_later_captures_intact():
+    """torch.cuda.graph updates the default generator's graph-safe state tensors in place at the start of every capture: were they
+    created under a caller's ``torch.inference_mode()`` (the automatic graph capturing there), the next capture in normal mode
+    would fail half-way and every later ``torch.rand`` on the device would raise.  The capture therefore runs with inference
+    mode locally off: a replayed forward under inference_mode, device RNG afterwards, a second capture in normal mode."""
+    model, lat_lons = _forecaster()
+    x = seeded_features(1, len(lat_lons), 102, seed=8).to(DEV)
+    with torch.inference_mode():
+        ys = [model(x) for _ in range(4)]
+    auto = model.__dict__["_auto"]
+    assert auto.enabled and auto._fg is not None and auto._fg.captures == 1
+    with torch.no_grad():
+        ref = model._forward_eager(x)
+    assert all((y - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() for y in ys)
+    r = torch.rand(16, device=DEV) + torch.randn(16, device=DEV)  # the device generator still works
+    assert torch.isfinite(r).all()
+    other, _ = _forecaster(seed=1)
+    fg = gw.ForwardGraph(other)
+    with torch.no_grad():
+        y = fg(x).clone()
+        assert fg.captures == 1 and (y - other._forward_eager(x)).abs().max().item() <= 1e-5 * y.abs().max().item()
+    assert torch.isfinite(torch.rand(4, device=DEV)).all()
