@@ -16,7 +16,7 @@ from torch import nn
 
 from . import ops
 from .graphs import build_latent_graph, build_observation_graph
-from .layers import (AssimilatorDecoder, Feed, GraphProcessor, MLP, Processor, _autograd_on, _check_native_dims, _ver,
+from .layers import (AssimilatorDecoder, Feed, GraphProcessor, KeyedCache, MLP, Processor, _autograd_on, _check_native_dims, _ver,
                      _version_key)
 from .ops import Operand
 
@@ -51,9 +51,8 @@ class AssimilatorEncoder(nn.Module):
         self.graph_processor = GraphProcessor(1, output_dim, output_edge_dim, hidden_dim_processor_node,
                                               hidden_dim_processor_edge, hidden_layers_processor_node,
                                               hidden_layers_processor_edge, mlp_norm_type)
-        self._obs_cache = None
         self._dev = {}
-        self._cache = {}
+        self._cache = KeyedCache()  # "obs" (observation graph per position tensor) + the batch-independent embeddings
 
     def _latent_plan(self, device):
         key = str(device)
@@ -65,19 +64,13 @@ class AssimilatorEncoder(nn.Module):
         """assimilator_encoder.py:166-219, once per distinct position tensor."""
         llh = lat_lon_heights.reshape(-1, 3) if lat_lon_heights.dim() == 2 else lat_lon_heights[0]
         key = (lat_lon_heights.data_ptr(), _ver(lat_lon_heights), tuple(lat_lon_heights.shape), str(device))
-        if self._obs_cache is None or self._obs_cache[0] != key or self._obs_cache[2] is not lat_lon_heights:
-            _, _, plan = build_observation_graph(llh.detach().cpu().numpy(), self.resolution)
-            self._obs_cache = (key, plan.to(device), lat_lon_heights)  # holds the tensor: its address stays taken
-        return self._obs_cache[1]
+        return self._cache.get("obs", key, lambda: build_observation_graph(llh.detach().cpu().numpy(), self.resolution)[2].to(device),
+                               hold=lat_lon_heights)  # (the entry holds the tensor: its address stays taken)
 
     def _cached(self, name, params, fn):
         if _autograd_on(self):
             return fn()
-        key = _version_key(params)
-        hit = self._cache.get(name)
-        if hit is None or hit[0] != key:
-            self._cache[name] = (key, fn())
-        return self._cache[name][1]
+        return self._cache.get(name, _version_key(params), fn)
 
     def latent_edge_embedding(self, plan) -> torch.Tensor:
         return self._cached("lat_e", list(self.latent_edge_encoder.parameters()), lambda: self.latent_edge_encoder.table(plan.edge_attr))

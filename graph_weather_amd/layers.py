@@ -43,6 +43,31 @@ def _version_key(params) -> tuple:
     return tuple((p.data_ptr(), _ver(p), p.device) for p in params)
 
 
+class KeyedCache:
+    """The per-module caches of batch-independent tensors (edge / mesh embeddings, their layer-1 products, tile forms, graph
+    plans): ``get(name, key, make, hold=None)`` returns the entry made for ``key`` or makes it.  Keys are built from
+    ``_version_key`` (address + version counter of every parameter involved) and/or the address + version of an input tensor;
+    an entry whose key contains a tensor's ADDRESS also ``hold``s that tensor - while the entry lives the address cannot be
+    recycled for another tensor, and a different object at the same address is a miss.  One class for what used to be four
+    hand-rolled tuples (``_cache``, ``_e0_cache``, ``_e0_seg_cache``, ``_plan_cache``)."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def get(self, name: str, key, make, hold=None):
+        hit = self._entries.get(name)
+        if hit is None or hit[0] != key or hit[2] is not hold:
+            hit = (key, make(), hold)
+            self._entries[name] = hit
+        return hit[1]
+
+    def clear(self) -> None:
+        self._entries.clear()
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._entries
+
+
 def _autograd_on(module: nn.Module, *inputs: Optional[torch.Tensor]) -> bool:
     """True when the call must be differentiable: grad mode on and either the module has trainable parameters or one of the
     given input tensors requires grad (a frozen block downstream of a trainable one must still pass gradients through)."""
@@ -125,12 +150,8 @@ def set_compute_dtype(module: nn.Module, dtype) -> nn.Module:
     for m in module.modules():
         if isinstance(m, MLP):
             m.compute_dtype = dtype
-        for attr in ("_cache",):
-            if hasattr(m, attr):
-                getattr(m, attr).clear()
-        if hasattr(m, "_e0_cache"):
-            m._e0_cache = None
-            m._e0_seg_cache = None
+        if isinstance(getattr(m, "_cache", None), KeyedCache):
+            m._cache.clear()
     return module
 
 
@@ -439,9 +460,7 @@ class GraphProcessor(nn.Module):
                                                            hidden_layers_node, hidden_layers_edge, norm_type))
         self.checkpoint_segments = 0  # processor.py:70-81, set through Processor.set_checkpoint_segments
         self.streams = 0  # HIP streams of the fused inference forward: 0 = automatic (see forward_streams), 1 = one stream
-        self._plan_cache = None
-        self._e0_cache = None
-        self._e0_seg_cache = None
+        self._cache = KeyedCache()  # "plan" (user COO graph), "e0_pe" / "e0_tiles" / "e0_seg" (block 0's batch-shared edge features)
         self._side_streams = {}
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
@@ -537,26 +556,26 @@ class GraphProcessor(nn.Module):
         """(We . e in padded order, e as one shared set of bf16 edge tiles over the padded list) of batch-independent edge
         features on segment-aligned tiles, cached per (e, weights)."""
         key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key(), seg.n_pad)
-        hit = getattr(self, "_e0_seg_cache", None)
-        if hit is None or hit[0] != key or hit[3] is not e_cur:
+
+        def make():
             pe = self._shared_e0(blk, e_cur, int(e_cur.shape[0]), tiles=False)[1]
-            e_pad = seg.pad_rows(e_cur)
-            self._e0_seg_cache = (key, seg.pad_rows(pe), ops.edge_rows_to_tiles(e_pad, 1, seg.n_pad, seg.n_pad), e_cur)
-        return self._e0_seg_cache[1], self._e0_seg_cache[2]
+            return seg.pad_rows(pe), ops.edge_rows_to_tiles(seg.pad_rows(e_cur), 1, seg.n_pad, seg.n_pad)
+
+        return self._cache.get("e0_seg", key, make, hold=e_cur)
 
     def _shared_e0(self, blk, e_cur: torch.Tensor, n_edges: int, tiles: bool = True):
-        """(We . e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights).
+        """(key, We . e, e, [e as one shared set of bf16 edge tiles]) of batch-independent edge features, cached per (e, weights).
         ``tiles=False``: the caller reads only the product (the segment-tile route keeps its own padded tile set)."""
         mlp_e = blk.edge_model.edge_mlp
         pm_e = mlp_e.packed()
-        tiled = routes.resident_bf16(routes.MlpForm.of(mlp_e, pm_e), n_edges)
         key = (e_cur.data_ptr(), _ver(e_cur), blk.params_key())
-        if self._e0_cache is None or self._e0_cache[0] != key or self._e0_cache[2] is not e_cur:
-            pe = ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0]
-            self._e0_cache = (key, pe, e_cur)  # holds e_cur: its address cannot be reused while the entry lives
-        if tiled and tiles and len(self._e0_cache) == 3:  # the residual of the resident bf16 kernel: e as one shared tile set
-            self._e0_cache = self._e0_cache + (ops.edge_rows_to_tiles(e_cur, 1, n_edges, n_edges),)
-        return self._e0_cache
+        pe = self._cache.get("e0_pe", key, lambda: ops.project_forward([pm_e.w1[2]], Operand(e_cur, n_edges, 256), n_edges, n_edges)[0],
+                             hold=e_cur)
+        out = (key, pe, e_cur)
+        if tiles and routes.resident_bf16(routes.MlpForm.of(mlp_e, pm_e), n_edges):
+            # the residual of the resident bf16 kernel: e as one shared tile set
+            out = out + (self._cache.get("e0_tiles", key, lambda: ops.edge_rows_to_tiles(e_cur, 1, n_edges, n_edges), hold=e_cur),)
+        return out
 
     def _run_blocks(self, lo: int, hi: int, x: torch.Tensor, e: torch.Tensor, e_shared: bool, plan: GraphPlan, batch: int,
                     want_edges: bool, pre_proj=None, tail_w=None, tail_half: bool = False):
@@ -657,17 +676,17 @@ class GraphProcessor(nn.Module):
 
     def _plan_for(self, edge_index: torch.Tensor, num_nodes: int) -> GraphPlan:
         key = (edge_index.data_ptr(), tuple(edge_index.shape), _ver(edge_index), num_nodes)
-        if self._plan_cache is not None and self._plan_cache[0] == key and self._plan_cache[2] is edge_index:
-            return self._plan_cache[1]
-        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
-            raise RuntimeError("edge_index must be [2, E] in COO format")
-        if edge_index.numel() and (int(edge_index.min()) < 0 or int(edge_index.max()) >= num_nodes):
-            raise IndexError("edge_index refers to nodes outside x")
-        dst_sorted, perm = torch.sort(edge_index[1], stable=True)
-        plan = GraphPlan(num_nodes, num_nodes, edge_index[0][perm].to(torch.int32).contiguous(),
-                         dst_sorted.to(torch.int32).contiguous(), perm, None)
-        self._plan_cache = (key, plan, edge_index)  # holds edge_index: its address cannot be reused while the entry lives
-        return plan
+
+        def make():
+            if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+                raise RuntimeError("edge_index must be [2, E] in COO format")
+            if edge_index.numel() and (int(edge_index.min()) < 0 or int(edge_index.max()) >= num_nodes):
+                raise IndexError("edge_index refers to nodes outside x")
+            dst_sorted, perm = torch.sort(edge_index[1], stable=True)
+            return GraphPlan(num_nodes, num_nodes, edge_index[0][perm].to(torch.int32).contiguous(),
+                             dst_sorted.to(torch.int32).contiguous(), perm, None)
+
+        return self._cache.get("plan", key, make, hold=edge_index)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """graph_net_block.py:279-301 for an arbitrary COO graph (the reference's random-graph test,
@@ -714,7 +733,7 @@ class Encoder(nn.Module):
                                               hidden_dim_processor_edge, hidden_layers_processor_node,
                                               hidden_layers_processor_edge, mlp_norm_type, use_checkpointing)
         self._dev_plans = {}
-        self._cache = {}
+        self._cache = KeyedCache()
 
     # plans live outside state_dict (like encoder.graph / encoder.latent_graph, encoder.py:107,109)
     def _plans(self, device):
@@ -726,11 +745,7 @@ class Encoder(nn.Module):
     def _cached(self, name: str, params, fn):
         if _autograd_on(self):  # training: batch-independent embeddings are part of the graph, recomputed every step
             return fn()
-        key = _version_key(params)
-        hit = self._cache.get(name)
-        if hit is None or hit[0] != key:
-            self._cache[name] = (key, fn())
-        return self._cache[name][1]
+        return self._cache.get(name, _version_key(params), fn)
 
     def mesh_embedding(self) -> torch.Tensor:
         """node_encoder(h3_nodes): batch independent (encoder.py:199-205 recomputes it for every sample)."""
@@ -948,7 +963,7 @@ class AssimilatorDecoder(nn.Module):
                                               use_checkpointing=use_checkpointing)
         self.node_decoder = MLP(input_dim, output_dim, hidden_dim_decoder, hidden_layers_decoder, None, use_checkpointing)
         self._dev_plans = {}
-        self._cache = {}
+        self._cache = KeyedCache()
 
     def _plan(self, device) -> GraphPlan:
         key = str(device)
@@ -959,11 +974,7 @@ class AssimilatorDecoder(nn.Module):
     def edge_embedding(self, plan: GraphPlan) -> torch.Tensor:
         if _autograd_on(self):
             return self.edge_encoder.table(plan.edge_attr)
-        key = _version_key(list(self.edge_encoder.parameters()))
-        hit = self._cache.get("dec_e")
-        if hit is None or hit[0] != key:
-            self._cache["dec_e"] = (key, self.edge_encoder.table(plan.edge_attr))
-        return self._cache["dec_e"][1]
+        return self._cache.get("dec_e", _version_key(list(self.edge_encoder.parameters())), lambda: self.edge_encoder.table(plan.edge_attr))
 
     def team_path(self) -> bool:
         """Inference in bf16 with everything the team-pipelined edge kernel needs (csrc/gw_edge16t.hip): one middle layer,
@@ -1018,40 +1029,32 @@ class AssimilatorDecoder(nn.Module):
             elif ps.dtype == torch.float16 and not team:
                 raise RuntimeError("graph_weather_amd: fp16 layer-1 products were handed to a decoder that cannot take them")
             key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
-            hit = self._cache.get("dec_pe")
-            if hit is None or hit[0] != key:
-                self._cache["dec_pe"] = (key, ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
-            pe = self._cache["dec_pe"][1]
+            e_rows = e
+            pe = self._cache.get("dec_pe", key, lambda: ops.project_forward([pm_e.w1[2]], Operand(e_rows, n_e, 256), n_e, n_e)[0])
             seg = plan.seg_tiles() if team else None
             if seg is not None:  # the per-edge product in the padded order of the segment-aligned tiles
-                hit = self._cache.get("dec_pe_pad")
-                if hit is None or hit[0] != key:
-                    self._cache["dec_pe_pad"] = (key, seg.pad_rows(pe))
-                pe = self._cache["dec_pe_pad"][1]
+                pe_rows = pe
+                pe = self._cache.get("dec_pe_pad", key, lambda: seg.pad_rows(pe_rows))
             x_node = FEED_ZERO
             x3 = self.split_path()
             if x3 or routes.resident_bf16(_form(mlp_e), n_e):
                 pm_n = blk.node_model.node_mlp.packed()
                 if not (team or x3):
                     # residual of the resident bf16 kernel: the cached edge embedding as one shared set of bf16 edge tiles
-                    hit = self._cache.get("dec_e_tiles")
-                    if hit is None or hit[0] != key:
-                        self._cache["dec_e_tiles"] = (key, ops.edge_rows_to_tiles(e, 1, n_e, n_e))
-                    e = self._cache["dec_e_tiles"][1]
+                    e = self._cache.get("dec_e_tiles", key, lambda: ops.edge_rows_to_tiles(e_rows, 1, n_e, n_e))
                 else:
                     # e' itself is dropped (assimilator_decoder.py:195) and e is the same for every sample, so
                     #   agg = sum(LN(.) + e) = sum(LN(.)) + S,  S[dst] = sum of e over the destination's edges (batch independent),
                     # and layer 1 of the node update (graph_net_block.py:189, x == 0) is Wa.agg = Wa.sum(LN(.)) + Wa.S: the edge
                     # kernel adds no residual at all, and Wa.S enters the node update as a cached, batch-shared PROJECTED operand
                     # in the slot of the all-zero x rows.
-                    hit = self._cache.get("dec_e_sum")
-                    if hit is None or hit[0] != key:
-                        e_sum = ag.segment_sum_rows(e, n_e, 1, 1, plan.n_dst, plan.dst_ptr(), None)
+                    def make_e_sum():
+                        e_sum = ag.segment_sum_rows(e_rows, n_e, 1, 1, plan.n_dst, plan.dst_ptr(), None)
                         # (bf16 mode: fp16 rows, like every layer-1 product of that path: the node update adds them to its fp32
                         # accumulator and rounds the sum to bf16; bf16x3: fp32 rows)
-                        self._cache["dec_e_sum"] = (key, ops.project_forward([pm_n.w1[1]], Operand(e_sum, plan.n_dst, 256),
-                                                                             plan.n_dst, plan.n_dst, out_half=team)[0])
-                    x_node = Feed(self._cache["dec_e_sum"][1], 0, "proj")
+                        return ops.project_forward([pm_n.w1[1]], Operand(e_sum, plan.n_dst, 256), plan.n_dst, plan.n_dst, out_half=team)[0]
+
+                    x_node = Feed(self._cache.get("dec_e_sum", key, make_e_sum), 0, "proj")
                     e = None
         res = None
         if residual is not None:

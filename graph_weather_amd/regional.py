@@ -27,7 +27,7 @@ from . import autograd as ag
 from . import mesh as _mesh
 from . import ops
 from .graphs import GraphPlan, _sincos, plan_from_coo
-from .layers import FEED_ZERO, Feed, GraphProcessor, MLP, Processor, _autograd_on, _check_native_dims, _version_key
+from .layers import FEED_ZERO, Feed, GraphProcessor, KeyedCache, MLP, Processor, _autograd_on, _check_native_dims, _version_key
 from .ops import Operand
 from .utils import validate_lat_lons
 
@@ -320,17 +320,13 @@ class RegionalForecaster(nn.Module):
                                           c.hidden_layers_processor_node, c.hidden_layers_processor_edge, c.norm_type,
                                           use_checkpointing=c.use_checkpointing)
         self.node_decoder = MLP(c.node_dim, output_dim, c.hidden_dim_decoder, c.hidden_layers_decoder, **mk)
-        self._cache = {}
+        self._cache = KeyedCache()
 
     def _cached(self, name: str, params, token, fn):
         """Batch-independent tensors of the inference path: recomputed when a parameter or the coordinate set changes."""
         if _autograd_on(self):
             return fn()
-        key = (_version_key(params), token)
-        hit = self._cache.get(name)
-        if hit is None or hit[0] != key:
-            self._cache[name] = (key, fn())
-        return self._cache[name][1]
+        return self._cache.get(name, (_version_key(params), token), fn)
 
     def _is_wide(self) -> bool:
         from . import wide

@@ -382,14 +382,13 @@ def _cached(owner, name: str, params, fn, of: Optional[torch.Tensor] = None):
     params = list(params)
     if torch.is_grad_enabled() and (any(p.requires_grad for p in params) or (of is not None and of.requires_grad)):
         return fn()
-    from .layers import _ver, _version_key
+    from .layers import KeyedCache, _ver, _version_key
 
-    cache = owner.__dict__.setdefault("_wide_cache", {})
+    cache = owner.__dict__.get("_wide_cache")
+    if cache is None:
+        cache = owner.__dict__["_wide_cache"] = KeyedCache()
     key = _version_key(params) + (() if of is None else ((of.data_ptr(), _ver(of), tuple(of.shape)),))
-    hit = cache.get(name)
-    if hit is None or hit[0] != key or hit[2] is not of:
-        cache[name] = (key, fn(), of)
-    return cache[name][1]
+    return cache.get(name, key, fn, hold=of)
 
 
 def block(blk, plan: GraphPlan, batch: int, x_src: torch.Tensor, src_rows_pb: int, x_dst: Optional[torch.Tensor], dst_rows_pb: int,
