@@ -243,7 +243,7 @@ __device__ __forceinline__ const float* operand_row(const float* ptr, const int*
   return ptr + ((size_t)b * (size_t)rows_pb + (size_t)r) * (size_t)ld;
 }
 
-template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE = false, bool POST = false>
+template <int K1S, bool K1FULL, int NSEG, int HT, int OT, int EPI, bool SINGLE = false, bool POST = false, bool HEAD = false>
 __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HS = HT * 4;                   // K-steps of a hidden layer
@@ -402,8 +402,10 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 #pragma unroll
         for (int t = 0; t < OT; ++t) rres[t] = ldg4(rrow + 16 * t + 4 * q);
       }
-      mma_pass<HS, OT, false>(o, hin, a.w_out, POST ? a.proj_w[0] : nullptr, POST ? kChunkSteps * HSTEPF : 0, lds, parity, lane, wave,
-                              nullptr, false, nullptr, false, q);
+      // (HEAD: the head's first Linear follows - packed [128, 256]: 8 row tiles = 512 floats per K-step)
+      mma_pass<HS, OT, false>(o, hin, a.w_out, POST ? a.proj_w[0] : (HEAD ? a.hd_w1 : nullptr),
+                              POST ? kChunkSteps * HSTEPF : (HEAD ? kChunkSteps * 512 : 0), lds, parity, lane, wave, nullptr, false,
+                              nullptr, false, q);
     }
   }
 
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
   }
 
   // ---- residual ----
-  if (!SINGLE && a.res_ptr != nullptr) {
+  if (!SINGLE && !HEAD && a.res_ptr != nullptr) {
     if (EPI == EPI_DEC) {
       const float* rrow = operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k);
       typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
 
   // ---- store ----
   float* outp = SINGLE ? a.proj_out[blockIdx.y] : a.out;
-  if (outp != nullptr && valid) {
+  if (!HEAD && outp != nullptr && valid) {
     float* orow = outp + (size_t)c * (size_t)a.out_ld;
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
@@ -495,6 +497,59 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(const ChainArgs a) {
         }
       } else {
         stg4(orow + f0, o[t]);
+      }
+    }
+  }
+
+  // ---- HEAD: the output head on the new rows while they are still in registers (ChainArgs): 256 -> 128 relu -> 128 relu ->
+  // <= 80 features (+ residual rows): AssimilatorDecoder.node_decoder + the Decoder residual (assimilator_decoder.py:197,
+  // decoder.py:93) behind the decoder's node update; the [rows, 256] table between them (133 MB at 1 degree, batch 2) is never
+  // written or read.  Same arithmetic, same order as the two launches (gw_node_update_forward, then gw_mlp_forward): bitwise. ----
+  if constexpr (HEAD) {
+    static_assert(!HEAD || (OT == 16 && HT == 16 && !POST && !SINGLE && EPI == EPI_ROWS), "HEAD follows a 256-wide node update");
+    float xin[64];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xin[4 * t + r] = o[t < OT ? t : 0][r];
+    f32x4 h1[8];
+    init_bias<8>(h1, a.hd_b1, q);
+    mma_pass<64, 8, false>(h1, xin, a.hd_w1, a.hd_w2, kChunkSteps * 512, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
+    f32x4 h2[8];
+    init_bias<8>(h2, a.hd_b2, q);
+    f32x4 none[3][2];
+    mma_pass_produce<8, 8>(h2, h1, none, nullptr, nullptr, nullptr, false, false, false, a.hd_w2, a.hd_w3, kChunkSteps * 512, lds, parity,
+                           lane, wave, q, nullptr);
+    float hin2[32];
+    relu_to_in<8>(hin2, h2);
+    f32x4 y[5];
+    init_bias<5>(y, a.hd_b3, q);
+    mma_pass<32, 5, false>(y, hin2, a.hd_w3, nullptr, 0, lds, parity, lane, wave, nullptr, false, nullptr, false, q);
+    if (valid) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float* rrow = a.res_ptr ? operand_row(a.res_ptr, a.res_idx, a.res_rows_pb, a.res_ld, b, k) : nullptr;
+      float* orow = a.out + (size_t)c * (size_t)a.out_ld;
+      const bool pairs = (a.out_cols & 1) == 0 && ((size_t)orow & 7) == 0 && ((size_t)rrow & 7) == 0;  // 78-float rows: 8-byte accesses
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int f0 = 16 * t + 4 * q;
+        if (pairs) {
+#pragma unroll
+          for (int r = 0; r < 4; r += 2)
+            if (f0 + r < a.out_cols) {
+              f32x2 v = f32x2{y[t][r], y[t][r + 1]};
+              if (rrow) {
+                const f32x2 rv = *(const GW_AS1 f32x2*)(rrow + f0 + r);
+                v.x += rv.x;
+                v.y += rv.y;
+              }
+              *(GW_AS1 f32x2*)(orow + f0 + r) = v;
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f0 + r < a.out_cols) stg1(orow + f0 + r, y[t][r] + (rrow ? ldg1(rrow + f0 + r) : 0.f));
+        }
       }
     }
   }
@@ -1267,8 +1322,8 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   if (!x || !agg || !w || !head || !out || n_rows < 0 || rows_per_batch <= 0) return fail(GW_E_BADARG, "gw_node_update_head_forward: bad arguments");
   if (n_rows == 0) return GW_OK;
   if (n_rows >= (int64_t)1 << 31) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: more than 2^31-1 rows");
-  if (!is16(w->weight_dtype) || head->weight_dtype != w->weight_dtype)
-    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: bf16 or bf16x3 weights, the same for both MLPs (the fp32 path runs the two launches)");
+  if (head->weight_dtype != w->weight_dtype)
+    return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: the same weight dtype for both MLPs");
   const bool b16 = w->weight_dtype == GW_DTYPE_BF16;  // (the 16-bit table formats belong to the bf16 mode)
   if (w->hidden != 256 || w->n_out != 256 || !w->b1 || !w->w_out || !w->b_out || bad_layers(w) || w->n_mid != 1 || !w->ln_gamma ||
       (w->ln_width > 0 && w->ln_width != 256))
@@ -1301,6 +1356,10 @@ int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw
   a.out = out;
   a.out_ld = out_ld;
   a.out_cols = head->n_out;
+  if (!is16(w->weight_dtype)) {  // fp32 (v17): chain_kernel with the head behind the node update
+    if (x->k != 0 && x->layout != GW_LAYOUT_ROWS_F32) return fail(GW_E_UNSUPPORTED, "gw_node_update_head_forward: fp32 weights take fp32 rows");
+    return launch_chain(chain_kernel<64, true, 2, 16, 16, EPI_ROWS, false, false, true>, a, stream, 1, 2);
+  }
   return launch16(w->weight_dtype, 6, a, 256, 256, 256, 1, stream);
 }
 

@@ -1062,18 +1062,28 @@ class AssimilatorDecoder(nn.Module):
                 raise RuntimeError("graph_weather_amd: the residual (start features) must have batch*num_latlons rows of at least "
                                    "output_dim = %d features, got %s" % (self.output_dim, tuple(residual.shape)))
             res = Operand(residual, G, self.output_dim)
-        if not train and x_node is not FEED_ZERO:
-            head = None
+        # node update + node_decoder (+ residual) in one launch wherever the head has the fused kernel's shape (256 -> 128 -> 128 ->
+        # <= 80 features, no norm, same matrix-product dtype as the node MLP): the [B*G, 256] grid-row table between them - 133 MB
+        # at 1 degree, batch 2 - is never written or read (fp32: round 6; bf16 / bf16x3: round 3 / 5)
+        head = None
+        if not train:
             nd = self.node_decoder
             if nd.compute_dtype == blk.node_model.node_mlp.compute_dtype and not wide.is_wide(nd) and not nd._layout()[4]:
                 pm_h = nd.packed()
-                if pm_h.hidden == 128 and pm_h.n_mid == 1 and pm_h.n_out <= 80 and pm_h.gamma is None:
-                    head = (pm_h, res)  # node update + node_decoder (+ residual) in one launch: the grid-row table is never written
+                pm_nn = blk.node_model.node_mlp.packed()
+                if (pm_h.hidden == 128 and pm_h.n_mid == 1 and pm_h.n_out <= 80 and pm_h.gamma is None and pm_nn.n_mid == 1
+                        and pm_nn.gamma is not None and pm_nn.ln_width == 0):
+                    head = (pm_h, res)
+        if not train and x_node is not FEED_ZERO:
             out, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), None, 0, x_node, None, 0, False, dev,
                              tag="decoder_edge", head=head, seg=seg)
             if head is not None:
                 return out.reshape(B, G, self.output_dim)
             xg = out
+        elif head is not None and mlp_e.compute_dtype == torch.float32:
+            out, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
+                             tag="decoder_edge", head=head)
+            return out.reshape(B, G, self.output_dim)
         else:
             xg, _ = blk.run(B, plan, Feed(ps, M, "proj"), FEED_ZERO, Feed(pe, 0, "proj"), e, 0, FEED_ZERO, None, 0, False, dev,
                             tag="decoder_edge")

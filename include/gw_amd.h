@@ -302,13 +302,15 @@ int gw_node_update_forward(int64_t n_rows, int32_t rows_per_batch, const gw_oper
  * same table and tests/test_routes.py compares the two. */
 int gw_node_update_row_split_groups(int64_t n_rows);
 
-/* ---- NodeProcessor.forward followed by the output head, one launch (bf16 or bf16x3 weights) ---------------------------
+/* ---- NodeProcessor.forward followed by the output head, one launch (fp32 since v17; bf16; bf16x3) ---------------------
  * AssimilatorDecoder.forward after its edge update (assimilator_decoder.py:195-200) + the Decoder residual (decoder.py:93):
  *   x_new[j] = LN(MLP_node(cat[x[j], agg[j]]))            (graph_net_block.py:189-191; the decoder's rows are zeros: no x_res)
  *   out[j, :n] = MLP_head(x_new[j]) + residual[j, :n]     (node_decoder 256 -> 128 -> 128 -> n <= 80 features, no norm)
  * x_new stays in registers: the [rows, 256] table between the two MLPs is neither written nor read.
  * Packed sizes the kernel streams unconditionally - checked through head->k_in == 256 and head->out_rows == 80 (v15):
- * head->w1[0] = [128, 256] slice (8 K-steps x 8 row tiles), head->w_mid = [128, 128], head->w_out / b_out packed with rows = 80. */
+ * head->w1[0] = [128, 256] slice (8 K-steps x 8 row tiles), head->w_mid = [128, 128], head->w_out / b_out packed with rows = 80.
+ * Both MLPs in the same weight dtype.  fp32: the same arithmetic in the same order as gw_node_update_forward followed by
+ * gw_mlp_forward with a residual - bitwise their result (tests/test_gpu_round6.py). */
 int gw_node_update_head_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand* x, const gw_operand* agg,
                                 const gw_mlp_weights* w, const gw_mlp_weights* head, const gw_operand* residual /* may be NULL */,
                                 float* out, int32_t out_ld, void* stream);

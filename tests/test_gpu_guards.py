@@ -317,7 +317,7 @@ def test_mlp_with_post_products_stays_inside_its_buffers(half, dtype, rows, B, i
     _both(run)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, X3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3])
 @pytest.mark.parametrize("rows,B,n_out,with_res", [(1000, 2, 78, True), (77, 1, 78, False), (333, 3, 37, True), (1, 1, 80, True)])
 def test_node_update_with_head_stays_inside_its_buffers(dtype, rows, B, n_out, with_res):
     """gw_node_update_head_forward (decoder node update + output head + residual, one launch), bf16; the x operand is the projected

@@ -291,3 +291,34 @@ def test_automatic_graph_under_inference_mode_leaves_the_generator_and_later_cap
         y = fg(x).clone()
         assert fg.captures == 1 and (y - other._forward_eager(x)).abs().max().item() <= 1e-5 * y.abs().max().item()
     assert torch.isfinite(torch.rand(4, device=DEV)).all()
+
+
+@pytest.mark.parametrize("rows,B,n_out,with_res,x_mode", [(64800, 2, 78, True, "zero"), (1000, 3, 78, True, "proj"), (77, 1, 37, False, "zero"),
+                                                           (4097, 1, 80, True, "raw")])
+def test_fp32_node_update_with_head_is_bitwise_the_two_launches(rows, B, n_out, with_res, x_mode):
+    """gw_node_update_head_forward with fp32 weights (v17): NodeProcessor.forward of the decoder block (graph_net_block.py:189-191)
+    + node_decoder (assimilator_decoder.py:197) + the Decoder residual (decoder.py:93) in ONE launch - the [rows, 256] table
+    between them is never written.  Same arithmetic in the same order as gw_node_update_forward followed by gw_mlp_forward."""
+    torch.manual_seed(rows + n_out)
+    blk = gw.build_graph_processor_block(256, 256, 256, 256, 2, 2, "LayerNorm")
+    head = gw.MLP(256, n_out, 128, 2, None)
+    deterministic_fill_(blk, seed=31)
+    deterministic_fill_(head, seed=32)
+    blk, head = blk.to(DEV), head.to(DEV)
+    n = rows * B
+    agg = torch.randn(n, 256, device=DEV)
+    feats = torch.randn(n, 102, device=DEV)
+    pm, ph = blk.node_model.node_mlp.packed(), head.packed()
+    if x_mode == "zero":
+        x = ops.ZERO
+    elif x_mode == "proj":
+        x = Operand(torch.randn(rows, 256, device=DEV), 0, 256, projected=True)  # a cached batch-shared product table
+    else:
+        x = Operand(torch.randn(n, 256, device=DEV), rows, 256)
+    res = Operand(feats, rows, n_out) if with_res else None
+    with torch.no_grad():
+        fused = ops.node_update_head_forward(pm, ph, n, rows, x, Operand(agg, rows, 256), res)
+        xg = ops.node_update_forward(pm, n, rows, x, ops.ZERO, Operand(agg, rows, 256))
+        two = head.run(xg, n, rows, residual=res)
+    torch.cuda.synchronize()
+    assert fused.shape == (n, n_out) and torch.equal(fused, two[:, :n_out])
