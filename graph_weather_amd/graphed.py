@@ -250,10 +250,12 @@ class AutoGraphModule:
         return state
 
     def _auto_graph_step(self, features: torch.Tensor) -> Optional[torch.Tensor]:
-        if not (self.auto_graph and features.is_cuda and features.dtype == torch.float32 and not self.training
-                and not torch.is_grad_enabled()):
+        if not self.auto_graph:
             return None
         auto = self.__dict__.get("_auto")
-        if auto is None:
+        if auto is None or auto._model_ref() is not self:
+            # (a shallow copy of the module - nn.DataParallel's replicas copy __dict__ - must not replay the ORIGINAL's graph)
             auto = self.__dict__["_auto"] = AutoGraph(self)
+        if not (features.is_cuda and features.dtype == torch.float32 and not self.training and not torch.is_grad_enabled()):
+            return None
         return auto.step(features)

@@ -100,6 +100,12 @@ def test_auto_graph_policy_on_the_host():
     with pytest.raises(RuntimeError, match="no CPU path"):
         with torch.no_grad():
             model(x)
+    # a shallow copy (what nn.DataParallel's replicas are) does not inherit the original's policy object
+    replica = model._replicate_for_data_parallel()
+    assert replica.__dict__.get("_auto") is auto
+    with torch.no_grad():
+        assert replica._auto_graph_step(x) is None  # (CPU tensor: not usable - but the step has re-bound the policy to the replica)
+    assert replica.__dict__["_auto"] is not auto and replica.__dict__["_auto"]._model_ref() is replica
 
 
 def test_a_model_with_an_automatic_graph_is_freed_by_reference_count():
