@@ -84,3 +84,26 @@ def test_node_update_form_equals_the_c_table():
                  (torch.float32, 5882, True, "raw", 2, 0, False), (torch.float32, 5882, True, "raw", 1, 128, False),
                  (torch.float32, 5882, True, "raw", 1, 0, True)):
         assert f(*args) == routes.NODE_COLS64
+
+
+def test_bench_reads_the_per_kernel_pmc_summaries_of_the_round():
+    """bench.py attaches counter traffic to the gather-scatter stage (the processor's edge update) from the newest committed per-kernel
+    PMC summary of the workload - a silent None there (renamed kernel, other grid size) would hide wasted re-reads: the lookup is
+    checked against the files under profiles/ for both modes at the batch-2 grid (1 287 tiles x 256 threads)."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    grid = ((2 * 41162 + 63) // 64) * 256
+    for cfg, prefix in (("c2", "edge_kernel<true, 2>"), ("c2x3", "chainx3_kernel<8, true, 3, 16, 16, 1,")):
+        traffic, name, busy = bench.pmc_kernel_traffic(cfg, (prefix,), grid)
+        assert traffic is not None and name.endswith("_pmc_%s_all_kernels.json" % cfg), (cfg, name)
+        algorithmic = 2 * (2 * 41162 * 256 * 4 + 2 * 5882 * 256 * 4)  # SURVEY 8(d): 96.3 MB per sample
+        assert 1.0 <= traffic / algorithmic <= 2.5, (cfg, traffic / algorithmic)
+        assert busy is None or 0.05 <= busy <= 1.0
+    assert bench.pmc_kernel_traffic("c2", ("no_such_kernel<",), grid) == (None, None, None)
+    total, d, name = bench.pmc_traffic("c2")
+    assert total is not None and name.startswith("r") and 0.5 <= d.get("mfma_busy_frac", 0.0) <= 1.0
