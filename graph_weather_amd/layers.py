@@ -61,6 +61,10 @@ class KeyedCache:
             self._entries[name] = hit
         return hit[1]
 
+    def fresh(self, name: str, key, hold=None) -> bool:
+        hit = self._entries.get(name)
+        return hit is not None and hit[0] == key and hit[2] is hold
+
     def clear(self) -> None:
         self._entries.clear()
 
@@ -976,6 +980,40 @@ class AssimilatorDecoder(nn.Module):
             return self.edge_encoder.table(plan.edge_attr)
         return self._cache.get("dec_e", _version_key(list(self.edge_encoder.parameters())), lambda: self.edge_encoder.table(plan.edge_attr))
 
+    def prefetch_tables(self, dev) -> Optional["torch.cuda.Stream"]:
+        """Cold forward (weights changed since the tables were made), inference, fp32 / bf16x3: the decoder's two big batch-
+        independent tables - the edge embedding ``edge_encoder(attr)`` on its ~7 G rows and its layer-1 product ``We . e``
+        (assimilator_decoder.py:175-177 recomputes the embedding on every forward) - are rebuilt on a SIDE stream while encoder and
+        processor run on the caller's: they are first read by the decoder's edge update, ~4 ms later.  Returns that stream (the
+        caller joins it in front of ``decode``) or None when everything is fresh / the path does not apply.  Measured
+        (scripts/probes/cold_parts_probe.py): the decoder's share of the cold step's extra time is 1.7 of 3.6 ms in fp32."""
+        if wide.decoder_is_wide(self) or _autograd_on(self) or len(self.graph_processor.blocks) == 0:
+            return None
+        blk = self.graph_processor.blocks[0]
+        mlp_e = blk.edge_model.edge_mlp
+        if mlp_e.compute_dtype == torch.bfloat16 or self.edge_encoder.compute_dtype == torch.bfloat16:
+            return None  # (the frozen bf16 mode keeps its own table formats and is left as it is)
+        key_e = _version_key(list(self.edge_encoder.parameters()))
+        key = _version_key(list(self.edge_encoder.parameters()) + list(blk.parameters()))
+        if self._cache.fresh("dec_e", key_e) and self._cache.fresh("dec_pe", key):
+            return None
+        plan = self._plan(dev)
+        n_e = plan.num_edges
+        if n_e == 0:
+            return None
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_prefetch_stream")
+        if side is None or side.device != main.device:
+            side = self.__dict__["_prefetch_stream"] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)  # (ordered behind everything that may still read the tables - and packed weights - being replaced)
+        with torch.cuda.stream(side):
+            e = self.edge_embedding(plan)
+            pm_e = mlp_e.packed()
+            pe = self._cache.get("dec_pe", key, lambda: ops.project_forward([pm_e.w1[2]], Operand(e, n_e, 256), n_e, n_e)[0])
+        for t in (e, pe):
+            t.record_stream(main)  # made on the side stream, read on the caller's for as long as the cache entry lives
+        return side
+
     def team_path(self) -> bool:
         """Inference in bf16 with everything the team-pipelined edge kernel needs (csrc/gw_edge16t.hip): one middle layer,
         LayerNorm over all 256 features, atomics mode, node and edge MLP of the block in the same dtype.  Then the decoder's edge
@@ -1120,11 +1158,18 @@ def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "Assimila
         x = encoder.encode(features)
         x, _ = gp.run_plan(x, lat_plan, e_lat, True, B, False)
         return decoder.decode(x, B, residual=residual)
+    dec_prefetch = decoder.prefetch_tables(features.device)  # cold forward: the decoder's big tables on a side stream
+
+    def join_prefetch():  # ... joined in front of decode
+        if dec_prefetch is not None:
+            torch.cuda.current_stream(features.device).wait_stream(dec_prefetch)
+
     x, posts, agg0 = encoder.encode(features, post_w=[first.w1[0], first.w1[1]])
     n_streams = gp.forward_streams(B)
     if n_streams <= 1:
         x, _, tail = gp.run_plan(x, lat_plan, e_lat, True, B, False, pre_proj=(posts[0], posts[1], agg0), tail_w=[dec_e.w1[0]],
                                  tail_half=decoder.team_path())
+        join_prefetch()
         return decoder.decode(x, B, residual=residual, ps=None if tail is None else tail[0])
     # The mesh stack as independent per-sample chains on separate HIP streams (batch elements never interact,
     # encoder.py:212-218).  One batched launch of a mesh-sized kernel fills the chip unevenly - 1 287 64-column tiles on 512
@@ -1154,6 +1199,7 @@ def fused_forward(encoder: "Encoder", processor: "Processor", decoder: "Assimila
             t.record_stream(st)  # allocated on the main stream, read on a side stream
     for t in xs + tails:
         t.record_stream(main)  # allocated on a side stream, read on the main stream
+    join_prefetch()
     return decoder.decode(torch.cat(xs), B, residual=residual, ps=torch.cat(tails))
 
 

@@ -322,3 +322,28 @@ def test_fp32_node_update_with_head_is_bitwise_the_two_launches(rows, B, n_out, 
         two = head.run(xg, n, rows, residual=res)
     torch.cuda.synchronize()
     assert fused.shape == (n, n_out) and torch.equal(fused, two[:, :n_out])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, X3])
+@pytest.mark.parametrize("B", [1, 2])
+def test_cold_forward_rebuilds_the_decoder_tables_on_a_side_stream_with_the_same_result(dtype, B):
+    """AssimilatorDecoder.prefetch_tables: right after a weight update the decoder's edge embedding and its layer-1 product are
+    rebuilt on a side stream beside encoder and processor (assimilator_decoder.py:175-177 recomputes them every forward); the
+    forecast is that of the warm forward with the same weights, call after call, and a warm forward starts no side work."""
+    model, lat_lons = _forecaster(deg=5.0, seed=3)
+    model.set_compute_dtype(dtype)
+    model.set_deterministic(True)
+    model.auto_graph = False
+    x = seeded_features(B, len(lat_lons), 102, seed=12).to(DEV)
+    with torch.no_grad():
+        model(x)
+        assert model.decoder.prefetch_tables(x.device) is None  # warm: nothing to do
+        for trial in range(3):
+            for p in model.parameters():
+                p.mul_(1.0 + 0.01 * (trial + 1))
+            assert not model.decoder._cache.fresh("dec_e", None)
+            cold = model(x)  # tables rebuilt on the side stream inside this call
+            warm = model(x)
+            assert torch.equal(cold, warm), trial
+            assert model.decoder.prefetch_tables(x.device) is None
+    torch.cuda.synchronize()
