@@ -11,7 +11,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 scripts/gpu_run.sh $TAG build
 case " $STEPS " in *" test "*) scripts/gpu_run.sh $TAG test;; esac
 case " $STEPS " in *" smoke "*) scripts/gpu_run.sh $TAG smoke; scripts/gpu_run.sh $TAG py:scripts/probes/graph_rccl_probe.py | tail -n 6;; esac
-case " $STEPS " in *" bench "*) scripts/gpu_run.sh $TAG bench | cut -c1-6000;; esac
+case " $STEPS " in *" bench "*) scripts/gpu_run.sh $TAG bench | cut -c1-6000; scripts/gpu_run.sh $TAG py:scripts/probes/cold_parts_probe.py | tail -n 3;; esac
 case " $STEPS " in *" prof "*) scripts/gpu_run.sh $TAG prof:c2 prof:c2x3 prof:c3 proftrain:fp32 proftrain:bf16x3 > $OUT/prof_summary.log 2>&1; tail -n 40 $OUT/prof_summary.log | cut -c1-200;; esac
 case " $STEPS " in *" pmc "*)
   PMC_LDS=0 bash scripts/gpu_pmc_cfg.sh $TAG c2 > $OUT/pmc_c2_summary.log 2>&1

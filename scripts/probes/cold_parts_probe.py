@@ -6,13 +6,11 @@ import torch
 import bench
 from graph_weather_amd.optim import _bump_versions
 
-PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+PRECS = sys.argv[1:] if len(sys.argv) > 1 else ["fp32", "bf16x3"]
 dev = torch.device("cuda:0")
 cfg = bench.CONFIGS["c2"]
 model, lat_lons = bench.build_model(cfg, dev)
 model = model.to(dev).eval()
-if PREC != "fp32":
-    model.set_compute_dtype(PREC)
 model.auto_graph = False
 torch.manual_seed(42)
 feats = torch.randn(cfg["batch"], len(lat_lons), 102, device=dev)
@@ -33,9 +31,12 @@ def run(params, n=6):
     return ts[len(ts) // 2]
 
 
-with torch.no_grad():
-    for _ in range(3):
-        model(feats)
 dec = list(model.decoder.parameters())
 rest = list(model.encoder.parameters()) + list(model.processor.parameters())
-print(PREC, "warm %.2f ms | all cold %.2f | decoder cold %.2f | encoder + processor cold %.2f" % (run(None), run(list(model.parameters())), run(dec), run(rest)))
+for PREC in PRECS:
+    bench.set_precision(model, PREC)
+    with torch.no_grad():
+        for _ in range(3):
+            model(feats)
+    print(PREC, "warm %.2f ms | all cold %.2f | decoder cold %.2f | encoder + processor cold %.2f"
+          % (run(None), run(list(model.parameters())), run(dec), run(rest)), flush=True)
