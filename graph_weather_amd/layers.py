@@ -43,6 +43,22 @@ def _version_key(params) -> tuple:
     return tuple((p.data_ptr(), _ver(p), p.device) for p in params)
 
 
+_DEVICE_STREAMS = {}
+
+
+def device_stream(device, kind: str, index: int = 0) -> "torch.cuda.Stream":
+    """The process-wide side stream ``(kind, index)`` of a device ("mesh" 0, 1, ...: per-sample chains of the mesh stack;
+    "prefetch": cold rebuild of the decoder tables).  One small fixed set per device, shared by every model of the process: a
+    stream per module instance (a bench run builds a dozen models) made the HIP runtime hand out dozens of streams, and which
+    hardware queue the two chains of a stack landed on - i.e. whether they overlapped at all - came to depend on how many
+    streams had been created before them (round 6: the batch-8 fp32 forward 24.9 ms or 27.3 ms on the same tree)."""
+    key = (str(torch.device(device)), kind, int(index))
+    st = _DEVICE_STREAMS.get(key)
+    if st is None:
+        st = _DEVICE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class KeyedCache:
     """The per-module caches of batch-independent tensors (edge / mesh embeddings, their layer-1 products, tile forms, graph
     plans): ``get(name, key, make, hold=None)`` returns the entry made for ``key`` or makes it.  Keys are built from
@@ -465,7 +481,6 @@ class GraphProcessor(nn.Module):
         self.checkpoint_segments = 0  # processor.py:70-81, set through Processor.set_checkpoint_segments
         self.streams = 0  # HIP streams of the fused inference forward: 0 = automatic (see forward_streams), 1 = one stream
         self._cache = KeyedCache()  # "plan" (user COO graph), "e0_pe" / "e0_tiles" / "e0_seg" (block 0's batch-shared edge features)
-        self._side_streams = {}
 
     # -- native path: shared dst-sorted plan, node table [batch*n, 256], edge features in sorted order ----------
     def run_plan(self, x: torch.Tensor, plan: GraphPlan, e: torch.Tensor, e_shared: bool, batch: int,
@@ -524,10 +539,7 @@ class GraphProcessor(nn.Module):
         return routes.mesh_streams(self.streams, [b.edge_model.edge_mlp.compute_dtype for b in self.blocks], batch)
 
     def side_streams(self, device, n: int):
-        key = (str(device), n)
-        if key not in self._side_streams:
-            self._side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-        return self._side_streams[key]
+        return [device_stream(device, "mesh", i) for i in range(n)]
 
     def prepare_shared(self, e: torch.Tensor, plan: GraphPlan) -> None:
         """Everything the per-sample chains share, made on the current stream: packed weights of every block and the cached
@@ -1002,9 +1014,7 @@ class AssimilatorDecoder(nn.Module):
         if n_e == 0:
             return None
         main = torch.cuda.current_stream(dev)
-        side = self.__dict__.get("_prefetch_stream")
-        if side is None or side.device != main.device:
-            side = self.__dict__["_prefetch_stream"] = torch.cuda.Stream(device=dev)
+        side = device_stream(dev, "prefetch")
         side.wait_stream(main)  # (ordered behind everything that may still read the tables - and packed weights - being replaced)
         with torch.cuda.stream(side):
             e = self.edge_embedding(plan)
