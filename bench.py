@@ -526,7 +526,10 @@ def h2d_step_ms(model, feats, steps=20):
         torch.cuda.synchronize()
         res["overlapped_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
     res["bytes_per_step"] = host.numel() * 4
-    res["note"] = "input batch copied from pinned host memory every step (PCIe); not part of `value`"
+    res["note"] = ("input batch copied from pinned host memory every step (PCIe); not part of `value`.  The overlapped figure depends on "
+                   "the copy stream getting a hardware queue of its own: HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) queues in "
+                   "order of creation, and a later stream shares one with an earlier - possibly a busy mesh chain's "
+                   "(profiles/r06_bench_hw_queues.log: 7.8 ms with 8 queues, no gain over the serial loop with 4)")
     return res
 
 
