@@ -45,6 +45,25 @@ __device__ __forceinline__ void load_operand_slice(float (&in)[NSTEPS], const fl
   }
 }
 
+// This wave's DMA pieces (p = wave, wave + 4, ...) of a chunk of NP 1-KiB pieces that are due behind K-step s when the pieces are
+// spread over the first SPREAD K-steps of the chunk that is computing (everything is a compile-time constant after unrolling: no
+// branch in the pass).  Round 6 (csrc/gw_noders.hip, scripts/gpu_timeline_rs.py): a global_load_lds blocks its wave for 60 - 180
+// cycles; issued all at once behind the barrier, every wave of a SIMD is blocked at the same time and the matrix pipe idles -
+// spread between the MFMA groups, the partner wave owns the pipe meanwhile (gw_edge.hip has done this since round 1).
+__device__ __forceinline__ void issue_chunk_step(const float* __restrict__ g, int np /* pieces of the chunk */, int spread, float* ldsbuf,
+                                                 int lane, int wave, int s) {
+  const int pw = (np + 3) >> 2;  // pieces per wave (<= 8: a chunk is at most 32 KiB)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < pw && i * spread / pw == s) {
+      const int pc = wave + 4 * i;
+      if ((np & 3) == 0 || pc < np)
+        glds16_asm_s(g + (size_t)pc * 256, (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)pc * 1024u));
+    }
+  }
+}
+
 // One K-pass of a layer: acc[t] += W[16t.., k] * in[k], K = 4*NSTEPS, NT row tiles of 16 features.
 // Protocol: the first chunk of this pass has already been issued into buffer `parity`.
 // With RELOAD, the 8 operand registers a chunk has consumed are refilled (one chunk later) with the same
@@ -65,12 +84,12 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[NT], float (&in)[NSTEPS], 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // chunk c has landed for every wave; nobody still reads the other buffer
     float* other = lds + (parity ^ 1) * kLdsBufFloats;
-    if (c + 1 < NCH) {
-      const int nn = (NSTEPS - (c + 1) * kChunkSteps) < kChunkSteps ? (NSTEPS - (c + 1) * kChunkSteps) : kChunkSteps;
-      issue_chunk(gw + (size_t)(c + 1) * kChunkSteps * STEPF, nn * STEPF, other, lane, wave);
-    } else if (next_gw != nullptr) {
-      issue_chunk(next_gw, next_floats, other, lane, wave);
-    }
+    // the next chunk of this pass: its pieces go out between the K-steps below; the first chunk of the NEXT pass (a size only
+    // known at run time) all at once
+    const int nn_c = (c + 1 < NCH) ? (((NSTEPS - (c + 1) * kChunkSteps) < kChunkSteps) ? (NSTEPS - (c + 1) * kChunkSteps) : kChunkSteps) : 0;
+    const int np_c = nn_c * STEPF / 256;                           // 1-KiB pieces of that chunk (a constant once unrolled)
+    const int spread_c = nsteps_c * 3 / 4 > 0 ? nsteps_c * 3 / 4 : 1;  // K-steps of THIS chunk that carry them
+    if (c + 1 >= NCH && next_gw != nullptr) issue_chunk(next_gw, next_floats, other, lane, wave);
     if (RELOAD) {
       // Operand registers are refilled one chunk behind their consumption, right after the barrier, so the
       // gathers have a whole chunk of MFMAs to land before the next vmcnt(0).
@@ -98,6 +117,7 @@ __device__ __forceinline__ void mma_pass(f32x4 (&acc)[NT], float (&in)[NSTEPS], 
         for (int t = 0; t < NT; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (np_c > 0) issue_chunk_step(gw + (size_t)(c + 1) * kChunkSteps * STEPF, np_c, spread_c, other, lane, wave, s);
         if (s + 1 < nsteps_c) {
 #pragma unroll
           for (int b4 = 0; b4 < NT4; ++b4) a_cur[b4] = a_nxt[b4];
@@ -129,11 +149,7 @@ __device__ __forceinline__ void mma_pass_produce(f32x4 (&acc)[NT], const f32x4 (
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float* other = lds + (parity ^ 1) * kLdsBufFloats;
-    if (c + 1 < NCH) {
-      issue_chunk(gw + (size_t)(c + 1) * kChunkSteps * STEPF, kChunkSteps * STEPF, other, lane, wave);
-    } else if (next_gw != nullptr) {
-      issue_chunk(next_gw, next_floats, other, lane, wave);
-    }
+    if (c + 1 >= NCH && next_gw != nullptr) issue_chunk(next_gw, next_floats, other, lane, wave);  // (next pass: all at once)
     f32x4 v0 = src[2 * c], v1 = src[2 * c + 1];
     if (p0) { v0 += tmp[0][0]; v1 += tmp[0][1]; }
     if (p1) { v0 += tmp[1][0]; v1 += tmp[1][1]; }
@@ -171,6 +187,8 @@ __device__ __forceinline__ void mma_pass_produce(f32x4 (&acc)[NT], const f32x4 (
       for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t >> 2][t & 3], b, acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < NCH)  // the next chunk of this pass: its pieces between the K-steps (see issue_chunk_step)
+        issue_chunk_step(gw + (size_t)(c + 1) * kChunkSteps * STEPF, kChunkSteps * STEPF / 256, 6, other, lane, wave, s);
       if (s + 1 < kChunkSteps) {
 #pragma unroll
         for (int b4 = 0; b4 < NT4; ++b4) a_cur[b4] = a_nxt[b4];
