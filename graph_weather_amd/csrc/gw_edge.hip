@@ -43,6 +43,7 @@ struct EdgeArgs {
   int n_dst;
   int stagger;
   int skip;  // tuning aid (GW_EDGE_SKIP): 1 = no segment sum, 2 = no staging either (results are then wrong)
+  int dma6;  // tuning aid (GW_EDGE_DMA6): DMA pieces of the next chunk over six K-steps instead of four
   // XCD-aware tile order: workgroup i is dispatched to XCD i % 8 (each XCD has its own L2); XCD x then walks the contiguous
   // tile range [x * xcd_base + min(x, xcd_rem), ...) so that neighbouring destination-sorted tiles - which gather the
   // same few mesh rows - share an L2.  xcd_base == 0: identity order.
@@ -85,6 +86,12 @@ struct EdgeArgs {
   int save_ld;
   float* save_y;
 };
+
+#ifdef GW_TUNING
+#define GW_DMA6(a) ((a).dma6)
+#else
+#define GW_DMA6(a) 0
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -217,7 +224,14 @@ __device__ __forceinline__ const float* chunk_src(const EdgeArgs& a, int i) {
     const float* nsrc_ = chunk_src<RAW>(a, ci + 1);                                                            \
     _Pragma("unroll") for (int s_ = 0; s_ < kChunkSteps; ++s_) {                                               \
       f32x4 a_nxt_[4];                                                                                         \
-      if ((NEXT_EXISTS) && s_ < kDmaSteps && GW_SKIP(a) != 4) {                                                     \
+      if ((NEXT_EXISTS) && GW_DMA6(a)) { /* tuning: the 8 pieces over SIX K-steps (2, 1, 1, 2, 1, 1) */                    \
+        if (s_ == 0) issue_pieces<2>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, 0, lane, wave);                    \
+        if (s_ == 1) issue_pieces<1>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, 2, lane, wave);                    \
+        if (s_ == 2) issue_pieces<1>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, 3, lane, wave);                    \
+        if (s_ == 3) issue_pieces<2>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, 4, lane, wave);                    \
+        if (s_ == 4) issue_pieces<1>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, 6, lane, wave);                    \
+        if (s_ == 5) issue_pieces<1>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, 7, lane, wave);                    \
+      } else if ((NEXT_EXISTS) && s_ < kDmaSteps && GW_SKIP(a) != 4) {                                              \
         issue_pieces<8 / kDmaSteps>(nsrc_, ((ci + 1) & 1) * kLdsBufFloats, s_ * (8 / kDmaSteps), lane, wave);  \
       }                                                                                                        \
       if (s_ + 1 < kChunkSteps) {                                                                              \
@@ -728,6 +742,8 @@ int edge_fast_launch(int32_t batch, int32_t n_edges, const int32_t* src, const i
     static int skip = -1;
     if (skip < 0) skip = GW_TUNE("GW_EDGE_SKIP", 0);
     a.skip = skip;
+    static const int dma6 = GW_TUNE("GW_EDGE_DMA6", 0);
+    a.dma6 = dma6;
   }
   {
     static int stagger_override = -2;
