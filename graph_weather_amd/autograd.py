@@ -174,7 +174,7 @@ def chain_backward(d: torch.Tensor, chain, fan):
 # ---------------------------------------------------------------------------------------------------------------------
 def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
                         gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None, ln_width: int = 0,
-                        fan: Sequence[Tuple[int, int]] = (), fan_out: Optional[dict] = None):
+                        fan: Sequence[Tuple[int, int]] = (), fan_out: Optional[dict] = None, bias0_by_caller: bool = False):
     """Backward through [LayerNorm] <- Linear_L <- ReLU <- ... <- Linear_1 <- ReLU, down to the output of Linear_0.
 
     ``weights`` = [W0, b0, W1, b1, ..., WL, bL, (gamma, beta)] (state_dict order of the reference ``MLP.model``);
@@ -182,7 +182,10 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     depends on how the caller feeds layer 0 (concatenated operands, gathers, pre-multiplied tables) and is left to it.
     Returns (dz0 [rows, hidden] = gradient at the output of Linear_0, already masked by its ReLU, device).
     ``fan``: column blocks (lo, hi) of W0 whose input gradients dz0 @ W0[:, lo:hi] the caller wants; ``fan_out[(lo, hi)]``
-    receives them (from the fused chain launch when the MLP has the kernel shapes, from single products otherwise)."""
+    receives them (from the fused chain launch when the MLP has the kernel shapes, from single products otherwise).
+    ``bias0_by_caller``: Linear_0's bias gradient (column sums of dz0) is NOT launched here: the caller's first weight-gradient
+    GEMM on dz0 takes it along (``gemm_tn_acc(dz0, ..., colsum=grads[1])``; ``grads[1]`` is handed over zeroed) - one pass over
+    dz0 less per MLP."""
     n_lin = (len(weights) - (2 if has_norm else 0)) // 2
     if n_lin < 2:
         raise RuntimeError("MLP needs at least one hidden layer")
@@ -226,7 +229,8 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
             grads[2 * l], grads[2 * l + 1] = gW, gb
         d = ds[-1]
         grads[1] = zs[1]
-        relu_backward(d, None, grads[1])
+        if not bias0_by_caller:
+            relu_backward(d, None, grads[1])
         if fan_out is not None:
             for lo, hi in fan:
                 if (lo, hi) not in fan_out:
@@ -244,7 +248,8 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
              else relu_backward(gemm_nn(d, W, int(W.shape[1])), h_prev, None))
     # Linear_0's bias gradient: column sums of dz0 (its weight gradient is the caller's: it depends on the operands)
     grads[1] = zs[1]
-    relu_backward(d, None, grads[1])
+    if not bias0_by_caller:
+        relu_backward(d, None, grads[1])
     if fan_out is not None and mlp is not None:
         for lo, hi in fan:
             fan_out[(lo, hi)] = input_grad(mlp, 0, d, weights[0], lo, hi)
@@ -275,9 +280,9 @@ class MLPRowsFunction(torch.autograd.Function):
         fan = [(0, int(W0.shape[1]))] if ctx.needs_input_grad[1] else []
         fo: dict = {}
         dz0, _ = _mlp_chain_backward(dy, ctx.save, params, ctx.has_norm, params[-2] if ctx.has_norm else None, grads, ctx.mlp,
-                                     ctx.mlp.out_dim, fan=fan, fan_out=fo)
+                                     ctx.mlp.out_dim, fan=fan, fan_out=fo, bias0_by_caller=True)
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
-        gemm_tn_acc(dz0, x2, gW0, x3=_x3(ctx.mlp))
+        gemm_tn_acc(dz0, x2, gW0, colsum=grads[1], x3=_x3(ctx.mlp))
         grads[0] = gW0
         dx = fo[fan[0]] if fan else None
         dres = None
@@ -437,9 +442,10 @@ class EdgeUpdateFunction(torch.autograd.Function):
         fan = [tuple(mlp.native_splits()[i]) for i, sp in enumerate(specs) if sp.mode == "raw" and ctx.needs_input_grad[5 + i]]
         fo: dict = {}
         dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim,
-                                     fan=fan, fan_out=fo)
+                                     fan=fan, fan_out=fo, bias0_by_caller=True)
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
+        gb0 = grads[1]  # bias gradient of Linear_0: rides on the first weight-gradient GEMM over dz0 (None once taken)
         tensors = (x_src, x_dst, e_in)
         n_rows_tab = (plan.n_src, plan.n_dst, E)
         dts: List[Optional[torch.Tensor]] = [None, None, None]
@@ -453,10 +459,13 @@ class EdgeUpdateFunction(torch.autograd.Function):
             else:  # raw rows multiplied by W0[:, lo:hi]
                 idx = (plan.src, plan.dst, None)[i]
                 g = t if (idx is None and sp.rows_pb > 0) else gather_rows(t, sp.rows_pb, idx, B, E)
-                gemm_tn_acc(dz0, g, gW0, c_col0=lo, x3=_x3(mlp))
+                gemm_tn_acc(dz0, g, gW0, c_col0=lo, colsum=gb0, x3=_x3(mlp))
+                gb0 = None
                 if ctx.needs_input_grad[5 + i]:
                     dg = fo[(lo, hi)]
                     dts[i] = _scatter_rows(dg, i, plan, B, sp.rows_pb, n_rows_tab[i])
+        if gb0 is not None:  # every operand pre-multiplied: no GEMM over dz0 here
+            relu_backward(dz0, None, gb0)
         grads[0] = gW0
         de_res = None
         if ctx.needs_input_grad[8]:
@@ -500,10 +509,10 @@ class NodeUpdateFunction(torch.autograd.Function):
         fan = ([(alo, ahi)] if ctx.needs_input_grad[7] else []) + ([(xlo, xhi)] if (sp.mode == "raw" and ctx.needs_input_grad[5]) else [])
         fo: dict = {}
         dz0, _ = _mlp_chain_backward(dout, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, ctx.mlp, ctx.mlp.out_dim,
-                                     fan=fan, fan_out=fo)
+                                     fan=fan, fan_out=fo, bias0_by_caller=True)
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
-        gemm_tn_acc(dz0, agg, gW0, c_col0=alo, x3=_x3(ctx.mlp))
+        gemm_tn_acc(dz0, agg, gW0, c_col0=alo, colsum=grads[1], x3=_x3(ctx.mlp))
         dagg = fo[(alo, ahi)] if ctx.needs_input_grad[7] else None
         dx = None
 

@@ -238,27 +238,46 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(int K, const float* __
 
 // TN on split operands (GW_GEMM_TN_BF16X3; mixed-precision training): the same tile and slab scheme, but
 // C += A_hi^T B_hi + A_hi^T B_lo + A_lo^T B_hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; v = hi + lo, hi = bf16(v),
-// lo = bf16(v - hi): 16 significant bits per operand).  Both operands are k-strided in memory ([rows][features]), so the fp32
-// tiles go to LDS as they lie and every lane builds its fragments from eight 4-byte reads - rows 4 e + (lane >> 4), e = 0..7,
-// of its column (the same permutation of the stage's 32 rows for A and B; LDS row stride 144: the 4 rows of a read hit
-// disjoint banks) - split in registers.  A stage is 32 rows: 64 reads + 64 splits for 48 MFMAs per wave.
-// (Measured and not kept: a 256 x 256 tile per 8-wave workgroup, every operand row read once - 531 vs 602 us at the decoder's
-// 905 k rows, but 125 vs 90 us at a processor block's 82 k and 37 vs 26 us at 11.7 k: one workgroup per CU, 256 KiB of atomics
-// per row slab; the training step went 28.9 -> 31.0 ms.)
-constexpr int kTx3KC = 32;   // k rows per stage (one bf16 MFMA K-step)
+// lo = bf16(v - hi): 16 significant bits per operand).  Both operands are k-strided in memory ([rows][features]) while an MFMA
+// fragment is 8 consecutive k of one column, so a stage (32 rows) is split ONCE, by the thread that loaded it, and written
+// to LDS transposed as bf16 planes [A_hi | A_lo | B_hi | B_lo][column][32 k]: thread (r = tid >> 5, c = tid & 31) loads rows
+// r + 8 h (h = 0..3) of columns c + 32 j (j = 0..3; 128 contiguous bytes per half wave and row) and stores, per column, the four
+// k's it holds as one 8-byte word at k slot 4 r + h - the same permutation of the stage's rows for A and B, which is all the
+// product needs.  A lane's fragment is then 16 contiguous bytes (slots 8 (lane >> 4) ..+7) of its column: 16 LDS reads and no
+// conversion per stage and wave for 48 MFMAs (round 5 kept fp32 tiles in LDS and split in every wave that read them: 64 reads,
+// 64 splits and ~200 register moves per stage - the loop was VALU bound at twice the MFMA time).  Column stride 72 bytes: the
+// 8-byte writes of 32 consecutive columns and the fragment reads of 16 consecutive columns spread over all banks.
+// Global loads run TWO stages ahead of the MFMAs in registers (a stage is ~0.4 us of arithmetic, an HBM round trip under load
+// 2 us; with the loads of one stage in flight the kernel sat at 2.6 TB/s on the decoder's 905 k rows), and the barriers wait
+// for LDS only, so the loads stay in flight across them.
+// (Measured and not kept in round 5: a 256 x 256 tile per 8-wave workgroup, every operand row read once - 531 vs 602 us at the
+// decoder's 905 k rows, but 125 vs 90 us at a processor block's 82 k and 37 vs 26 us at 11.7 k: one workgroup per CU, 256 KiB of
+// atomics per row slab; the training step went 28.9 -> 31.0 ms.)
+constexpr int kTx3KC = 32;                    // k rows per stage (one bf16 MFMA K-step)
+constexpr int kTx3ColB = 72;                  // bytes per column in a plane: 32 k x 2 + 8
+constexpr int kTx3Plane = 128 * kTx3ColB;     // one bf16 plane of a stage
+constexpr int kTx3Stage = 4 * kTx3Plane;      // A_hi | A_lo | B_hi | B_lo = 36 864 bytes
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split8_tn(const float (&v)[8], bf16x8_t& h, bf16x8_t& l) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 hv = (__bf16)v[e];
-    h[e] = hv;
-    l[e] = (__bf16)(v[e] - (float)hv);
-  }
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// (hi, lo) of two values: one packed conversion each way; the hi halves come back as floats by a shift / a mask of the pair
+__device__ __forceinline__ void split2_tn(float v0, float v1, unsigned& h, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v0, v1}, bf16x2_t));
+  const float h0 = __uint_as_float(h << 16), h1 = __uint_as_float(h & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v0 - h0, v1 - h1}, bf16x2_t));
 }
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8_t lds_frag8(const unsigned char* p) {  // 8-byte aligned (column stride 72)
+  const bf16x4_t a = *(const bf16x4_t*)p, b = *(const bf16x4_t*)(p + 8);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void lds_barrier_tn() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* __restrict__ A, int lda,
                                                             const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                                             int k_slab, float* __restrict__ colsum_a) {
-  extern __shared__ __attribute__((aligned(16))) float smx[];  // [stage 2][A|B][32 * 144]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];  // [stage 2][plane 4][column 128][72 bytes]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
@@ -266,90 +285,107 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int k_begin = blockIdx.z * k_slab;
   const int k_end = k_begin + k_slab < K ? k_begin + k_slab : K;
-  const int lrow = threadIdx.x >> 5;        // 0..7 (+ 8 h): k row inside a stage
-  const int lcol = (threadIdx.x & 31) * 4;  // float offset inside the 128-wide tile
-  constexpr int kTile = kTx3KC * kTnLd;
+  const int lrow = threadIdx.x >> 5;  // 0..7 (+ 8 h): k row inside a stage
+  const int lc = threadIdx.x & 31;    // (+ 32 j): column inside the 128-wide tile
   f32x4 acc[4][4];
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_sum = colsum_a != nullptr && blockIdx.y == 0 && (wave & 1) == 0;
-  float asum[4] = {0.f, 0.f, 0.f, 0.f};
+  // column sums of A (the bias gradient when A = dZ): taken once per m, by the workgroups of the first n-block column
+  const bool do_sum = colsum_a != nullptr && blockIdx.y == 0;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[4], rb[4];
-  auto fetch = [&](int k0) {
+  float r0[32], r1[32];  // two stages in flight: [A | B][h][j]
+  // rows past k_end (the ragged last stage of the matrix, and the one or two stages fetched past the end of the slab) are read
+  // from row k_end - 1 - no branch, no register merge - and zeroed when the stage is split
+  auto fetch = [&](int k0, float (&r)[32]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const int k = k0 + lrow + 8 * h;
-      if (k < k_end) {
-        ra[h] = ldg4(A + (size_t)k * lda + mB + lcol);
-        rb[h] = ldg4(B + (size_t)k * ldb + nB + lcol);
-      } else {
-        ra[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int k = k0 + lrow + 8 * h;
+      k = k < k_end ? k : k_end - 1;
+      const float* pa = A + (size_t)k * lda + mB + lc;
+      const float* pb = B + (size_t)k * ldb + nB + lc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[4 * h + j] = ldg1(pa + 32 * j);
+        r[16 + 4 * h + j] = ldg1(pb + 32 * j);
       }
     }
   };
-  auto stash = [&](int st) {
-    float* sa = smx + (size_t)st * 2 * kTile;
+  auto stash = [&](int st, int k0, const float (&r)[32]) {
+    unsigned char* s = smx + st * kTx3Stage + lrow * 8;
+    bool ok[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      *(f32x4*)(&sa[(lrow + 8 * h) * kTnLd + lcol]) = ra[h];
-      *(f32x4*)(&sa[kTile + (lrow + 8 * h) * kTnLd + lcol]) = rb[h];
-    }
+    for (int h = 0; h < 4; ++h) ok[h] = k0 + lrow + 8 * h < k_end;
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = ok[0] ? r[16 * op + j] : 0.f, v1 = ok[1] ? r[16 * op + 4 + j] : 0.f;
+        const float v2 = ok[2] ? r[16 * op + 8 + j] : 0.f, v3 = ok[3] ? r[16 * op + 12 + j] : 0.f;
+        if (op == 0) csum[j] += (v0 + v1) + (v2 + v3);
+        unsigned h01, l01, h23, l23;
+        split2_tn(v0, v1, h01, l01);
+        split2_tn(v2, v3, h23, l23);
+        unsigned char* d = s + (2 * op) * kTx3Plane + (lc + 32 * j) * kTx3ColB;
+        *(u32x2_t*)d = u32x2_t{h01, h23};
+        *(u32x2_t*)(d + kTx3Plane) = u32x2_t{l01, l23};
+      }
   };
-  fetch(k_begin);
-  stash(0);
-  __syncthreads();
-  int st = 0;
-  for (int k0 = k_begin; k0 < k_end; k0 += kTx3KC) {
-    const bool more = k0 + kTx3KC < k_end;
-    if (more) fetch(k0 + kTx3KC);  // global loads of the next stage fly under this stage's MFMAs
-    const float* as = smx + (size_t)st * 2 * kTile + kq * kTnLd + wm + i;
-    const float* bs = smx + (size_t)st * 2 * kTile + kTile + kq * kTnLd + wn + i;
+  auto compute = [&](int st) {
+    const unsigned char* s = smx + st * kTx3Stage + kq * 16;
     bf16x8_t ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      float va[8], vb[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        va[e] = as[4 * e * kTnLd + 16 * t];
-        vb[e] = bs[4 * e * kTnLd + 16 * t];
-        asum[t] += va[e];
-      }
-      split8_tn(va, ah[t], al[t]);
-      split8_tn(vb, bh[t], bl[t]);
+      const unsigned char* pa = s + (wm + 16 * t + i) * kTx3ColB;
+      const unsigned char* pb = s + 2 * kTx3Plane + (wn + 16 * t + i) * kTx3ColB;
+      ah[t] = lds_frag8(pa);
+      al[t] = lds_frag8(pa + kTx3Plane);
+      bh[t] = lds_frag8(pb);
+      bl[t] = lds_frag8(pb + kTx3Plane);
     }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-      }
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-      }
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-      }
-    if (more) stash(st ^ 1);
-    __syncthreads();
-    st ^= 1;
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+  };
+  fetch(k_begin, r0);
+  stash(0, k_begin, r0);
+  fetch(k_begin + kTx3KC, r0);
+  fetch(k_begin + 2 * kTx3KC, r1);
+  lds_barrier_tn();
+  for (int k0 = k_begin;; k0 += 2 * kTx3KC) {
+    compute(0);
+    if (k0 + kTx3KC >= k_end) break;
+    stash(1, k0 + kTx3KC, r0);  // (stage 1 was last read before the barrier that closed the previous round)
+    fetch(k0 + 3 * kTx3KC, r0);
+    lds_barrier_tn();
+    compute(1);
+    if (k0 + 2 * kTx3KC >= k_end) break;
+    stash(0, k0 + 2 * kTx3KC, r1);
+    fetch(k0 + 4 * kTx3KC, r1);
+    lds_barrier_tn();
   }
-  if (do_sum) {
+  if (do_sum) {  // (uniform over the workgroup) the eight threads of a column add up in LDS: one atomic per column and workgroup
+    lds_barrier_tn();
+    float* cs = (float*)smx;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float v = asum[t];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      if (kq == 0) __hip_atomic_fetch_add((GW_AS1 float*)(colsum_a + mB + wm + 16 * t + i), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < 4; ++j) cs[lrow * 128 + lc + 32 * j] = csum[j];
+    lds_barrier_tn();
+    if (threadIdx.x < 128) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += cs[r * 128 + threadIdx.x];
+      __hip_atomic_fetch_add((GW_AS1 float*)(colsum_a + mB + threadIdx.x), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   // D layout of the 16x16 MFMAs (fp32 and bf16 alike): column = lane & 15, rows 4 (lane >> 4) + r.  Here the A operand carries the
@@ -774,7 +810,7 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
     if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
       if (x3) {  // split-operand products (the unaligned / narrow cases below compute the same sums in fp32)
-        constexpr int lds = 2 * 2 * kTx3KC * kTnLd * 4;
+        constexpr int lds = 2 * kTx3Stage;
         static DeviceOnce once;
         if (once.first()) (void)hipFuncSetAttribute((const void*)gemm_tn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(gemm_tn_x3_kernel, grid, block, lds, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
