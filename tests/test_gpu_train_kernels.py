@@ -54,7 +54,7 @@ def test_gemm_tn_accumulates(m, n, k):
                                             (256, 102, 4097, 0),
                                             # one, two, three stages of 32 rows and their ragged neighbours (the loads run two stages ahead)
                                             (128, 128, 1, 0), (256, 256, 32, 0), (256, 256, 33, 0), (128, 256, 64, 0), (256, 128, 65, 0),
-                                            (256, 256, 96, 0), (256, 256, 127, 0), (256, 256, 256 + 95, 0), (256, 256, 1000003, 0)])
+                                            (256, 256, 96, 0), (256, 256, 127, 0), (256, 256, 256 + 95, 0), (256, 256, 300007, 0)])
 def test_gemm_tn_on_split_operands(m, n, k, ld_extra):
     """GW_GEMM_TN_BF16X3 (weight gradients of the mixed-precision training step): the fp32 TN sums to ~1e-5 on operands of mixed
     sign and magnitude (a transposed operand or a k permutation that differs between A and B would be an O(1) error); ragged k,
