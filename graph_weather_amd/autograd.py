@@ -154,7 +154,8 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
 
 
 def chain_backward(d: torch.Tensor, chain, fan):
-    """gw_mlp_chain_backward: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows x 256."""
+    """gw_mlp_chain_backward[_bf16x3]: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows
+    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream)."""
     import ctypes as C
 
     def arr(ptrs):
@@ -163,10 +164,12 @@ def chain_backward(d: torch.Tensor, chain, fan):
             a[i] = v
         return a
 
-    _lib.check(_L().gw_mlp_chain_backward(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), len(chain),
-                                          arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
-                                          arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]),
-                                          arr([f[1].data_ptr() for f in fan]), _st(d)), "gw_mlp_chain_backward")
+    streams = [c[0] for c in chain] + [f[0] for f in fan]
+    fn = _L().gw_mlp_chain_backward if streams[0].dtype == torch.float32 else _L().gw_mlp_chain_backward_bf16x3
+    _lib.check(fn(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), len(chain),
+                  arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
+                  arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]),
+                  arr([f[1].data_ptr() for f in fan]), _st(d)), "gw_mlp_chain_backward")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -209,8 +212,8 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     if (mlp is not None and 2 <= n_lin <= 3 and d.shape[1] == 256 and d.stride(0) % 4 == 0 and d.shape[0] > 0
             and all(saved.hidden[l].shape[1] == 256 and saved.hidden[l].stride(0) == 256 for l in range(n_lin - 1))):
         pts = [_packed_transposed(mlp, l, weights[2 * l], 0, int(weights[2 * l].shape[1])) for l in range(n_lin - 1, 0, -1)]
-        # (the register-resident chain kernel is an fp32 kernel; bf16x3 runs the same products as single launches of the split kernel)
-        if all(p is not None and p.dtype == torch.float32 for p in pts):
+        # (fp32 streams: bwd_chain_kernel; split streams of the bf16x3 mode: bwd_chainx3_kernel - the same three-MFMA products)
+        if all(p is not None for p in pts):
             fblk = [(tuple(blk), _packed_transposed(mlp, 0, weights[0], blk[0], blk[1])) for blk in (fan if fan_out is not None else ())]
             fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
             rows = int(d.shape[0])

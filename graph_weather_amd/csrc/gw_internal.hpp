@@ -87,6 +87,17 @@ struct ChainArgs {
 int chain16_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
 // split-operand launches (gw_split.hip, GW_DTYPE_BF16X3): the same kinds; operands and outputs are fp32 rows only
 int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int grid_y, void* stream);
+// gw_mlp_chain_backward: d, then n_chain masked products (w[i], mask[i] -> out[i]), then n_fan products of the last gradient
+// (w[n_chain + i] -> out[n_chain + i]); all rows x 256.  fp32 streams: gw_kernels.hip; split streams (bf16x3): gw_split.hip
+struct BwdChainArgs {
+  const float* d;
+  const void* w[5];
+  const float* mask[2];
+  float* out[5];
+  long long n_rows;
+  int d_ld, n_chain, n_fan;
+};
+int bwd_chainx3_launch(const BwdChainArgs& a, void* stream);
 // one matrix item of gw_pack_many into the split stream (strides in floats)
 void pack_x3_item(const float* w, long long stride_f, long long stride_k, int n_out, int kseg, int ntp, int nsteps, void* out, void* stream);
 

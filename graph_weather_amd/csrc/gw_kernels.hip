@@ -666,15 +666,6 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, int n, int npad, 
 // gradients of layer 1, d_n . W1[:, block], for up to 3 operand blocks.  The forward kernel's structure: the accumulator of one
 // product is the B operand of the next, weights stream through LDS (double buffered DMA, two workgroups per CU); every d_i is
 // stored once (the weight-gradient GEMMs read it) and never read back by this chain.
-struct BwdChainArgs {
-  const float* d;
-  const float* w[5];
-  const float* mask[2];
-  float* out[5];
-  long long n_rows;
-  int d_ld, n_chain, n_fan;
-};
-
 __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HS = 64, HSTEPF = 1024;  // K-steps / floats per step of a 256 -> 256 product
@@ -687,7 +678,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
   const long long c = valid ? c_raw : a.n_rows - 1;
   const int n_prod = a.n_chain + a.n_fan;
   int parity = 0;
-  issue_chunk(a.w[0], kChunkSteps * HSTEPF, lds, lane, wave);
+  issue_chunk((const float*)a.w[0], kChunkSteps * HSTEPF, lds, lane, wave);
   float x[HS];
   load_operand<HS, true>(x, a.d + (size_t)c * (size_t)a.d_ld, 256, q);
 #pragma unroll 1
@@ -702,8 +693,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
     f32x4 acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* nx = p + 1 < n_prod ? a.w[p + 1] : nullptr;
-    mma_pass<HS, 16, false>(acc, x, a.w[p], nx, nx ? kChunkSteps * HSTEPF : 0, lds, parity, lane, wave, nullptr, false, nullptr,
+    const float* nx = p + 1 < n_prod ? (const float*)a.w[p + 1] : nullptr;
+    mma_pass<HS, 16, false>(acc, x, (const float*)a.w[p], nx, nx ? kChunkSteps * HSTEPF : 0, lds, parity, lane, wave, nullptr, false, nullptr,
                             false, q);
     if (chain) {
 #pragma unroll
@@ -999,14 +990,12 @@ int gw_pack_many(int32_t weight_dtype, int32_t n_mats, const gw_pack_item* mats,
   return check_launch("pack_many_kernel launch");
 }
 
-int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const float* const* chain_w,
-                          const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const float* const* fan_w,
-                          float* const* fan_out, void* stream) {
+namespace {
+int fill_bwd_chain(BwdChainArgs& a, int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const void* const* chain_w,
+                   const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w, float* const* fan_out) {
   if (n_rows < 0 || !d || d_ld < 256 || d_ld % 4 != 0 || n_chain < 0 || n_chain > 2 || n_fan < 0 || n_fan > 3 || n_chain + n_fan < 1 ||
       (n_chain > 0 && (!chain_w || !chain_mask || !chain_out)) || (n_fan > 0 && (!fan_w || !fan_out)))
     return fail(GW_E_BADARG, "gw_mlp_chain_backward: bad arguments");
-  if (n_rows == 0) return GW_OK;
-  BwdChainArgs a;
   memset(&a, 0, sizeof(a));
   a.d = d;
   a.d_ld = d_ld;
@@ -1024,12 +1013,33 @@ int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t 
     a.w[n_chain + i] = fan_w[i];
     a.out[n_chain + i] = fan_out[i];
   }
+  if ((n_rows + kColsPerWG - 1) / kColsPerWG > 0x7fffffffLL) return fail(GW_E_BADARG, "gw_mlp_chain_backward: too many rows");
+  return GW_OK;
+}
+}  // namespace
+
+int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const float* const* chain_w,
+                          const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const float* const* fan_w,
+                          float* const* fan_out, void* stream) {
+  BwdChainArgs a;
+  if (int rc = fill_bwd_chain(a, n_rows, d, d_ld, n_chain, (const void* const*)chain_w, chain_mask, chain_out, n_fan, (const void* const*)fan_w,
+                              fan_out))
+    return rc;
+  if (n_rows == 0) return GW_OK;
   static DeviceOnce once;
   if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   const long long grid = (n_rows + kColsPerWG - 1) / kColsPerWG;
-  if (grid > 0x7fffffffLL) return fail(GW_E_BADARG, "gw_mlp_chain_backward: too many rows");
   hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
   return check_launch("bwd_chain_kernel launch");
+}
+
+int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const void* const* chain_w,
+                                 const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
+                                 float* const* fan_out, void* stream) {
+  BwdChainArgs a;
+  if (int rc = fill_bwd_chain(a, n_rows, d, d_ld, n_chain, chain_w, chain_mask, chain_out, n_fan, fan_w, fan_out)) return rc;
+  if (n_rows == 0) return GW_OK;
+  return bwd_chainx3_launch(a, stream);
 }
 
 int gw_pad_vector(const float* v, int n, float* out, void* stream) {

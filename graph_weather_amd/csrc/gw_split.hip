@@ -775,6 +775,58 @@ __global__ void pack_linear_x3_kernel(const float* __restrict__ w, long long sf,
   }
 }
 
+// ---- gw_mlp_chain_backward on split operands: d_{i+1} = (d_i . W_i) * (h_i > 0) for the Linear layers above layer 1, then the
+// layer-1 input gradients d_n . W1[:, block] - every product three bf16 MFMAs on (hi, lo) pairs like the forward, the gradient
+// rows register-resident between the products (the accumulator of one is the B operand of the next), each d_i stored once for the
+// weight-gradient GEMMs and never read back here.  Single launches of chainx3_kernel<SINGLE> read d_i again for every product
+// that consumes it: 2 - 4 of the ~10 table passes of an MLP's input-gradient chain.  64 rows per workgroup, two per CU.
+template <int RING>
+__global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ldsx[];
+  constexpr int NW = 4, HT = 16, HKS = 8;
+  constexpr int FIRST = buf_bytes(NW);  // first chunk of a 256 -> 256 stream: one K-step of 16 row tiles (hi + lo)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15;
+  const int q = lane >> 4;
+  const long long c_raw = (long long)blockIdx.x * (NW * 16) + wave * 16 + j;
+  const bool valid = c_raw < a.n_rows;
+  const long long c = valid ? c_raw : a.n_rows - 1;
+  const int n_prod = a.n_chain + a.n_fan;
+  int parity = 0;
+  issue_bytes<NW>((const char*)a.w[0], FIRST, 0u, lane, wave);
+  bf16x8 bh[1][HKS], bl[1][HKS];
+  load_raw<HKS, true, 8>(bh[0], bl[0], a.d + (size_t)c * (size_t)a.d_ld, 256, q);
+#pragma unroll 1
+  for (int p = 0; p < n_prod; ++p) {
+    const bool chain = p < a.n_chain;
+    f32x4 acc[1][HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* nx = p + 1 < n_prod ? (const char*)a.w[p + 1] : nullptr;
+    pass_x3<NW, 1, HKS, HKS, HT, HT, RING>(acc, bh, bl, (const char*)a.w[p], nx, nx ? FIRST : 0, ldsx, parity, lane, wave);
+    if (chain) {  // the ReLU output that fed this layer gates its input gradient
+      const float* mrow = a.mask[p] + (size_t)c * 256;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const f32x4 mv = ldg4(mrow + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!(mv[r] > 0.f)) acc[0][t][r] = 0.f;
+      }
+    }
+    if (valid) {
+      float* orow = a.out[p] + (size_t)c * 256;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) stg4(orow + 16 * t + 4 * q, acc[0][t]);
+    }
+    if (chain) {
+      acc_to_b<HT, false>(bh[0], bl[0], acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <typename K>
 int launchx3(K kernel, ChainArgs& a, void* stream, int grid_y, int lds, int threads, int cols) {
   static DeviceOnce once;  // per template instantiation and device
@@ -847,6 +899,15 @@ int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
       return set_error(GW_E_UNSUPPORTED, "bf16x3 mlp + post products: hidden 256, 256 outputs, 33..128 inputs");
   }
   return set_error(GW_E_BADARG, "chainx3_launch: bad kind");
+}
+
+int bwd_chainx3_launch(const BwdChainArgs& a, void* stream) {
+  constexpr int lds = 2 * buf_bytes(4);
+  static DeviceOnce once;
+  if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chainx3_kernel<kRing>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const long long grid = (a.n_rows + 63) / 64;
+  hipLaunchKernelGGL(bwd_chainx3_kernel<kRing>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("bwd_chainx3_kernel launch");
 }
 
 void pack_x3_item(const float* w, long long sf, long long sk, int n_out, int kseg, int ntp, int nsteps, void* out, void* stream) {

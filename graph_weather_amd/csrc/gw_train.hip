@@ -276,14 +276,23 @@ __device__ __forceinline__ void lds_barrier_tn() { asm volatile("s_waitcnt lgkmc
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* __restrict__ A, int lda,
                                                             const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                                                            int k_slab, float* __restrict__ colsum_a) {
+                                                            int k_slab, float* __restrict__ colsum_a, int tiles_m, int tiles, int tune) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];  // [stage 2][plane 4][column 128][72 bytes]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int mB = blockIdx.x * 128, nB = blockIdx.y * 128;
+  // One-dimensional grid, XCD aware: workgroup L runs on XCD L % 8 (observed placement, used for speed only), and the tiles of
+  // one row slab read the same operand rows - they are given to consecutive workgroups of ONE XCD, so the second, third and
+  // fourth reader of a row find it in that XCD's L2 instead of fetching it again over the fabric.
+  const int xl = (int)blockIdx.x >> 3;
+  const bool plain = (tune & 2) != 0;  // (tuning builds: launch order, the tiles of a slab on different XCDs)
+  const int tile = plain ? (int)blockIdx.x % tiles : xl % tiles;
+  const int slab = plain ? (int)blockIdx.x / tiles : (xl / tiles) * 8 + ((int)blockIdx.x & 7);
+  const int k_begin = slab * k_slab;
+  if (k_begin >= K) return;
+  const int bx = tile % tiles_m, by = tile / tiles_m;
+  const int mB = bx * 128, nB = by * 128;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int k_begin = blockIdx.z * k_slab;
   const int k_end = k_begin + k_slab < K ? k_begin + k_slab : K;
   const int lrow = threadIdx.x >> 5;  // 0..7 (+ 8 h): k row inside a stage
   const int lc = threadIdx.x & 31;    // (+ 32 j): column inside the 128-wide tile
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   // column sums of A (the bias gradient when A = dZ): taken once per m, by the workgroups of the first n-block column
-  const bool do_sum = colsum_a != nullptr && blockIdx.y == 0;
+  const bool do_sum = colsum_a != nullptr && by == 0;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
   float r0[32], r1[32];  // two stages in flight: [A | B][h][j]
@@ -345,6 +354,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
       bh[t] = lds_frag8(pb);
       bl[t] = lds_frag8(pb + kTx3Plane);
     }
+    if (tune & 4) {  // (tuning builds: the loop without its MFMAs - the fragments are still read)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][0][0] += (float)ah[t][0] + (float)al[t][1] + (float)bh[t][2] + (float)bl[t][3];
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -388,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
       __hip_atomic_fetch_add((GW_AS1 float*)(colsum_a + mB + threadIdx.x), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (tune & 1) return;  // (tuning builds: the cost of the atomics)
   // D layout of the 16x16 MFMAs (fp32 and bf16 alike): column = lane & 15, rows 4 (lane >> 4) + r.  Here the A operand carries the
   // M index in its row slot (lane & 15 of the A fragment = m) and B the N index: D[row = m][col = n]
 #pragma unroll
@@ -800,20 +815,29 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
   const dim3 block(256);
   if (mode == GW_GEMM_TN) {
     if (k == 0) return GW_OK;  // nothing to add
-    // slab of rows per block: enough blocks to fill the chip (>= ~1024), each at least 256 rows deep
+    // slab of rows per block: enough blocks to fill the chip, each at least 256 rows deep.  Every slab ends in 64 K atomics per
+    // 128 x 128 tile (0.4 T atomics/s measured: 12 of the 25 us at the 11 764 mesh-node rows, 33 of 83 us at a processor block's
+    // 82 324 edge rows), so the split kernel - whose loads run two stages ahead and need fewer workgroups to cover the latency -
+    // aims at one resident round (512 workgroups, two per CU) without the 4096-row cap: 83 -> 62 us at 82 324 rows, the same
+    // time at 907 200 and at 11 764 (scripts/probes/gemm_tn_x3_probe.py)
     const int tiles = (int)((m + 127) / 128) * ((n + 127) / 128);
-    static const int tn_target = GW_TUNE("GW_TN_TARGET", 1024), tn_min = GW_TUNE("GW_TN_MIN", 256);
-    int64_t k_slab = (k * tiles + tn_target - 1) / tn_target;
+    static const int tn_target = GW_TUNE("GW_TN_TARGET", 0), tn_min = GW_TUNE("GW_TN_MIN", 256), tn_cap = GW_TUNE("GW_TN_CAP", 0);
+    const int target = tn_target > 0 ? tn_target : (x3 ? 512 : 1024), cap = tn_cap > 0 ? tn_cap : (x3 ? 16384 : 4096);
+    int64_t k_slab = (k * tiles + target - 1) / target;
     k_slab = ((k_slab + 63) / 64) * 64;
     if (k_slab < tn_min) k_slab = tn_min;
-    if (k_slab > 4096) k_slab = 4096;
+    if (k_slab > cap) k_slab = cap;
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
     if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
       if (x3) {  // split-operand products (the unaligned / narrow cases below compute the same sums in fp32)
         constexpr int lds = 2 * kTx3Stage;
         static DeviceOnce once;
         if (once.first()) (void)hipFuncSetAttribute((const void*)gemm_tn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(gemm_tn_x3_kernel, grid, block, lds, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
+        const int tiles_m = (int)(m / 128), slabs8 = ((int)grid.z + 7) / 8 * 8;
+        static const int x3_tune = GW_TUNE("GW_TN_X3_TUNE", 0);
+        const dim3 grid1((unsigned)(tiles * slabs8));
+        hipLaunchKernelGGL(gemm_tn_x3_kernel, grid1, block, lds, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a,
+                           tiles_m, tiles, x3_tune);
         return check_launch("gemm_tn_x3_kernel launch");
       }
       hipLaunchKernelGGL(gemm_tn_lds_kernel, grid, block, 0, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);

@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 17
+#define GW_ABI_VERSION 18
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -227,10 +227,16 @@ int gw_mlp_post_forward(int64_t n_rows, int32_t rows_per_batch, const gw_operand
  * chain_out[i] [n_rows, 256] (the weight-gradient products read them); then fan_out[s] = d_{n_chain} . Wf_s for s < n_fan (<= 3):
  * the input gradients of the first Linear's operand blocks.  chain_w / fan_w: packed TRANSPOSED 256 x 256 blocks
  * (gw_pack_many with {w + lo, 1, k_total}); chain_mask[i]: the ReLU output that fed layer i [n_rows, 256] (gw_activation_save).
- * fp32 only. */
+ * fp32 streams. */
 int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const float* const* chain_w,
                           const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const float* const* fan_w,
                           float* const* fan_out, void* stream);
+/* (v18) The same chain on split operands (mixed-precision training, GW_DTYPE_BF16X3): chain_w / fan_w are the packed transposed
+ * blocks in the split stream (gw_pack_many with GW_DTYPE_BF16X3); every product is the forward's three bf16 MFMAs on (hi, lo)
+ * pairs, the gradient rows stay in registers between the products.  d, masks and outputs are fp32 rows as above. */
+int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const void* const* chain_w,
+                                 const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
+                                 float* const* fan_out, void* stream);
 
 /* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
  * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7

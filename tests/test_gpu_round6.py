@@ -347,3 +347,51 @@ def test_cold_forward_rebuilds_the_decoder_tables_on_a_side_stream_with_the_same
             assert torch.equal(cold, warm), trial
             assert model.decoder.prefetch_tables(x.device) is None
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows", [1, 64, 1000, 4097])
+def test_chain_backward_on_split_operands_against_torch_and_the_single_products(rows):
+    """gw_mlp_chain_backward_bf16x3 (ABI v18): d1 = (d W2) * (h1 > 0), dz0 = (d1 W1) * (h0 > 0) and the fan products dz0 W0[:, block]
+    in one launch on split operands - against torch fp64 at the split mode's accuracy (operands carry 16 significant bits) and
+    against the single-layer launches it replaces (the same three-MFMA products on the same split of the same rows: equal to
+    fp32 rounding of the intermediate rows, which the single launches read back from memory as the identical fp32 values)."""
+    from graph_weather_amd import _lib, autograd as ag
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    W2, W1 = (torch.randn(256, 256, generator=g) / 16).to(DEV), (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    W0 = (torch.randn(256, 768, generator=g) / 16).to(DEV)
+    d = torch.randn(rows, 256, generator=g).to(DEV)
+    h1, h0 = torch.randn(rows, 256, generator=g).relu().to(DEV), torch.randn(rows, 256, generator=g).relu().to(DEV)
+    n = int(L.gw_packed_bytes_bf16x3(256, 0, 256)) // 2
+    blocks = [(W2, 0), (W1, 0), (W0, 0), (W0, 256), (W0, 512)]
+    buf = torch.empty(len(blocks) * n, dtype=torch.int16, device=DEV)
+    ops.pack_many(_lib.DTYPE_BF16X3, [(W.data_ptr() + 4 * lo, 1, int(W.shape[1]), 256, 256, buf[i * n:].data_ptr())
+                                      for i, (W, lo) in enumerate(blocks)], [], st)
+    pk = [buf[i * n:(i + 1) * n] for i in range(len(blocks))]
+    dd = d.double()
+    r1 = (dd @ W2.double()) * (h1 > 0)
+    r0 = (r1 @ W1.double()) * (h0 > 0)
+    # the launches this kernel replaces
+    s1 = ops.project_forward([pk[0]], Operand(d, rows, 256), rows, rows, relu_mask=h1)[0]
+    s0 = ops.project_forward([pk[1]], Operand(s1, rows, 256), rows, rows, relu_mask=h0)[0]
+    for n_chain in (1, 2):
+        for n_fan in (0, 1, 3):
+            outs = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(n_chain)]
+            fouts = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(n_fan)]
+            chain = [(pk[0], h1, outs[0])] + ([(pk[1], h0, outs[1])] if n_chain == 2 else [])
+            ag.chain_backward(d, chain, [(pk[2 + s], fouts[s]) for s in range(n_fan)])
+            torch.cuda.synchronize()
+            last = r0 if n_chain == 2 else r1
+            want = [r1, r0][:n_chain] + [last @ W0.double()[:, 256 * s:256 * (s + 1)] for s in range(n_fan)]
+            for got, ref in zip(outs + fouts, want):
+                scale = ref.abs().max().item() + 1e-12
+                assert (got.double() - ref).abs().max().item() <= 5e-5 * scale
+            assert torch.equal(outs[0], s1)
+            if n_chain == 2:
+                assert torch.equal(outs[1], s0)
+            slast = s0 if n_chain == 2 else s1
+            for s in range(n_fan):
+                single = ops.project_forward([pk[2 + s]], Operand(slast, rows, 256), rows, rows)[0]
+                assert torch.equal(fouts[s], single)

@@ -279,9 +279,12 @@ def test_split_kernels_fit_two_workgroups_per_cu_and_issue_three_mfmas_per_fragm
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", src, "-o", "s.o", "-save-temps"]
     subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True)
     text = (tmp_path / "gw_split-hip-amdgcn-amd-amdhsa-gfx950.s").read_text()
-    names = re.findall(r"^(_Z\w*chainx3_kernel\w*):", text, re.M)
+    names = re.findall(r"^(_Z\w*14chainx3_kernel\w*):", text, re.M)
     assert len(names) == 11, names  # mlp x 5 shapes, edge, node update (+ post, + head), project, mlp + post
     assert all(n.endswith("ELi4ELi1ELi3EEEvN2gw9ChainArgsE") for n in names), names
+    bwd = re.findall(r"^(_Z\w*18bwd_chainx3_kernel\w*):", text, re.M)  # the input-gradient chain of the training step (ABI v18)
+    assert len(bwd) == 1, bwd
+    names = names + bwd
     assert "s_memtime" not in text
     # 256 x 256 passes per instantiation family: (raw layer-1 operands) + middle + output (+ products / head)
     for name in names:
