@@ -165,7 +165,10 @@ def chain_backward(d: torch.Tensor, chain, fan):
         return a
 
     streams = [c[0] for c in chain] + [f[0] for f in fan]
-    fn = _L().gw_mlp_chain_backward if streams[0].dtype == torch.float32 else _L().gw_mlp_chain_backward_bf16x3
+    if len({t.dtype for t in streams}) > 1:
+        raise RuntimeError("graph_weather_amd: chain_backward: packed streams of different dtypes")
+    x3 = bool(streams) and streams[0].dtype != torch.float32  # (no product at all: the C entry refuses)
+    fn = _L().gw_mlp_chain_backward_bf16x3 if x3 else _L().gw_mlp_chain_backward
     _lib.check(fn(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), len(chain),
                   arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
                   arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]),
