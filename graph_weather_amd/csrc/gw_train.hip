@@ -274,7 +274,10 @@ __device__ __forceinline__ bf16x8_t lds_frag8(const unsigned char* p) {  // 8-by
 }
 __device__ __forceinline__ void lds_barrier_tn() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* __restrict__ A, int lda,
+// RAGGED: m or n is not a multiple of 128 (the 102 input / 78 output features of the node encoder's first and the head's last
+// Linear): columns past the edge are read from the last real column and zeroed with the rows past k_end; nothing is stored for them.
+template <bool RAGGED>
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                             const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                                             int k_slab, float* __restrict__ colsum_a, int tiles_m, int tiles, int tune) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smx[];  // [stage 2][plane 4][column 128][72 bytes]
@@ -308,6 +311,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
   float r0[32], r1[32];  // two stages in flight: [A | B][h][j]
   // rows past k_end (the ragged last stage of the matrix, and the one or two stages fetched past the end of the slab) are read
   // from row k_end - 1 - no branch, no register merge - and zeroed when the stage is split
+  int ca[4], cb[4];       // RAGGED: column offsets from (mB + lc) / (nB + lc), clamped to the last real column
+  bool aok[4], bok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    aok[j] = !RAGGED || mB + lc + 32 * j < M;
+    bok[j] = !RAGGED || nB + lc + 32 * j < N;
+    ca[j] = aok[j] ? 32 * j : M - 1 - mB - lc;
+    cb[j] = bok[j] ? 32 * j : N - 1 - nB - lc;
+  }
   auto fetch = [&](int k0, float (&r)[32]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -317,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
       const float* pb = B + (size_t)k * ldb + nB + lc;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        r[4 * h + j] = ldg1(pa + 32 * j);
-        r[16 + 4 * h + j] = ldg1(pb + 32 * j);
+        r[4 * h + j] = ldg1(pa + (RAGGED ? ca[j] : 32 * j));
+        r[16 + 4 * h + j] = ldg1(pb + (RAGGED ? cb[j] : 32 * j));
       }
     }
   };
@@ -331,8 +343,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
     for (int op = 0; op < 2; ++op)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float v0 = ok[0] ? r[16 * op + j] : 0.f, v1 = ok[1] ? r[16 * op + 4 + j] : 0.f;
-        const float v2 = ok[2] ? r[16 * op + 8 + j] : 0.f, v3 = ok[3] ? r[16 * op + 12 + j] : 0.f;
+        const bool cok = !RAGGED || (op == 0 ? aok[j] : bok[j]);
+        const float v0 = (ok[0] && cok) ? r[16 * op + j] : 0.f, v1 = (ok[1] && cok) ? r[16 * op + 4 + j] : 0.f;
+        const float v2 = (ok[2] && cok) ? r[16 * op + 8 + j] : 0.f, v3 = (ok[3] && cok) ? r[16 * op + 12 + j] : 0.f;
         if (op == 0) csum[j] += (v0 + v1) + (v2 + v3);
         unsigned h01, l01, h23, l23;
         split2_tn(v0, v1, h01, l01);
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs[lrow * 128 + lc + 32 * j] = csum[j];
     lds_barrier_tn();
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < 128 && (!RAGGED || mB + (int)threadIdx.x < M)) {
       float v = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) v += cs[r * 128 + threadIdx.x];
@@ -413,7 +426,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(int K, const float* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mm = mB + wm + 16 * tm + 4 * kq + r;
-        __hip_atomic_fetch_add((GW_AS1 float*)(C + (size_t)mm * ldc + n), acc[tm][tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!RAGGED || (mm < M && n < N))
+          __hip_atomic_fetch_add((GW_AS1 float*)(C + (size_t)mm * ldc + n), acc[tm][tn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
 }
@@ -828,18 +842,25 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     if (k_slab < tn_min) k_slab = tn_min;
     if (k_slab > cap) k_slab = cap;
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)((k + k_slab - 1) / k_slab));
-    if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
-      if (x3) {  // split-operand products (the unaligned / narrow cases below compute the same sums in fp32)
-        constexpr int lds = 2 * kTx3Stage;
+    if (x3) {  // split-operand products: any shape (4-byte loads, ragged tiles guarded)
+      constexpr int lds = 2 * kTx3Stage;
+      const int tiles_m = (int)((m + 127) / 128), slabs8 = ((int)grid.z + 7) / 8 * 8;
+      static const int x3_tune = GW_TUNE("GW_TN_X3_TUNE", 0);
+      const dim3 grid1((unsigned)(tiles * slabs8));
+      if (m % 128 == 0 && n % 128 == 0) {
         static DeviceOnce once;
-        if (once.first()) (void)hipFuncSetAttribute((const void*)gemm_tn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        const int tiles_m = (int)(m / 128), slabs8 = ((int)grid.z + 7) / 8 * 8;
-        static const int x3_tune = GW_TUNE("GW_TN_X3_TUNE", 0);
-        const dim3 grid1((unsigned)(tiles * slabs8));
-        hipLaunchKernelGGL(gemm_tn_x3_kernel, grid1, block, lds, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a,
-                           tiles_m, tiles, x3_tune);
-        return check_launch("gemm_tn_x3_kernel launch");
+        if (once.first()) (void)hipFuncSetAttribute((const void*)gemm_tn_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(gemm_tn_x3_kernel<false>, grid1, block, lds, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab,
+                           colsum_a, tiles_m, tiles, x3_tune);
+      } else {
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)gemm_tn_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(gemm_tn_x3_kernel<true>, grid1, block, lds, (hipStream_t)stream, (int)m, n, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab,
+                           colsum_a, tiles_m, tiles, x3_tune);
       }
+      return check_launch("gemm_tn_x3_kernel launch");
+    }
+    if (m % 128 == 0 && n % 128 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
       hipLaunchKernelGGL(gemm_tn_lds_kernel, grid, block, 0, (hipStream_t)stream, (int)k, a, lda, b, ldb, c, ldc, (int)k_slab, colsum_a);
       return check_launch("gemm_tn_lds_kernel launch");
     }

@@ -54,12 +54,15 @@ def test_gemm_tn_accumulates(m, n, k):
                                             (256, 102, 4097, 0),
                                             # one, two, three stages of 32 rows and their ragged neighbours (the loads run two stages ahead)
                                             (128, 128, 1, 0), (256, 256, 32, 0), (256, 256, 33, 0), (128, 256, 64, 0), (256, 128, 65, 0),
-                                            (256, 256, 96, 0), (256, 256, 127, 0), (256, 256, 256 + 95, 0), (256, 256, 300007, 0)])
+                                            (256, 256, 96, 0), (256, 256, 127, 0), (256, 256, 256 + 95, 0), (256, 256, 300007, 0),
+                                            # ragged m / n, odd leading dimensions
+                                            (78, 128, 5000, 0), (80, 128, 333, 1), (256, 78, 4097, 3), (1, 1, 70, 0), (129, 257, 1000, 1),
+                                            (102, 256, 129600, 0)])
 def test_gemm_tn_on_split_operands(m, n, k, ld_extra):
     """GW_GEMM_TN_BF16X3 (weight gradients of the mixed-precision training step): the fp32 TN sums to ~1e-5 on operands of mixed
     sign and magnitude (a transposed operand or a k permutation that differs between A and B would be an O(1) error); ragged k,
-    strided operands, a 768-wide destination written at a column offset; shapes that are not multiples of 128 take the fp32
-    kernel."""
+    strided operands (any leading dimension: the loads are 4-byte), a 768-wide destination written at a column offset; shapes
+    that are not multiples of 128 (the 102 input / 78 output features of the path) run the ragged form of the same kernel."""
     rs = np.random.RandomState(k + n)
     a = torch.from_numpy((rs.standard_normal((k, m + ld_extra)) * 10.0 ** rs.uniform(-2, 2, size=(k, 1))).astype(np.float32))
     b = torch.from_numpy(rs.standard_normal((k, n + ld_extra)).astype(np.float32))
