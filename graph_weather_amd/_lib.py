@@ -15,14 +15,14 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgw_amd.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared", "-fPIC"]
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
 LAYOUT_ROWS_F32, LAYOUT_EDGE_TILES_BF16, LAYOUT_ROWS_F16, LAYOUT_ROWS_BF16K = 0, 1, 2, 3
 EDGE_DETERMINISTIC, EDGE_SEGMENT_TILES, EDGE_AGG_BF16K, EDGE_SEGMENT_SPLIT = 1, 2, 4, 8
 
 EXPORTS = [
     "gw_version", "gw_last_error", "gw_debug_timestamps", "gw_packed_floats", "gw_pack_linear", "gw_packed_bytes_bf16",
-    "gw_pack_linear_bf16", "gw_packed_bytes_bf16x3", "gw_pack_linear_bf16x3", "gw_padded_n", "gw_pad_vector", "gw_pack_many", "gw_mlp_chain_backward", "gw_mlp_chain_backward_bf16x3",
+    "gw_pack_linear_bf16", "gw_packed_bytes_bf16x3", "gw_pack_linear_bf16x3", "gw_padded_n", "gw_pad_vector", "gw_pack_many", "gw_mlp_chain_backward", "gw_mlp_chain_backward_bf16x3", "gw_mlp_ln_chain_backward",
     "gw_mlp_forward", "gw_mlp_post_forward", "gw_project_forward", "gw_edge_update_forward", "gw_edge_update_workspace_bytes", "gw_edge_tiles_bytes",
     "gw_edge_rows_to_tiles", "gw_node_update_forward", "gw_node_update_row_split_groups", "gw_node_update_head_forward",
     "gw_normalized_mse_forward", "gw_gemm_f32", "gw_relu_backward", "gw_layernorm_backward", "gw_gather_rows",
@@ -126,6 +126,10 @@ def lib():
                                         c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p]
     L.gw_mlp_chain_backward_bf16x3.restype = c_int
     L.gw_mlp_chain_backward_bf16x3.argtypes = L.gw_mlp_chain_backward.argtypes
+    L.gw_mlp_ln_chain_backward.restype = c_int
+    L.gw_mlp_ln_chain_backward.argtypes = [c_int32, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                           c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p]
     L.gw_pack_many.restype = c_int
     L.gw_pack_many.argtypes = [c_int32, c_int32, POINTER(GwPackItem), c_int32, POINTER(GwPadItem), c_void_p]
     L.gw_mlp_forward.restype = c_int

@@ -153,9 +153,11 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
     return out
 
 
-def chain_backward(d: torch.Tensor, chain, fan):
+def chain_backward(d: torch.Tensor, chain, fan, ln=None):
     """gw_mlp_chain_backward[_bf16x3]: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows
-    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream)."""
+    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream).  ``ln`` = (pre-norm rows, gamma,
+    dgamma, dbeta, dy): ``d`` is the gradient at the OUTPUT of the MLP's LayerNorm and the launch walks back through the norm
+    first (gw_mlp_ln_chain_backward; split streams only - ``ln_chain_ok``)."""
     import ctypes as C
 
     def arr(ptrs):
@@ -168,11 +170,16 @@ def chain_backward(d: torch.Tensor, chain, fan):
     if len({t.dtype for t in streams}) > 1:
         raise RuntimeError("graph_weather_amd: chain_backward: packed streams of different dtypes")
     x3 = bool(streams) and streams[0].dtype != torch.float32  # (no product at all: the C entry refuses)
+    items = (len(chain), arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
+             arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]), arr([f[1].data_ptr() for f in fan]), _st(d))
+    if ln is not None:
+        y, gamma, dgamma, dbeta, dy = ln
+        _lib.check(_L().gw_mlp_ln_chain_backward(_lib.DTYPE_BF16X3 if x3 else _lib.DTYPE_F32, int(d.shape[0]), d.data_ptr(), int(d.stride(0)),
+                                                 y.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), *items),
+                   "gw_mlp_ln_chain_backward")
+        return
     fn = _L().gw_mlp_chain_backward_bf16x3 if x3 else _L().gw_mlp_chain_backward
-    _lib.check(fn(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), len(chain),
-                  arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
-                  arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]),
-                  arr([f[1].data_ptr() for f in fan]), _st(d)), "gw_mlp_chain_backward")
+    _lib.check(fn(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), *items), "gw_mlp_chain_backward")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -203,30 +210,41 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         zs.append(zbuf[off:off + int(w.numel())].view(w.shape))
         off += int(w.numel())
     grads[0] = zs[0]
-    if has_norm:
-        grads[-2] = zs[-2]
-        grads[-1] = zs[-1]
-        d = layernorm_backward(dout.contiguous(), saved.pre_norm, gamma, grads[-2], grads[-1], ln_width)
-    else:
-        d = dout.contiguous()
+    dout = dout.contiguous()
+    n_rows = int(dout.shape[0])
     # Kernel-shaped MLPs (256 wide, at most two Linear layers above layer 0): the whole chain of masked input-gradient products
     # and the requested layer-0 blocks in ONE launch (gw_mlp_chain_backward); the weight-gradient GEMMs read what it stored.
-    fused = None
-    if (mlp is not None and 2 <= n_lin <= 3 and d.shape[1] == 256 and d.stride(0) % 4 == 0 and d.shape[0] > 0
+    # In the split mode the LayerNorm backward in front of the chain is that launch's prologue (gw_mlp_ln_chain_backward).
+    pts = None
+    if (mlp is not None and 2 <= n_lin <= 3 and dout.shape[1] == 256 and n_rows > 0
             and all(saved.hidden[l].shape[1] == 256 and saved.hidden[l].stride(0) == 256 for l in range(n_lin - 1))):
         pts = [_packed_transposed(mlp, l, weights[2 * l], 0, int(weights[2 * l].shape[1])) for l in range(n_lin - 1, 0, -1)]
         # (fp32 streams: bwd_chain_kernel; split streams of the bf16x3 mode: bwd_chainx3_kernel - the same three-MFMA products)
-        if all(p is not None for p in pts):
-            fblk = [(tuple(blk), _packed_transposed(mlp, 0, weights[0], blk[0], blk[1])) for blk in (fan if fan_out is not None else ())]
-            fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
-            rows = int(d.shape[0])
-            outs = [torch.empty((rows, 256), dtype=torch.float32, device=d.device) for _ in pts]
-            fouts = [torch.empty((rows, 256), dtype=torch.float32, device=d.device) for _ in fblk]
-            chain_backward(d, [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
-                           [(ft, t) for (_, ft), t in zip(fblk, fouts)])
-            fused = outs
-            for (blk, _), t in zip(fblk, fouts):
-                fan_out[blk] = t
+        if any(p is None for p in pts):
+            pts = None
+    ln_fused = (pts is not None and has_norm and pts[0].dtype != torch.float32 and int(gamma.numel()) == 256 and ln_width in (0, 256)
+                and saved.pre_norm.shape[1] == 256 and saved.pre_norm.stride(0) == 256)
+    if has_norm:
+        grads[-2] = zs[-2]
+        grads[-1] = zs[-1]
+        if ln_fused:
+            d = torch.empty((n_rows, 256), dtype=torch.float32, device=dout.device)  # written by the chain launch
+        else:
+            d = layernorm_backward(dout, saved.pre_norm, gamma, grads[-2], grads[-1], ln_width)
+    else:
+        d = dout
+    fused = None
+    if pts is not None:
+        fblk = [(tuple(blk), _packed_transposed(mlp, 0, weights[0], blk[0], blk[1])) for blk in (fan if fan_out is not None else ())]
+        fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
+        outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in pts]
+        fouts = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in fblk]
+        chain_backward(dout if ln_fused else d, [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
+                       [(ft, t) for (_, ft), t in zip(fblk, fouts)],
+                       ln=(saved.pre_norm, gamma, grads[-2], grads[-1], d) if ln_fused else None)
+        fused = outs
+        for (blk, _), t in zip(fblk, fouts):
+            fan_out[blk] = t
     if fused is not None:
         ds = [d] + fused  # ds[i]: gradient at the output of Linear_{n_lin-1-i}
         for i, l in enumerate(range(n_lin - 1, 0, -1)):

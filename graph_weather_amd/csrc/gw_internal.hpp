@@ -96,6 +96,12 @@ struct BwdChainArgs {
   float* out[5];
   long long n_rows;
   int d_ld, n_chain, n_fan;
+  // gw_mlp_ln_chain_backward: d is the gradient at the OUTPUT of the MLP's LayerNorm; the kernel walks back through the norm first
+  const float* ln_y;      // pre-LayerNorm rows [n_rows, 256] (the forward's activation save); NULL: no LayerNorm in front
+  const float* ln_gamma;  // [256]
+  float* ln_dgamma;       // [256] +=
+  float* ln_dbeta;        // [256] +=
+  float* ln_dy;           // [n_rows, 256]: gradient at the LayerNorm input (the last Linear's weight-gradient GEMM reads it)
 };
 int bwd_chainx3_launch(const BwdChainArgs& a, void* stream);
 // one matrix item of gw_pack_many into the split stream (strides in floats)

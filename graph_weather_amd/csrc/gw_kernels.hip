@@ -1033,6 +1033,24 @@ int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t 
   return check_launch("bwd_chain_kernel launch");
 }
 
+int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
+                             float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
+                             const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
+                             float* const* fan_out, void* stream) {
+  if (!y || !gamma || !dgamma || !dbeta || !dy) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: NULL LayerNorm argument");
+  if (weight_dtype != GW_DTYPE_BF16X3)
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_ln_chain_backward: split streams (GW_DTYPE_BF16X3) only - fp32: gw_layernorm_backward + gw_mlp_chain_backward");
+  BwdChainArgs a;
+  if (int rc = fill_bwd_chain(a, n_rows, dn, dn_ld, n_chain, chain_w, chain_mask, chain_out, n_fan, fan_w, fan_out)) return rc;
+  if (n_rows == 0) return GW_OK;
+  a.ln_y = y;
+  a.ln_gamma = gamma;
+  a.ln_dgamma = dgamma;
+  a.ln_dbeta = dbeta;
+  a.ln_dy = dy;
+  return bwd_chainx3_launch(a, stream);
+}
+
 int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const void* const* chain_w,
                                  const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
                                  float* const* fan_out, void* stream) {

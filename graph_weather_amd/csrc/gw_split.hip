@@ -780,7 +780,31 @@ __global__ void pack_linear_x3_kernel(const float* __restrict__ w, long long sf,
 // rows register-resident between the products (the accumulator of one is the B operand of the next), each d_i stored once for the
 // weight-gradient GEMMs and never read back here.  Single launches of chainx3_kernel<SINGLE> read d_i again for every product
 // that consumes it: 2 - 4 of the ~10 table passes of an MLP's input-gradient chain.  64 rows per workgroup, two per CU.
-template <int RING>
+// sums over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15 = the 16 table rows of a wave at one q) for four values at once;
+// every lane gets the totals.  v_add_f32_dpp from an asm statement (hipcc emits v_mov_b32_dpp + v_add_f32 for the builtin): one
+// VALU instruction per step and value.  A DPP operand written by the previous VALU instruction needs two wait states: the four
+// values alternate, so inside the block every read is three instructions behind its write; s_nop 1 covers the block's entry.
+__device__ __forceinline__ void row16_sum4(f32x4& v) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+#define GW_DPP4(ctrl)                                                  \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" GW_DPP4("quad_perm:[1,0,3,2]") GW_DPP4("quad_perm:[2,3,0,1]") GW_DPP4("row_half_mirror") GW_DPP4("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef GW_DPP4
+  v = f32x4{a, b, c, d};
+}
+constexpr int kBwdLnScratch = 4 * 512 * 4;  // LN: column sums of the four waves (d gamma | d beta), behind the two weight buffers
+
+// LN (gw_mlp_ln_chain_backward): a.d is the gradient at the output of the MLP's LayerNorm.  The kernel reads it together with the
+// saved pre-norm row, walks back through the norm in registers (the row is spread over the 4 q lanes of its column: row sums are
+// two shuffles, as in the forward's LayerNorm), stores the gradient at the norm's input once (the last Linear's weight-gradient
+// GEMM reads it) and feeds it to the first product without reading it back - ln_bwd_kernel + this chain were three + one passes
+// over the table, now three.  d gamma / d beta: per column over the wave's 16 rows by DPP row sums, over the four waves through
+// LDS, one set of atomics per workgroup.
+template <int RING, bool LN>
 __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ldsx[];
   constexpr int NW = 4, HT = 16, HKS = 8;
@@ -796,7 +820,85 @@ __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainA
   int parity = 0;
   issue_bytes<NW>((const char*)a.w[0], FIRST, 0u, lane, wave);
   bf16x8 bh[1][HKS], bl[1][HKS];
-  load_raw<HKS, true, 8>(bh[0], bl[0], a.d + (size_t)c * (size_t)a.d_ld, 256, q);
+  if constexpr (LN) {
+    const float* yrow = a.ln_y + (size_t)c * 256;
+    const float* drow = a.d + (size_t)c * (size_t)a.d_ld;
+    f32x4 yv[HKS][2], gv[HKS][2];  // this lane's 64 columns: 32 s + 16 e + 4 q + r
+#pragma unroll
+    for (int s = 0; s < HKS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        yv[s][e] = ldg4(yrow + 32 * s + 16 * e + 4 * q);
+        gv[s][e] = ldg4(drow + 32 * s + 16 * e + 4 * q);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < HKS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) sum += (yv[s][e].x + yv[s][e].y) + (yv[s][e].z + yv[s][e].w);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / 256.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < HKS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        yv[s][e] = yv[s][e] - mean;
+        var += (yv[s][e].x * yv[s][e].x + yv[s][e].y * yv[s][e].y) + (yv[s][e].z * yv[s][e].z + yv[s][e].w * yv[s][e].w);
+      }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
+    float* red_all = (float*)(ldsx + 2 * buf_bytes(NW));  // [wave][d gamma | d beta][256]
+    float* red = red_all + wave * 512;
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int s = 0; s < HKS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int col = 32 * s + 16 * e + 4 * q;
+        const f32x4 xh = yv[s][e] * rstd;
+        yv[s][e] = xh;
+        const f32x4 dv = valid ? gv[s][e] : f32x4{0.f, 0.f, 0.f, 0.f};  // (rows past the end are copies of the last row)
+        f32x4 pg = dv * xh, pb = dv;
+        row16_sum4(pg);
+        row16_sum4(pb);
+        if (j == 0) {
+          *(f32x4*)(red + col) = pg;
+          *(f32x4*)(red + 256 + col) = pb;
+        }
+        const f32x4 g = gv[s][e] * ldg4(a.ln_gamma + col);
+        gv[s][e] = g;
+        sg += (g.x + g.y) + (g.z + g.w);
+        sgx += (g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w);
+      }
+    sg += __shfl_xor(sg, 16);
+    sg += __shfl_xor(sg, 32);
+    sgx += __shfl_xor(sgx, 16);
+    sgx += __shfl_xor(sgx, 32);
+    const float mg = sg * (1.0f / 256.0f), mgx = sgx * (1.0f / 256.0f);
+    float* orow = a.ln_dy + (size_t)c * 256;
+#pragma unroll
+    for (int s = 0; s < HKS; ++s) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        gv[s][e] = (gv[s][e] - mg - yv[s][e] * mgx) * rstd;
+        if (valid) stg4(orow + 32 * s + 16 * e + 4 * q, gv[s][e]);
+      }
+      split8(gv[s][0], gv[s][1], bh[0][s], bl[0][s]);
+    }
+    lds_barrier();  // the four waves' column sums are in LDS
+    {
+      const int t = threadIdx.x;
+      const float dg = (red_all[t] + red_all[512 + t]) + (red_all[1024 + t] + red_all[1536 + t]);
+      const float db = (red_all[256 + t] + red_all[768 + t]) + (red_all[1280 + t] + red_all[1792 + t]);
+      __hip_atomic_fetch_add((GW_AS1 float*)(a.ln_dgamma + t), dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add((GW_AS1 float*)(a.ln_dbeta + t), db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    load_raw<HKS, true, 8>(bh[0], bl[0], a.d + (size_t)c * (size_t)a.d_ld, 256, q);
+  }
 #pragma unroll 1
   for (int p = 0; p < n_prod; ++p) {
     const bool chain = p < a.n_chain;
@@ -902,11 +1004,18 @@ int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
 }
 
 int bwd_chainx3_launch(const BwdChainArgs& a, void* stream) {
+  const long long grid = (a.n_rows + 63) / 64;
+  if (a.ln_y != nullptr) {
+    constexpr int lds = 2 * buf_bytes(4) + kBwdLnScratch;
+    static DeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chainx3_kernel<kRing, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((bwd_chainx3_kernel<kRing, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+    return check_launch("bwd_chainx3_kernel launch");
+  }
   constexpr int lds = 2 * buf_bytes(4);
   static DeviceOnce once;
-  if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chainx3_kernel<kRing>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  const long long grid = (a.n_rows + 63) / 64;
-  hipLaunchKernelGGL(bwd_chainx3_kernel<kRing>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+  if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chainx3_kernel<kRing, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((bwd_chainx3_kernel<kRing, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("bwd_chainx3_kernel launch");
 }
 

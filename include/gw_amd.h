@@ -31,7 +31,7 @@ extern "C" {
 #define GW_E_UNSUPPORTED (-2)
 #define GW_E_LAUNCH (-3)
 
-#define GW_ABI_VERSION 18
+#define GW_ABI_VERSION 19
 
 /* dtype of the packed weight stream of an MLP (activations in HBM, accumulation, LayerNorm, residuals and segment
  * sums are always fp32). GW_DTYPE_BF16: matrix products on v_mfma_f32_16x16x32_bf16, operands rounded to bf16 (RNE)
@@ -237,6 +237,17 @@ int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t 
 int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const void* const* chain_w,
                                  const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
                                  float* const* fan_out, void* stream);
+
+/* (v19) native_layer_norm_backward + that chain in one launch (what autograd runs behind MLP.forward's LayerNorm,
+ * graph_net_block.py:59-61, under loss.backward()): dn [n_rows, 256 (ld dn_ld)] is the gradient at the OUTPUT of the LayerNorm
+ * (width 256, eps 1e-5, biased variance), y the saved pre-norm rows [n_rows, 256]; dy [n_rows, 256] receives the gradient at the
+ * norm's input (the last Linear's weight-gradient product reads it) and is the chain's d_0 without being read back;
+ * dgamma / dbeta [256] are accumulated (+=).  The chain arguments are those of gw_mlp_chain_backward_bf16x3.
+ * weight_dtype: GW_DTYPE_BF16X3 (fp32 streams: GW_E_UNSUPPORTED - use gw_layernorm_backward + gw_mlp_chain_backward). */
+int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
+                             float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
+                             const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
+                             float* const* fan_out, void* stream);
 
 /* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
  * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(cdll, name), name
     L = _lib.lib()
-    assert L.gw_version() == _lib.ABI_VERSION == 18
+    assert L.gw_version() == _lib.ABI_VERSION == 19
     assert L.gw_packed_floats(256, 0, 256) == 256 * 256
     assert L.gw_packed_floats(78, 0, 128) == 32 * 2 * 256
     assert L.gw_packed_floats(256, 0, 102) == 28 * 4 * 256

@@ -36,7 +36,7 @@ def _golden(golden_dir, name):
 
 def test_extension_is_loaded():
     L = _lib.lib()
-    assert L.gw_version() == 18
+    assert L.gw_version() == 19
     assert torch.cuda.is_available()
 
 

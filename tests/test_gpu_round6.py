@@ -395,3 +395,60 @@ def test_chain_backward_on_split_operands_against_torch_and_the_single_products(
             for s in range(n_fan):
                 single = ops.project_forward([pk[2 + s]], Operand(slast, rows, 256), rows, rows)[0]
                 assert torch.equal(fouts[s], single)
+
+
+@pytest.mark.parametrize("rows", [1, 63, 1000, 4097])
+def test_layernorm_backward_as_the_prologue_of_the_split_chain(rows):
+    """gw_mlp_ln_chain_backward (ABI v19): the gradient at the LayerNorm's input, d gamma, d beta and the chain's rows from ONE launch
+    against gw_layernorm_backward followed by gw_mlp_chain_backward_bf16x3 (same formulas, other summation orders: fp32 rounding)
+    and against torch's fp64 LayerNorm backward; d gamma / d beta are accumulated onto what the buffers hold; rows past the end of a
+    ragged last tile add nothing to them."""
+    from graph_weather_amd import _lib, autograd as ag
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(100 + rows)
+    W2, W1 = (torch.randn(256, 256, generator=g) / 16).to(DEV), (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    W0 = (torch.randn(256, 512, generator=g) / 16).to(DEV)
+    dn = torch.randn(rows, 256, generator=g).to(DEV)
+    y = (torch.randn(rows, 256, generator=g) * 2 + 0.3).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV)
+    h1, h0 = torch.randn(rows, 256, generator=g).relu().to(DEV), torch.randn(rows, 256, generator=g).relu().to(DEV)
+    n = int(L.gw_packed_bytes_bf16x3(256, 0, 256)) // 2
+    blocks = [(W2, 0), (W1, 0), (W0, 0), (W0, 256)]
+    buf = torch.empty(len(blocks) * n, dtype=torch.int16, device=DEV)
+    ops.pack_many(_lib.DTYPE_BF16X3, [(W.data_ptr() + 4 * lo, 1, int(W.shape[1]), 256, 256, buf[i * n:].data_ptr())
+                                      for i, (W, lo) in enumerate(blocks)], [], st)
+    pk = [buf[i * n:(i + 1) * n] for i in range(len(blocks))]
+
+    def run(fused):
+        dg, db = torch.full((256,), 2.0, device=DEV), torch.full((256,), -3.0, device=DEV)
+        outs = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(2)]
+        fouts = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(2)]
+        chain = [(pk[0], h1, outs[0]), (pk[1], h0, outs[1])]
+        fan = [(pk[2], fouts[0]), (pk[3], fouts[1])]
+        if fused:
+            d = torch.full((rows, 256), float("nan"), device=DEV)
+            ag.chain_backward(dn, chain, fan, ln=(y, gamma, dg, db, d))
+        else:
+            d = ag.layernorm_backward(dn, y, gamma, dg, db)
+            ag.chain_backward(d, chain, fan)
+        torch.cuda.synchronize()
+        return [d, dg, db] + outs + fouts
+
+    one, two = run(True), run(False)
+    for a_, b_, name in zip(one, two, ["d", "dgamma", "dbeta", "d1", "dz0", "fan0", "fan1"]):
+        scale = b_.abs().max().item() + 1e-12
+        err = (a_.double() - b_.double()).abs().max().item() / scale
+        assert err <= 2e-5, (name, err)
+    # torch fp64
+    yd = y.double().cpu().requires_grad_(True)
+    gd = gamma.double().cpu().requires_grad_(True)
+    bd = torch.zeros(256, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.layer_norm(yd, (256,), gd, bd, 1e-5).backward(dn.double().cpu())
+    assert (one[0].double().cpu() - yd.grad).abs().max().item() <= 1e-5 * yd.grad.abs().max().item()
+    assert (one[1].double().cpu() - 2.0 - gd.grad).abs().max().item() <= 1e-5 * (gd.grad.abs().max().item() + 2.0)
+    assert (one[2].double().cpu() + 3.0 - bd.grad).abs().max().item() <= 1e-5 * (bd.grad.abs().max().item() + 3.0)
+    with pytest.raises(RuntimeError):  # fp32 streams: two launches
+        nf = int(L.gw_packed_floats(256, 0, 256))
+        ag.chain_backward(dn, [(torch.zeros(nf, device=DEV), h1, one[3])], [], ln=(y, gamma, one[1], one[2], one[0]))
