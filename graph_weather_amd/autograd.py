@@ -153,11 +153,12 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
     return out
 
 
-def chain_backward(d: torch.Tensor, chain, fan, ln=None):
+def chain_backward(d: torch.Tensor, chain, fan, ln=None, colsum=None, fan_add=None):
     """gw_mlp_chain_backward[_bf16x3]: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows
-    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream).  ``ln`` = (pre-norm rows, gamma,
-    dgamma, dbeta, dy): ``d`` is the gradient at the OUTPUT of the MLP's LayerNorm and the launch walks back through the norm
-    first (gw_mlp_ln_chain_backward; split streams only - ``ln_chain_ok``)."""
+    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream).  Extras of gw_mlp_ln_chain_backward
+    (split streams only - the C entry refuses fp32): ``ln`` = (pre-norm rows, gamma, dgamma, dbeta, dy): ``d`` is the gradient at the
+    OUTPUT of the MLP's LayerNorm and the launch walks back through the norm first; ``colsum`` [256] += column sums of the last chain
+    gradient; ``fan_add`` = one tensor or None per fan item, added to that product before it is stored."""
     import ctypes as C
 
     def arr(ptrs):
@@ -170,16 +171,22 @@ def chain_backward(d: torch.Tensor, chain, fan, ln=None):
     if len({t.dtype for t in streams}) > 1:
         raise RuntimeError("graph_weather_amd: chain_backward: packed streams of different dtypes")
     x3 = bool(streams) and streams[0].dtype != torch.float32  # (no product at all: the C entry refuses)
-    items = (len(chain), arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]),
-             arr([c[2].data_ptr() for c in chain]), len(fan), arr([f[0].data_ptr() for f in fan]), arr([f[1].data_ptr() for f in fan]), _st(d))
-    if ln is not None:
-        y, gamma, dgamma, dbeta, dy = ln
+    chain_items = (len(chain), arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]), arr([c[2].data_ptr() for c in chain]))
+    fan_items = (len(fan), arr([f[0].data_ptr() for f in fan]), arr([f[1].data_ptr() for f in fan]))
+    adds = [t for t in (fan_add or []) if t is not None]
+    if ln is not None or colsum is not None or adds:
+        y, gamma, dgamma, dbeta, dy = ln if ln is not None else (None,) * 5
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        if adds and (len(fan_add) != len(fan) or len({int(t.stride(0)) for t in adds}) != 1):
+            raise RuntimeError("graph_weather_amd: chain_backward: fan_add needs one entry per fan item and one leading dimension")
         _lib.check(_L().gw_mlp_ln_chain_backward(_lib.DTYPE_BF16X3 if x3 else _lib.DTYPE_F32, int(d.shape[0]), d.data_ptr(), int(d.stride(0)),
-                                                 y.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), *items),
+                                                 ptr(y), ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(dy), *chain_items, ptr(colsum), *fan_items,
+                                                 arr([0 if t is None else t.data_ptr() for t in fan_add]) if adds else None,
+                                                 int(adds[0].stride(0)) if adds else 0, _st(d)),
                    "gw_mlp_ln_chain_backward")
         return
     fn = _L().gw_mlp_chain_backward_bf16x3 if x3 else _L().gw_mlp_chain_backward
-    _lib.check(fn(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), *items), "gw_mlp_chain_backward")
+    _lib.check(fn(int(d.shape[0]), d.data_ptr(), int(d.stride(0)), *chain_items, *fan_items, _st(d)), "gw_mlp_chain_backward")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -187,7 +194,8 @@ def chain_backward(d: torch.Tensor, chain, fan, ln=None):
 # ---------------------------------------------------------------------------------------------------------------------
 def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
                         gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None, ln_width: int = 0,
-                        fan: Sequence[Tuple[int, int]] = (), fan_out: Optional[dict] = None, bias0_by_caller: bool = False):
+                        fan: Sequence[Tuple[int, int]] = (), fan_out: Optional[dict] = None, bias0_by_caller: bool = False,
+                        bias0_in_chain: bool = False, fan_add: Optional[dict] = None):
     """Backward through [LayerNorm] <- Linear_L <- ReLU <- ... <- Linear_1 <- ReLU, down to the output of Linear_0.
 
     ``weights`` = [W0, b0, W1, b1, ..., WL, bL, (gamma, beta)] (state_dict order of the reference ``MLP.model``);
@@ -198,7 +206,11 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     receives them (from the fused chain launch when the MLP has the kernel shapes, from single products otherwise).
     ``bias0_by_caller``: Linear_0's bias gradient (column sums of dz0) is NOT launched here: the caller's first weight-gradient
     GEMM on dz0 takes it along (``gemm_tn_acc(dz0, ..., colsum=grads[1])``; ``grads[1]`` is handed over zeroed) - one pass over
-    dz0 less per MLP."""
+    dz0 less per MLP.  ``bias0_in_chain``: the caller has no such GEMM (every operand pre-multiplied): the fused chain launch of
+    the split mode sums the columns itself and ``fan_out["bias0_done"]`` is set; otherwise the caller falls back to its own pass.
+    ``fan_add[(lo, hi)]``: rows the caller would add to that input gradient (the same tensor's gradient from another use: a
+    block's residual); the fused launch of the split mode adds them before the store and lists the block in
+    ``fan_out["added"]``."""
     n_lin = (len(weights) - (2 if has_norm else 0)) // 2
     if n_lin < 2:
         raise RuntimeError("MLP needs at least one hidden layer")
@@ -239,12 +251,20 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
         outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in pts]
         fouts = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in fblk]
+        split = pts[0].dtype != torch.float32  # the extras below are the split mode's launch (gw_mlp_ln_chain_backward)
+        adds = [fan_add.get(blk) if (split and fan_add) else None for blk, _ in fblk]
+        in_chain = split and bias0_in_chain and fan_out is not None
         chain_backward(dout if ln_fused else d, [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
                        [(ft, t) for (_, ft), t in zip(fblk, fouts)],
-                       ln=(saved.pre_norm, gamma, grads[-2], grads[-1], d) if ln_fused else None)
+                       ln=(saved.pre_norm, gamma, grads[-2], grads[-1], d) if ln_fused else None,
+                       colsum=zs[1] if in_chain else None, fan_add=adds)
         fused = outs
         for (blk, _), t in zip(fblk, fouts):
             fan_out[blk] = t
+        if fan_out is not None:
+            fan_out["added"] = [blk for (blk, _), t in zip(fblk, adds) if t is not None]
+            if in_chain:
+                fan_out["bias0_done"] = True
     if fused is not None:
         ds = [d] + fused  # ds[i]: gradient at the output of Linear_{n_lin-1-i}
         for i, l in enumerate(range(n_lin - 1, 0, -1)):
@@ -448,6 +468,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
                                 n_dst, agg, e_out, save=save)
         ctx.mlp, ctx.plan, ctx.batch, ctx.specs, ctx.save, ctx.e_res_rows_pb = mlp, plan, batch, specs, save, e_res_rows_pb
         ctx.want_edges = want_edges
+        ctx.same_e = e_in is e_res  # (one tensor in two argument slots: its two gradients may be returned as one)
         ctx.save_for_backward(x_src, x_dst, e_in, *params)
         if want_edges:
             return agg, e_out
@@ -465,11 +486,19 @@ class EdgeUpdateFunction(torch.autograd.Function):
         has_norm = mlp._norm() is not None
         fan = [tuple(mlp.native_splits()[i]) for i, sp in enumerate(specs) if sp.mode == "raw" and ctx.needs_input_grad[5 + i]]
         fo: dict = {}
+        no_gemm_on_dz0 = not any(sp.mode == "raw" for sp in specs)
+        # e' = MLP(..., e) + e with e a per-sample table: the gradient of e from the residual (dn) joins the one from the operand
+        same_e = (ctx.same_e and specs[2].mode == "raw" and specs[2].rows_pb > 0 and ctx.e_res_rows_pb > 0
+                  and ctx.needs_input_grad[7] and ctx.needs_input_grad[8])
+        e_blk = tuple(mlp.native_splits()[2])
         dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim,
-                                     fan=fan, fan_out=fo, bias0_by_caller=True)
+                                     fan=fan, fan_out=fo, bias0_by_caller=True, bias0_in_chain=no_gemm_on_dz0,
+                                     fan_add={e_blk: dn} if same_e else None)
+        e_joined = same_e and e_blk in fo.get("added", ())
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
-        gb0 = grads[1]  # bias gradient of Linear_0: rides on the first weight-gradient GEMM over dz0 (None once taken)
+        # bias gradient of Linear_0: rides on the first weight-gradient GEMM over dz0 (None once taken, or summed by the chain launch)
+        gb0 = None if fo.get("bias0_done") else grads[1]
         tensors = (x_src, x_dst, e_in)
         n_rows_tab = (plan.n_src, plan.n_dst, E)
         dts: List[Optional[torch.Tensor]] = [None, None, None]
@@ -492,7 +521,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
             relu_backward(dz0, None, gb0)
         grads[0] = gW0
         de_res = None
-        if ctx.needs_input_grad[8]:
+        if ctx.needs_input_grad[8] and not e_joined:  # (joined: dts[2] already carries dn - e_in and e_res are one tensor)
             de_res = dn if ctx.e_res_rows_pb > 0 else segment_sum_rows(dn, E, B, 1, E, plan.identity_ptr(), None)
         return (None, None, None, None, None, dts[0], dts[1], dts[2], de_res, None, *grads)
 

@@ -102,6 +102,9 @@ struct BwdChainArgs {
   float* ln_dgamma;       // [256] +=
   float* ln_dbeta;        // [256] +=
   float* ln_dy;           // [n_rows, 256]: gradient at the LayerNorm input (the last Linear's weight-gradient GEMM reads it)
+  const float* add[5];    // fan products: rows added to the product before it is stored (NULL: none), leading dimension add_ld
+  int add_ld;
+  float* colsum;          // [256] += column sums of the last chain gradient (Linear_0's bias gradient); NULL: not wanted
 };
 int bwd_chainx3_launch(const BwdChainArgs& a, void* stream);
 // one matrix item of gw_pack_many into the split stream (strides in floats)

@@ -1035,19 +1035,28 @@ int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t 
 
 int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
                              float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
-                             const float* const* chain_mask, float* const* chain_out, int32_t n_fan, const void* const* fan_w,
-                             float* const* fan_out, void* stream) {
-  if (!y || !gamma || !dgamma || !dbeta || !dy) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: NULL LayerNorm argument");
+                             const float* const* chain_mask, float* const* chain_out, float* dz_colsum, int32_t n_fan,
+                             const void* const* fan_w, float* const* fan_out, const float* const* fan_add, int32_t fan_add_ld,
+                             void* stream) {
+  const bool ln = y != nullptr;
+  if (ln && (!gamma || !dgamma || !dbeta || !dy)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: NULL LayerNorm argument");
   if (weight_dtype != GW_DTYPE_BF16X3)
     return fail(GW_E_UNSUPPORTED, "gw_mlp_ln_chain_backward: split streams (GW_DTYPE_BF16X3) only - fp32: gw_layernorm_backward + gw_mlp_chain_backward");
+  if (dz_colsum && n_chain < 1) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: dz_colsum needs a chain product");
+  if (fan_add && (fan_add_ld < 256 || fan_add_ld % 4 != 0)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: bad fan_add_ld");
   BwdChainArgs a;
   if (int rc = fill_bwd_chain(a, n_rows, dn, dn_ld, n_chain, chain_w, chain_mask, chain_out, n_fan, fan_w, fan_out)) return rc;
   if (n_rows == 0) return GW_OK;
-  a.ln_y = y;
-  a.ln_gamma = gamma;
-  a.ln_dgamma = dgamma;
-  a.ln_dbeta = dbeta;
-  a.ln_dy = dy;
+  if (ln) {
+    a.ln_y = y;
+    a.ln_gamma = gamma;
+    a.ln_dgamma = dgamma;
+    a.ln_dbeta = dbeta;
+    a.ln_dy = dy;
+  }
+  a.colsum = dz_colsum;
+  a.add_ld = fan_add_ld;
+  for (int i = 0; fan_add && i < n_fan; ++i) a.add[n_chain + i] = fan_add[i];
   return bwd_chainx3_launch(a, stream);
 }
 

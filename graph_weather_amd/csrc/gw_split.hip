@@ -796,7 +796,7 @@ __device__ __forceinline__ void row16_sum4(f32x4& v) {
 #undef GW_DPP4
   v = f32x4{a, b, c, d};
 }
-constexpr int kBwdLnScratch = 4 * 512 * 4;  // LN: column sums of the four waves (d gamma | d beta), behind the two weight buffers
+constexpr int kBwdLnScratch = 4 * 512 * 4;  // column sums of the four waves (LN: d gamma | d beta; bias gradient), behind the two weight buffers
 
 // LN (gw_mlp_ln_chain_backward): a.d is the gradient at the output of the MLP's LayerNorm.  The kernel reads it together with the
 // saved pre-norm row, walks back through the norm in registers (the row is spread over the 4 q lanes of its column: row sums are
@@ -917,10 +917,29 @@ __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainA
           if (!(mv[r] > 0.f)) acc[0][t][r] = 0.f;
       }
     }
+    if (!chain && a.add[p] != nullptr) {  // an input gradient that joins another one of the same tensor (an edge row is operand
+      // and residual of its block): added here instead of by a pass of its own over both tables
+      const float* arow = a.add[p] + (size_t)c * (size_t)a.add_ld;
+#pragma unroll
+      for (int t = 0; t < HT; ++t) acc[0][t] += ldg4(arow + 16 * t + 4 * q);
+    }
     if (valid) {
       float* orow = a.out[p] + (size_t)c * 256;
 #pragma unroll
       for (int t = 0; t < HT; ++t) stg4(orow + 16 * t + 4 * q, acc[0][t]);
+    }
+    if (chain && p + 1 == a.n_chain && a.colsum != nullptr) {  // (uniform) Linear_0's bias gradient: column sums of this gradient
+      float* red_all = (float*)(ldsx + 2 * buf_bytes(NW));  // [wave][256]
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        f32x4 v = valid ? acc[0][t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        row16_sum4(v);
+        if (j == 0) *(f32x4*)(red_all + wave * 256 + 16 * t + 4 * q) = v;
+      }
+      lds_barrier();
+      const int t = threadIdx.x;
+      __hip_atomic_fetch_add((GW_AS1 float*)(a.colsum + t), (red_all[t] + red_all[256 + t]) + (red_all[512 + t] + red_all[768 + t]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (chain) {
       acc_to_b<HT, false>(bh[0], bl[0], acc[0]);
@@ -1005,14 +1024,13 @@ int chainx3_launch(int kind, ChainArgs& a, int k_in, int hidden, int n_out, int 
 
 int bwd_chainx3_launch(const BwdChainArgs& a, void* stream) {
   const long long grid = (a.n_rows + 63) / 64;
+  constexpr int lds = 2 * buf_bytes(4) + kBwdLnScratch;
   if (a.ln_y != nullptr) {
-    constexpr int lds = 2 * buf_bytes(4) + kBwdLnScratch;
     static DeviceOnce once;
     if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chainx3_kernel<kRing, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((bwd_chainx3_kernel<kRing, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("bwd_chainx3_kernel launch");
   }
-  constexpr int lds = 2 * buf_bytes(4);
   static DeviceOnce once;
   if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chainx3_kernel<kRing, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((bwd_chainx3_kernel<kRing, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);

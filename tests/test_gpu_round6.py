@@ -452,3 +452,21 @@ def test_layernorm_backward_as_the_prologue_of_the_split_chain(rows):
     with pytest.raises(RuntimeError):  # fp32 streams: two launches
         nf = int(L.gw_packed_floats(256, 0, 256))
         ag.chain_backward(dn, [(torch.zeros(nf, device=DEV), h1, one[3])], [], ln=(y, gamma, one[1], one[2], one[0]))
+    # the other two extras of the launch, with and without the LayerNorm in front: Linear_0's bias gradient (column sums of dz0,
+    # accumulated) and a fan product that another gradient of the same tensor joins before the store
+    addend = torch.randn(rows + 3, 260, generator=g).to(DEV)[:rows, :256]  # (its own leading dimension)
+    for with_ln in (True, False):
+        cs = torch.full((256,), 5.0, device=DEV)
+        outs = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(2)]
+        fouts = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(2)]
+        d_in = dn if with_ln else two[0]
+        ln = (y, gamma, torch.zeros(256, device=DEV), torch.zeros(256, device=DEV), torch.empty(rows, 256, device=DEV)) if with_ln else None
+        ag.chain_backward(d_in, [(pk[0], h1, outs[0]), (pk[1], h0, outs[1])], [(pk[2], fouts[0]), (pk[3], fouts[1])], ln=ln, colsum=cs,
+                          fan_add=[None, addend])
+        torch.cuda.synchronize()
+        ref = one if with_ln else two
+        tol = 2e-5 if with_ln else 0.0  # (without the norm the launch is the plain chain: the same bits)
+        for got, want, name in ((outs[0], ref[3], "d1"), (outs[1], ref[4], "dz0"), (fouts[0], ref[5], "fan0"), (fouts[1], ref[6] + addend, "fan1+add")):
+            assert (got.double() - want.double()).abs().max().item() <= tol * (want.abs().max().item() + 1e-12) + (1e-6 if name == "fan1+add" else 0.0), name
+        want_cs = 5.0 + outs[1].double().sum(0)
+        assert (cs.double() - want_cs).abs().max().item() <= 1e-5 * (want_cs.abs().max().item() + 1.0)
