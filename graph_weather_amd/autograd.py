@@ -155,8 +155,8 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
 
 def chain_backward(d: torch.Tensor, chain, fan, ln=None, colsum=None, fan_add=None):
     """gw_mlp_chain_backward[_bf16x3]: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows
-    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream).  Extras of gw_mlp_ln_chain_backward
-    (split streams only - the C entry refuses fp32): ``ln`` = (pre-norm rows, gamma, dgamma, dbeta, dy): ``d`` is the gradient at the
+    x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream).  Extras of gw_mlp_ln_chain_backward:
+    ``ln`` = (pre-norm rows, gamma, dgamma, dbeta, dy): ``d`` is the gradient at the
     OUTPUT of the MLP's LayerNorm and the launch walks back through the norm first; ``colsum`` [256] += column sums of the last chain
     gradient; ``fan_add`` = one tensor or None per fan item, added to that product before it is stored."""
     import ctypes as C
@@ -206,11 +206,10 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     receives them (from the fused chain launch when the MLP has the kernel shapes, from single products otherwise).
     ``bias0_by_caller``: Linear_0's bias gradient (column sums of dz0) is NOT launched here: the caller's first weight-gradient
     GEMM on dz0 takes it along (``gemm_tn_acc(dz0, ..., colsum=grads[1])``; ``grads[1]`` is handed over zeroed) - one pass over
-    dz0 less per MLP.  ``bias0_in_chain``: the caller has no such GEMM (every operand pre-multiplied): the fused chain launch of
-    the split mode sums the columns itself and ``fan_out["bias0_done"]`` is set; otherwise the caller falls back to its own pass.
+    dz0 less per MLP.  ``bias0_in_chain``: the caller has no such GEMM (every operand pre-multiplied): the fused chain launch
+    sums the columns itself and ``fan_out["bias0_done"]`` is set; MLPs off the kernel shapes leave it to the caller's own pass.
     ``fan_add[(lo, hi)]``: rows the caller would add to that input gradient (the same tensor's gradient from another use: a
-    block's residual); the fused launch of the split mode adds them before the store and lists the block in
-    ``fan_out["added"]``."""
+    block's residual); the fused launch adds them before the store and lists the block in ``fan_out["added"]``."""
     n_lin = (len(weights) - (2 if has_norm else 0)) // 2
     if n_lin < 2:
         raise RuntimeError("MLP needs at least one hidden layer")
@@ -226,7 +225,7 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     n_rows = int(dout.shape[0])
     # Kernel-shaped MLPs (256 wide, at most two Linear layers above layer 0): the whole chain of masked input-gradient products
     # and the requested layer-0 blocks in ONE launch (gw_mlp_chain_backward); the weight-gradient GEMMs read what it stored.
-    # In the split mode the LayerNorm backward in front of the chain is that launch's prologue (gw_mlp_ln_chain_backward).
+    # The LayerNorm backward in front of the chain is that launch's prologue (gw_mlp_ln_chain_backward).
     pts = None
     if (mlp is not None and 2 <= n_lin <= 3 and dout.shape[1] == 256 and n_rows > 0
             and all(saved.hidden[l].shape[1] == 256 and saved.hidden[l].stride(0) == 256 for l in range(n_lin - 1))):
@@ -234,7 +233,7 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         # (fp32 streams: bwd_chain_kernel; split streams of the bf16x3 mode: bwd_chainx3_kernel - the same three-MFMA products)
         if any(p is None for p in pts):
             pts = None
-    ln_fused = (pts is not None and has_norm and pts[0].dtype != torch.float32 and int(gamma.numel()) == 256 and ln_width in (0, 256)
+    ln_fused = (pts is not None and has_norm and int(gamma.numel()) == 256 and ln_width in (0, 256)
                 and saved.pre_norm.shape[1] == 256 and saved.pre_norm.stride(0) == 256)
     if has_norm:
         grads[-2] = zs[-2]
@@ -251,9 +250,8 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         fblk = [(blk, ft) for blk, ft in fblk if ft is not None][:3]  # (other blocks: single products below)
         outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in pts]
         fouts = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in fblk]
-        split = pts[0].dtype != torch.float32  # the extras below are the split mode's launch (gw_mlp_ln_chain_backward)
-        adds = [fan_add.get(blk) if (split and fan_add) else None for blk, _ in fblk]
-        in_chain = split and bias0_in_chain and fan_out is not None
+        adds = [fan_add.get(blk) if fan_add else None for blk, _ in fblk]
+        in_chain = bias0_in_chain and fan_out is not None
         chain_backward(dout if ln_fused else d, [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
                        [(ft, t) for (_, ft), t in zip(fblk, fouts)],
                        ln=(saved.pre_norm, gamma, grads[-2], grads[-1], d) if ln_fused else None,

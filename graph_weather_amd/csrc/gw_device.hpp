@@ -91,6 +91,102 @@ __device__ __forceinline__ void l2_prefetch_stream(const char* const* mats, int 
   }
 }
 
+// ---- LayerNorm backward inside the fused-MLP kernels (the input-gradient chains of csrc/gw_kernels.hip and csrc/gw_split.hip) ----
+// sums over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15 = the 16 table rows of a wave at one q) for four values at once;
+// every lane gets the totals.  v_add_f32_dpp from an asm statement (hipcc emits v_mov_b32_dpp + v_add_f32 for the builtin): one
+// VALU instruction per step and value.  A DPP operand written by the previous VALU instruction needs two wait states: the four
+// values alternate, so inside the block every read is three instructions behind its write; s_nop 1 covers the block's entry.
+__device__ __forceinline__ void row16_sum4(f32x4& v) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+#define GW_DPP4(ctrl)                                                 \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" GW_DPP4("quad_perm:[1,0,3,2]") GW_DPP4("quad_perm:[2,3,0,1]") GW_DPP4("row_half_mirror") GW_DPP4("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef GW_DPP4
+  v = f32x4{a, b, c, d};
+}
+// One table row per lane group: lane (j = lane & 15: row of the wave, q = lane >> 4) holds columns 16 t + 4 q + r of its row, the
+// layout of the kernels' accumulators and operands.  dn: gradient at the output of the LayerNorm (width 256, eps 1e-5, biased
+// variance), y: the saved pre-norm row; g receives the gradient at the norm's input.  Row sums are two shuffles over q (as in the
+// forward's LayerNorm); the column sums of d gamma = dn * xhat and d beta = dn over the wave's 16 rows go through DPP row sums into
+// red[0..255 | 256..511] (LDS, this wave's 512 floats) - rows past the end of the table (valid == false: copies of the last row)
+// add nothing.  After a workgroup barrier ln_backward_flush adds the four waves' sums to dgamma / dbeta (one atomic per column).
+__device__ __forceinline__ void ln_backward_rows16(f32x4 (&g)[16], const float* __restrict__ yrow, const float* __restrict__ drow,
+                                                   const float* __restrict__ gamma, bool valid, int q, int j, float* red) {
+  f32x4 yv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    yv[t] = ldg4(yrow + 16 * t + 4 * q);
+    g[t] = ldg4(drow + 16 * t + 4 * q);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) sum += (yv[t].x + yv[t].y) + (yv[t].z + yv[t].w);
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * (1.0f / 256.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    yv[t] = yv[t] - mean;
+    var += (yv[t].x * yv[t].x + yv[t].y * yv[t].y) + (yv[t].z * yv[t].z + yv[t].w * yv[t].w);
+  }
+  var += __shfl_xor(var, 16);
+  var += __shfl_xor(var, 32);
+  const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int col = 16 * t + 4 * q;
+    const f32x4 xh = yv[t] * rstd;
+    yv[t] = xh;
+    const f32x4 dv = valid ? g[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pg = dv * xh, pb = dv;
+    row16_sum4(pg);
+    row16_sum4(pb);
+    if (j == 0) {
+      *(f32x4*)(red + col) = pg;
+      *(f32x4*)(red + 256 + col) = pb;
+    }
+    const f32x4 gg = g[t] * ldg4(gamma + col);
+    g[t] = gg;
+    sg += (gg.x + gg.y) + (gg.z + gg.w);
+    sgx += (gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w);
+  }
+  sg += __shfl_xor(sg, 16);
+  sg += __shfl_xor(sg, 32);
+  sgx += __shfl_xor(sgx, 16);
+  sgx += __shfl_xor(sgx, 32);
+  const float mg = sg * (1.0f / 256.0f), mgx = sgx * (1.0f / 256.0f);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) g[t] = (g[t] - mg - yv[t] * mgx) * rstd;
+}
+// red_all: [4 waves][d gamma | d beta][256] floats of LDS; tid = threadIdx.x of a 256-thread workgroup
+__device__ __forceinline__ void ln_backward_flush(const float* red_all, float* dgamma, float* dbeta, int tid) {
+  const float dg = (red_all[tid] + red_all[512 + tid]) + (red_all[1024 + tid] + red_all[1536 + tid]);
+  const float db = (red_all[256 + tid] + red_all[768 + tid]) + (red_all[1280 + tid] + red_all[1792 + tid]);
+  __hip_atomic_fetch_add((GW_AS1 float*)(dgamma + tid), dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add((GW_AS1 float*)(dbeta + tid), db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Column sums of a row-per-lane-group tile (same layout) over the workgroup's 64 rows, added to out[256]: red_all = [4 waves][256]
+// floats of LDS; `barrier` is the caller's workgroup barrier.
+template <typename Barrier>
+__device__ __forceinline__ void colsum_rows64(const f32x4 (&v)[16], bool valid, int q, int j, int wave, int tid, float* red_all,
+                                              float* out, Barrier barrier) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    f32x4 s = valid ? v[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    row16_sum4(s);
+    if (j == 0) *(f32x4*)(red_all + wave * 256 + 16 * t + 4 * q) = s;
+  }
+  barrier();
+  __hip_atomic_fetch_add((GW_AS1 float*)(out + tid), (red_all[tid] + red_all[256 + tid]) + (red_all[512 + tid] + red_all[768 + tid]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Each wave DMAs its share of `nfloats` (multiple of 256) from the packed weight stream into an LDS buffer.
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ g, int nfloats, float* ldsbuf, int lane, int wave) {
   const int npieces = nfloats >> 8;

@@ -666,6 +666,12 @@ __global__ void pad_vector_kernel(const float* __restrict__ v, int n, int npad, 
 // gradients of layer 1, d_n . W1[:, block], for up to 3 operand blocks.  The forward kernel's structure: the accumulator of one
 // product is the B operand of the next, weights stream through LDS (double buffered DMA, two workgroups per CU); every d_i is
 // stored once (the weight-gradient GEMMs read it) and never read back by this chain.
+// LN (gw_mlp_ln_chain_backward): a.d is the gradient at the output of the MLP's LayerNorm; the kernel walks back through the norm
+// in registers first (gw_device.hpp: ln_backward_rows16), stores the gradient at the norm's input once and feeds it to the first
+// product.  The extras of that entry point: column sums of the last chain gradient (Linear_0's bias gradient) and rows added to a
+// fan product before it is stored.  8 KiB of LDS behind the two weight buffers hold the four waves' column sums.
+constexpr int kBwdScratchBytes = 4 * 512 * 4;
+template <bool LN, bool EXTRA>
 __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HS = 64, HSTEPF = 1024;  // K-steps / floats per step of a 256 -> 256 product
@@ -677,15 +683,31 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
   const bool valid = c_raw < a.n_rows;
   const long long c = valid ? c_raw : a.n_rows - 1;
   const int n_prod = a.n_chain + a.n_fan;
+  float* red_all = lds + 2 * kLdsBufFloats;
+  auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   int parity = 0;
   issue_chunk((const float*)a.w[0], kChunkSteps * HSTEPF, lds, lane, wave);
   float x[HS];
-  load_operand<HS, true>(x, a.d + (size_t)c * (size_t)a.d_ld, 256, q);
+  if constexpr (LN) {
+    f32x4 g[16];
+    ln_backward_rows16(g, a.ln_y + (size_t)c * 256, a.d + (size_t)c * (size_t)a.d_ld, a.ln_gamma, valid, q, j, red_all + wave * 512);
+    float* orow = a.ln_dy + (size_t)c * 256;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if (valid) stg4(orow + 16 * t + 4 * q, g[t]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[4 * t + r] = g[t][r];
+    }
+    barrier();  // the four waves' column sums are in LDS
+    ln_backward_flush(red_all, a.ln_dgamma, a.ln_dbeta, threadIdx.x);
+  } else {
+    load_operand<HS, true>(x, a.d + (size_t)c * (size_t)a.d_ld, 256, q);
+  }
 #pragma unroll 1
   for (int p = 0; p < n_prod; ++p) {
     const bool chain = p < a.n_chain;
     f32x4 mv[16];
-    if (chain) {  // the ReLU output that gates this product: fetched underneath its MFMAs
+    if (chain && !EXTRA) {  // the ReLU output that gates this product: fetched underneath its MFMAs
       const float* mrow = a.mask[p] + (size_t)c * 256;
 #pragma unroll
       for (int t = 0; t < 16; ++t) mv[t] = ldg4(mrow + 16 * t + 4 * q);
@@ -697,6 +719,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
     mma_pass<HS, 16, false>(acc, x, (const float*)a.w[p], nx, nx ? kChunkSteps * HSTEPF : 0, lds, parity, lane, wave, nullptr, false, nullptr,
                             false, q);
     if (chain) {
+      if (EXTRA) {  // (the instantiation with the extras has no registers for the prefetch: the mask is fetched behind the pass)
+        const float* mrow = a.mask[p] + (size_t)c * 256;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mv[t] = ldg4(mrow + 16 * t + 4 * q);
+      }
 #pragma unroll
       for (int t = 0; t < 16; ++t)
 #pragma unroll
@@ -705,13 +732,35 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
           acc[t][r] = v;
           x[4 * t + r] = v;  // (accumulator layout == B-operand layout of the next product)
         }
+    } else if (EXTRA && a.add[p] != nullptr) {  // rows that join this input gradient (gw_mlp_ln_chain_backward: fan_add)
+      const float* arow = a.add[p] + (size_t)c * (size_t)a.add_ld;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] += ldg4(arow + 16 * t + 4 * q);
     }
     if (valid) {
       float* orow = a.out[p] + (size_t)c * 256;
 #pragma unroll
       for (int t = 0; t < 16; ++t) stg4(orow + 16 * t + 4 * q, acc[t]);
     }
+    if (EXTRA && chain && p + 1 == a.n_chain && a.colsum != nullptr)  // (uniform) Linear_0's bias gradient: column sums of this gradient
+      colsum_rows64(acc, valid, q, j, wave, threadIdx.x, red_all, a.colsum, barrier);
   }
+}
+
+template <bool LN, bool EXTRA>
+int bwd_chain_launch_as(const BwdChainArgs& a, void* stream) {
+  constexpr int ldsb = kLdsBytes + kBwdScratchBytes;
+  const long long grid = (a.n_rows + kColsPerWG - 1) / kColsPerWG;
+  static DeviceOnce once;  // per instantiation and device
+  if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chain_kernel<LN, EXTRA>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+  hipLaunchKernelGGL((bwd_chain_kernel<LN, EXTRA>), dim3((unsigned)grid), dim3(kThreads), ldsb, (hipStream_t)stream, a);
+  return check_launch("bwd_chain_kernel launch");
+}
+int bwd_chain_launch(const BwdChainArgs& a, void* stream) {
+  bool extra = a.colsum != nullptr;
+  for (int i = 0; i < 5; ++i) extra = extra || a.add[i] != nullptr;
+  if (a.ln_y != nullptr) return extra ? bwd_chain_launch_as<true, true>(a, stream) : bwd_chain_launch_as<true, false>(a, stream);
+  return extra ? bwd_chain_launch_as<false, true>(a, stream) : bwd_chain_launch_as<false, false>(a, stream);
 }
 
 // ---- gw_pack_many: all slices / vectors of an MLP in one launch (blockIdx.y = item; the last y packs the vectors) --------
@@ -1026,11 +1075,7 @@ int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t 
                               fan_out))
     return rc;
   if (n_rows == 0) return GW_OK;
-  static DeviceOnce once;
-  if (once.first()) (void)hipFuncSetAttribute((const void*)bwd_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  const long long grid = (n_rows + kColsPerWG - 1) / kColsPerWG;
-  hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
-  return check_launch("bwd_chain_kernel launch");
+  return bwd_chain_launch(a, stream);
 }
 
 int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
@@ -1040,8 +1085,8 @@ int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* 
                              void* stream) {
   const bool ln = y != nullptr;
   if (ln && (!gamma || !dgamma || !dbeta || !dy)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: NULL LayerNorm argument");
-  if (weight_dtype != GW_DTYPE_BF16X3)
-    return fail(GW_E_UNSUPPORTED, "gw_mlp_ln_chain_backward: split streams (GW_DTYPE_BF16X3) only - fp32: gw_layernorm_backward + gw_mlp_chain_backward");
+  if (weight_dtype != GW_DTYPE_BF16X3 && weight_dtype != GW_DTYPE_F32)
+    return fail(GW_E_UNSUPPORTED, "gw_mlp_ln_chain_backward: fp32 or split (GW_DTYPE_BF16X3) streams");
   if (dz_colsum && n_chain < 1) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: dz_colsum needs a chain product");
   if (fan_add && (fan_add_ld < 256 || fan_add_ld % 4 != 0)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: bad fan_add_ld");
   BwdChainArgs a;
@@ -1057,7 +1102,7 @@ int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* 
   a.colsum = dz_colsum;
   a.add_ld = fan_add_ld;
   for (int i = 0; fan_add && i < n_fan; ++i) a.add[n_chain + i] = fan_add[i];
-  return bwd_chainx3_launch(a, stream);
+  return weight_dtype == GW_DTYPE_BF16X3 ? bwd_chainx3_launch(a, stream) : bwd_chain_launch(a, stream);
 }
 
 int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, int32_t n_chain, const void* const* chain_w,

@@ -780,22 +780,6 @@ __global__ void pack_linear_x3_kernel(const float* __restrict__ w, long long sf,
 // rows register-resident between the products (the accumulator of one is the B operand of the next), each d_i stored once for the
 // weight-gradient GEMMs and never read back here.  Single launches of chainx3_kernel<SINGLE> read d_i again for every product
 // that consumes it: 2 - 4 of the ~10 table passes of an MLP's input-gradient chain.  64 rows per workgroup, two per CU.
-// sums over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15 = the 16 table rows of a wave at one q) for four values at once;
-// every lane gets the totals.  v_add_f32_dpp from an asm statement (hipcc emits v_mov_b32_dpp + v_add_f32 for the builtin): one
-// VALU instruction per step and value.  A DPP operand written by the previous VALU instruction needs two wait states: the four
-// values alternate, so inside the block every read is three instructions behind its write; s_nop 1 covers the block's entry.
-__device__ __forceinline__ void row16_sum4(f32x4& v) {
-  float a = v.x, b = v.y, c = v.z, d = v.w;
-#define GW_DPP4(ctrl)                                                  \
-  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"  \
-  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"  \
-  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"  \
-  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
-  asm volatile("s_nop 1\n\t" GW_DPP4("quad_perm:[1,0,3,2]") GW_DPP4("quad_perm:[2,3,0,1]") GW_DPP4("row_half_mirror") GW_DPP4("row_mirror")
-               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-#undef GW_DPP4
-  v = f32x4{a, b, c, d};
-}
 constexpr int kBwdLnScratch = 4 * 512 * 4;  // column sums of the four waves (LN: d gamma | d beta; bias gradient), behind the two weight buffers
 
 // LN (gw_mlp_ln_chain_backward): a.d is the gradient at the output of the MLP's LayerNorm.  The kernel reads it together with the
@@ -821,81 +805,20 @@ __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainA
   issue_bytes<NW>((const char*)a.w[0], FIRST, 0u, lane, wave);
   bf16x8 bh[1][HKS], bl[1][HKS];
   if constexpr (LN) {
-    const float* yrow = a.ln_y + (size_t)c * 256;
-    const float* drow = a.d + (size_t)c * (size_t)a.d_ld;
-    f32x4 yv[HKS][2], gv[HKS][2];  // this lane's 64 columns: 32 s + 16 e + 4 q + r
-#pragma unroll
-    for (int s = 0; s < HKS; ++s)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        yv[s][e] = ldg4(yrow + 32 * s + 16 * e + 4 * q);
-        gv[s][e] = ldg4(drow + 32 * s + 16 * e + 4 * q);
-      }
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < HKS; ++s)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) sum += (yv[s][e].x + yv[s][e].y) + (yv[s][e].z + yv[s][e].w);
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / 256.0f);
-    float var = 0.f;
-#pragma unroll
-    for (int s = 0; s < HKS; ++s)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        yv[s][e] = yv[s][e] - mean;
-        var += (yv[s][e].x * yv[s][e].x + yv[s][e].y * yv[s][e].y) + (yv[s][e].z * yv[s][e].z + yv[s][e].w * yv[s][e].w);
-      }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
     float* red_all = (float*)(ldsx + 2 * buf_bytes(NW));  // [wave][d gamma | d beta][256]
-    float* red = red_all + wave * 512;
-    float sg = 0.f, sgx = 0.f;
-#pragma unroll
-    for (int s = 0; s < HKS; ++s)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int col = 32 * s + 16 * e + 4 * q;
-        const f32x4 xh = yv[s][e] * rstd;
-        yv[s][e] = xh;
-        const f32x4 dv = valid ? gv[s][e] : f32x4{0.f, 0.f, 0.f, 0.f};  // (rows past the end are copies of the last row)
-        f32x4 pg = dv * xh, pb = dv;
-        row16_sum4(pg);
-        row16_sum4(pb);
-        if (j == 0) {
-          *(f32x4*)(red + col) = pg;
-          *(f32x4*)(red + 256 + col) = pb;
-        }
-        const f32x4 g = gv[s][e] * ldg4(a.ln_gamma + col);
-        gv[s][e] = g;
-        sg += (g.x + g.y) + (g.z + g.w);
-        sgx += (g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w);
-      }
-    sg += __shfl_xor(sg, 16);
-    sg += __shfl_xor(sg, 32);
-    sgx += __shfl_xor(sgx, 16);
-    sgx += __shfl_xor(sgx, 32);
-    const float mg = sg * (1.0f / 256.0f), mgx = sgx * (1.0f / 256.0f);
+    f32x4 g[HT];  // this lane's 64 columns of its row: 16 t + 4 q + r
+    ln_backward_rows16(g, a.ln_y + (size_t)c * 256, a.d + (size_t)c * (size_t)a.d_ld, a.ln_gamma, valid, q, j, red_all + wave * 512);
     float* orow = a.ln_dy + (size_t)c * 256;
 #pragma unroll
     for (int s = 0; s < HKS; ++s) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        gv[s][e] = (gv[s][e] - mg - yv[s][e] * mgx) * rstd;
-        if (valid) stg4(orow + 32 * s + 16 * e + 4 * q, gv[s][e]);
+      if (valid) {
+        stg4(orow + 32 * s + 4 * q, g[2 * s]);
+        stg4(orow + 32 * s + 16 + 4 * q, g[2 * s + 1]);
       }
-      split8(gv[s][0], gv[s][1], bh[0][s], bl[0][s]);
+      split8(g[2 * s], g[2 * s + 1], bh[0][s], bl[0][s]);
     }
     lds_barrier();  // the four waves' column sums are in LDS
-    {
-      const int t = threadIdx.x;
-      const float dg = (red_all[t] + red_all[512 + t]) + (red_all[1024 + t] + red_all[1536 + t]);
-      const float db = (red_all[256 + t] + red_all[768 + t]) + (red_all[1280 + t] + red_all[1792 + t]);
-      __hip_atomic_fetch_add((GW_AS1 float*)(a.ln_dgamma + t), dg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add((GW_AS1 float*)(a.ln_dbeta + t), db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    ln_backward_flush(red_all, a.ln_dgamma, a.ln_dbeta, threadIdx.x);
   } else {
     load_raw<HKS, true, 8>(bh[0], bl[0], a.d + (size_t)c * (size_t)a.d_ld, 256, q);
   }
@@ -928,19 +851,8 @@ __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainA
 #pragma unroll
       for (int t = 0; t < HT; ++t) stg4(orow + 16 * t + 4 * q, acc[0][t]);
     }
-    if (chain && p + 1 == a.n_chain && a.colsum != nullptr) {  // (uniform) Linear_0's bias gradient: column sums of this gradient
-      float* red_all = (float*)(ldsx + 2 * buf_bytes(NW));  // [wave][256]
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        f32x4 v = valid ? acc[0][t] : f32x4{0.f, 0.f, 0.f, 0.f};
-        row16_sum4(v);
-        if (j == 0) *(f32x4*)(red_all + wave * 256 + 16 * t + 4 * q) = v;
-      }
-      lds_barrier();
-      const int t = threadIdx.x;
-      __hip_atomic_fetch_add((GW_AS1 float*)(a.colsum + t), (red_all[t] + red_all[256 + t]) + (red_all[512 + t] + red_all[768 + t]),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (chain && p + 1 == a.n_chain && a.colsum != nullptr)  // (uniform) Linear_0's bias gradient: column sums of this gradient
+      colsum_rows64(acc[0], valid, q, j, wave, threadIdx.x, (float*)(ldsx + 2 * buf_bytes(NW)), a.colsum, [] { lds_barrier(); });
     if (chain) {
       acc_to_b<HT, false>(bh[0], bl[0], acc[0]);
       __builtin_amdgcn_sched_barrier(0);

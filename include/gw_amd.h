@@ -248,7 +248,7 @@ int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, i
  * (addmm backward's sum over rows); fan_add[s] (array or entries may be NULL; rows [n_rows, 256 (ld fan_add_ld)]) is added
  * to fan_out[s] before it is stored - the gradient of a tensor that is both an operand of the first Linear and the block's
  * residual (EdgeProcessor: graph_net_block.py:131-137) arrives as one row.
- * weight_dtype: GW_DTYPE_BF16X3 (fp32 streams: GW_E_UNSUPPORTED - use gw_layernorm_backward + gw_mlp_chain_backward). */
+ * weight_dtype: GW_DTYPE_F32 or GW_DTYPE_BF16X3 - the dtype of the packed streams. */
 int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
                              float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
                              const float* const* chain_mask, float* const* chain_out, float* dz_colsum, int32_t n_fan,

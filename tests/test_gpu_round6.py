@@ -397,10 +397,11 @@ def test_chain_backward_on_split_operands_against_torch_and_the_single_products(
                 assert torch.equal(fouts[s], single)
 
 
+@pytest.mark.parametrize("x3", [True, False])
 @pytest.mark.parametrize("rows", [1, 63, 1000, 4097])
-def test_layernorm_backward_as_the_prologue_of_the_split_chain(rows):
+def test_layernorm_backward_as_the_prologue_of_the_input_gradient_chain(rows, x3):
     """gw_mlp_ln_chain_backward (ABI v19): the gradient at the LayerNorm's input, d gamma, d beta and the chain's rows from ONE launch
-    against gw_layernorm_backward followed by gw_mlp_chain_backward_bf16x3 (same formulas, other summation orders: fp32 rounding)
+    (split and fp32 streams) against gw_layernorm_backward followed by gw_mlp_chain_backward[_bf16x3] (same formulas, other summation orders: fp32 rounding)
     and against torch's fp64 LayerNorm backward; d gamma / d beta are accumulated onto what the buffers hold; rows past the end of a
     ragged last tile add nothing to them."""
     from graph_weather_amd import _lib, autograd as ag
@@ -414,11 +415,11 @@ def test_layernorm_backward_as_the_prologue_of_the_split_chain(rows):
     y = (torch.randn(rows, 256, generator=g) * 2 + 0.3).to(DEV)
     gamma = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV)
     h1, h0 = torch.randn(rows, 256, generator=g).relu().to(DEV), torch.randn(rows, 256, generator=g).relu().to(DEV)
-    n = int(L.gw_packed_bytes_bf16x3(256, 0, 256)) // 2
+    n = int(L.gw_packed_bytes_bf16x3(256, 0, 256)) // 2 if x3 else int(L.gw_packed_floats(256, 0, 256))
     blocks = [(W2, 0), (W1, 0), (W0, 0), (W0, 256)]
-    buf = torch.empty(len(blocks) * n, dtype=torch.int16, device=DEV)
-    ops.pack_many(_lib.DTYPE_BF16X3, [(W.data_ptr() + 4 * lo, 1, int(W.shape[1]), 256, 256, buf[i * n:].data_ptr())
-                                      for i, (W, lo) in enumerate(blocks)], [], st)
+    buf = torch.empty(len(blocks) * n, dtype=torch.int16 if x3 else torch.float32, device=DEV)
+    ops.pack_many(_lib.DTYPE_BF16X3 if x3 else _lib.DTYPE_F32, [(W.data_ptr() + 4 * lo, 1, int(W.shape[1]), 256, 256, buf[i * n:].data_ptr())
+                                                                for i, (W, lo) in enumerate(blocks)], [], st)
     pk = [buf[i * n:(i + 1) * n] for i in range(len(blocks))]
 
     def run(fused):
@@ -449,9 +450,8 @@ def test_layernorm_backward_as_the_prologue_of_the_split_chain(rows):
     assert (one[0].double().cpu() - yd.grad).abs().max().item() <= 1e-5 * yd.grad.abs().max().item()
     assert (one[1].double().cpu() - 2.0 - gd.grad).abs().max().item() <= 1e-5 * (gd.grad.abs().max().item() + 2.0)
     assert (one[2].double().cpu() + 3.0 - bd.grad).abs().max().item() <= 1e-5 * (bd.grad.abs().max().item() + 3.0)
-    with pytest.raises(RuntimeError):  # fp32 streams: two launches
-        nf = int(L.gw_packed_floats(256, 0, 256))
-        ag.chain_backward(dn, [(torch.zeros(nf, device=DEV), h1, one[3])], [], ln=(y, gamma, one[1], one[2], one[0]))
+    with pytest.raises(RuntimeError):  # a LayerNorm without its buffers
+        ag.chain_backward(dn, [(pk[0], h1, one[3])], [], ln=(y, gamma, None, one[2], one[0]))
     # the other two extras of the launch, with and without the LayerNorm in front: Linear_0's bias gradient (column sums of dz0,
     # accumulated) and a fan product that another gradient of the same tensor joins before the store
     addend = torch.randn(rows + 3, 260, generator=g).to(DEV)[:rows, :256]  # (its own leading dimension)

@@ -258,7 +258,8 @@ def test_row_wise_kernels_keep_the_register_budget_of_two_workgroups_per_cu(tmp_
         assert vgpr <= 256 and scratch == 0, (name, vgpr, scratch)
     k32 = kernels("gw_kernels.hip")
     bwd = [v for n, v in k32.items() if "bwd_chain_kernel" in n]
-    assert len(bwd) == 1 and bwd[0][0] <= 256 and bwd[0][1] == 0, bwd
+    # (with / without the LayerNorm-backward prologue) x (with / without bias column sums and joined rows): ABI v19
+    assert len(bwd) == 4 and all(v <= 256 and sc == 0 for v, sc in bwd), bwd
     chains = {n: v for n, v in k32.items() if "chain_kernel" in n and "bwd" not in n}
     assert len(chains) >= 8
     for name, (vgpr, scratch) in chains.items():
