@@ -31,4 +31,4 @@ for rows in (907200, 453600, 164648, 82324, 23528, 11764):
     gb = torch.zeros(256, device=dev)
     t = timeit(lambda: gemm_tn_acc(d, h, gw_, colsum=gb, x3=True))
     t32 = timeit(lambda: gemm_tn_acc(d, h, gw_, colsum=gb, x3=False))
-    print(f"rows {rows:7d}: x3 {t*1e3:7.1f} us  {2 * rows * 1024 / t / 1e9:6.2f} TB/s  {3 * 2.0 * rows * 65536 / t / 1e12:6.1f} TF/s (3 MFMA products) | fp32 {t32*1e3:7.1f} us")
+    print(f"rows {rows:7d}: x3 {t*1e3:7.1f} us  {2 * rows * 1024 / (t * 1e-3) / 1e12:6.2f} TB/s  {3 * 2.0 * rows * 65536 / (t * 1e-3) / 1e12:6.1f} TF/s (3 MFMA products) | fp32 {t32*1e3:7.1f} us")
