@@ -390,36 +390,55 @@ def recompute(fn, inputs: Sequence[torch.Tensor], module) -> Tuple[torch.Tensor,
     return RecomputeFunction.apply(fn, len(inputs), params, *inputs, *params)
 
 
+def _input_grad_joined(mlp, d: torch.Tensor, W: torch.Tensor, lo: int, hi: int, addend: Optional[torch.Tensor]) -> torch.Tensor:
+    """d @ W[:, lo:hi] + addend: another gradient of the same tensor joins the product before it is stored (the chain launch's
+    ``fan_add``; the addend may be the buffer of an earlier product - every lane reads its values before it writes them)."""
+    if addend is None:
+        return input_grad(mlp, 0, d, W, lo, hi)
+    pt = _packed_transposed(mlp, 0, W, lo, hi) if (d.shape[1] == 256 and d.stride(0) % 4 == 0 and d.shape[0] > 0) else None
+    if (pt is not None and addend.shape == d.shape and addend.stride(1) == 1 and addend.stride(0) % 4 == 0 and addend.stride(0) >= 256
+            and addend.dtype == torch.float32):
+        out = torch.empty((int(d.shape[0]), 256), dtype=torch.float32, device=d.device)
+        chain_backward(d, [], [(pt, out)], fan_add=[addend])
+        return out
+    return input_grad(mlp, 0, d, W, lo, hi).add_(addend)
+
+
 class ProjectFunction(torch.autograd.Function):
-    """out_s = x @ W[:, lo_s:hi_s]^T for slices of a layer-1 weight (the layer-1 split of graph_net_block.py:131-134)."""
+    """out_s = x @ W[:, lo_s:hi_s]^T for slices of a layer-1 weight (the layer-1 split of graph_net_block.py:131-134).
+    ``passthrough``: x itself is one more output - for a caller that also uses x directly (the residual ``e' = MLP(..) + e`` of an
+    encoder / decoder block, whose edge embedding e enters the edge MLP as the product We.e): the gradients of both uses arrive in
+    ONE backward call and leave it as one tensor, instead of autograd adding two 464 MB tables (1 degree) in a pass of its own."""
 
     @staticmethod
-    def forward(ctx, mlp, slice_ids, x, n_rows, rows_per_batch, W):
+    def forward(ctx, mlp, slice_ids, passthrough, x, n_rows, rows_per_batch, W):
         pm = mlp.packed()
         outs = ops.project_forward([pm.w1[s] for s in slice_ids], Operand(x, rows_per_batch, 256), n_rows, rows_per_batch)
-        ctx.mlp, ctx.slice_ids = mlp, slice_ids
+        ctx.mlp, ctx.slice_ids, ctx.passthrough = mlp, slice_ids, passthrough
         ctx.save_for_backward(x, W)
-        return tuple(outs)
+        return (*outs, x) if passthrough else tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         x, W = ctx.saved_tensors
         gW = torch.zeros_like(W)
-        dx = None
+        dx = douts[len(ctx.slice_ids)] if ctx.passthrough else None  # gradient of the direct use of x
+        if dx is not None and not ctx.needs_input_grad[3]:
+            dx = None
         for s, d in zip(ctx.slice_ids, douts):
             if d is None:
                 continue
             lo, hi = ctx.mlp.native_splits()[s]
             d = d.contiguous()
             gemm_tn_acc(d, x, gW, c_col0=lo, x3=_x3(ctx.mlp))  # dW[:, lo:hi] += d^T x
-            if ctx.needs_input_grad[2]:
-                part = input_grad(ctx.mlp, 0, d, W, lo, hi)
-                dx = part if dx is None else dx.add_(part)
-        return None, None, dx, None, None, gW
+            if ctx.needs_input_grad[3]:
+                dx = _input_grad_joined(ctx.mlp, d, W, lo, hi, dx)
+        return None, None, None, dx, None, None, gW
 
 
-def project(mlp, slice_ids: Sequence[int], x: torch.Tensor, n_rows: int, rows_per_batch: int) -> Tuple[torch.Tensor, ...]:
-    return ProjectFunction.apply(mlp, tuple(slice_ids), x, n_rows, rows_per_batch, mlp.native_params()[0])
+def project(mlp, slice_ids: Sequence[int], x: torch.Tensor, n_rows: int, rows_per_batch: int, passthrough: bool = False) -> Tuple[torch.Tensor, ...]:
+    """-> the products; with ``passthrough`` followed by x as an output of the same autograd node (see ProjectFunction)."""
+    return ProjectFunction.apply(mlp, tuple(slice_ids), bool(passthrough), x, n_rows, rows_per_batch, mlp.native_params()[0])
 
 
 # ---------------------------------------------------------------------------------------------------------------------

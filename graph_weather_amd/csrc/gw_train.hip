@@ -832,11 +832,14 @@ int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, i
     // slab of rows per block: enough blocks to fill the chip, each at least 256 rows deep.  Every slab ends in 64 K atomics per
     // 128 x 128 tile (0.4 T atomics/s measured: 12 of the 25 us at the 11 764 mesh-node rows, 33 of 83 us at a processor block's
     // 82 324 edge rows), so the split kernel - whose loads run two stages ahead and need fewer workgroups to cover the latency -
-    // aims at one resident round (512 workgroups, two per CU) without the 4096-row cap: 83 -> 62 us at 82 324 rows, the same
-    // time at 907 200 and at 11 764 (scripts/probes/gemm_tn_x3_probe.py)
+    // aims at one resident round (512 workgroups, two per CU) for the shorter tables: 83 -> 62 us at 82 324 rows, the same time at
+    // 11 764 (scripts/probes/gemm_tn_x3_probe.py, scripts/gpu_ab_gemm_tn_x3.sh)
     const int tiles = (int)((m + 127) / 128) * ((n + 127) / 128);
     static const int tn_target = GW_TUNE("GW_TN_TARGET", 0), tn_min = GW_TUNE("GW_TN_MIN", 256), tn_cap = GW_TUNE("GW_TN_CAP", 0);
-    const int target = tn_target > 0 ? tn_target : (x3 ? 512 : 1024), cap = tn_cap > 0 ? tn_cap : (x3 ? 16384 : 4096);
+    // (one round only while the slabs of two rounds would be short: at 453 600 rows two rounds of 1 792-row slabs - workgroups out
+    // of step, the atomics of one under the loads of the next - measured 267 us against 310 us for one round of 3 584-row slabs)
+    const bool one_round = x3 && k * tiles < (int64_t)1024 * 1024;
+    const int target = tn_target > 0 ? tn_target : (one_round ? 512 : 1024), cap = tn_cap > 0 ? tn_cap : (x3 ? 16384 : 4096);
     int64_t k_slab = (k * tiles + target - 1) / target;
     k_slab = ((k_slab + 63) / 64) * 64;
     if (k_slab < tn_min) k_slab = tn_min;

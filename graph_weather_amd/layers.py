@@ -805,7 +805,7 @@ class Encoder(nn.Module):
         e = self.encoder_edge_embedding(enc_plan)
         blk = self.graph_processor.blocks[0]
         _check_native_dims(*self.graph_processor._dims)
-        pd_xm, pe, px_xm = self._static_projections(blk, xm, e)
+        pd_xm, pe, px_xm, e = self._static_projections(blk, xm, e)
         x_src, e_res = Feed(xg, G, "raw"), e
         seg = None
         if team or x3:
@@ -869,22 +869,25 @@ class Encoder(nn.Module):
 
     def _static_projections(self, blk, xm: torch.Tensor, e: torch.Tensor):
         """Batch-independent layer-1 products of the encoder block (mesh rows are the same for every sample,
-        encoder.py:199-204): Wd.xm (edge MLP), We.e (edge MLP), Wx.xm (node MLP) - cached per weight version."""
+        encoder.py:199-204): Wd.xm (edge MLP), We.e (edge MLP), Wx.xm (node MLP) - cached per weight version; and e itself (under
+        autograd: as an output of the node that made We.e)."""
         ps = list(self.parameters())
 
         def make():
             M, G = int(xm.shape[0]), int(e.shape[0])
             if _autograd_on(self):
                 pd_xm = ag.project(blk.edge_model.edge_mlp, (1,), xm, M, M)[0]
-                pe = ag.project(blk.edge_model.edge_mlp, (2,), e, G, G)[0]
+                # (e comes back as an output of the same autograd node: it is also the block's residual, and the two gradients of
+                # the [E, 256] table then leave that node as one - autograd.ProjectFunction)
+                pe, e_same = ag.project(blk.edge_model.edge_mlp, (2,), e, G, G, passthrough=True)
                 px_xm = ag.project(blk.node_model.node_mlp, (0,), xm, M, M)[0]
-                return pd_xm, pe, px_xm
+                return pd_xm, pe, px_xm, e_same
             pm_e = blk.edge_model.edge_mlp.packed()
             pm_n = blk.node_model.node_mlp.packed()
             pd_xm = ops.project_forward([pm_e.w1[1]], Operand(xm, M, 256), M, M)[0]
             pe = ops.project_forward([pm_e.w1[2]], Operand(e, G, 256), G, G)[0]
             px_xm = ops.project_forward([pm_n.w1[0]], Operand(xm, M, 256), M, M)[0]
-            return pd_xm, pe, px_xm
+            return pd_xm, pe, px_xm, e
 
         return self._cached("enc_proj", ps, make)
 
@@ -1068,7 +1071,7 @@ class AssimilatorDecoder(nn.Module):
         n_e = plan.num_edges
         if train:
             ps = ag.project(mlp_e, (0,), processor_features.contiguous(), B * M, M)[0]
-            pe = ag.project(mlp_e, (2,), e, n_e, n_e)[0]
+            pe, e = ag.project(mlp_e, (2,), e, n_e, n_e, passthrough=True)  # (e is the block's residual too: see Encoder._static_projections)
         else:
             pm_e = mlp_e.packed()
             team = self.team_path()
