@@ -3,12 +3,14 @@
 The reference trains through autograd over ATen / torch_scatter ops (``train/run.py:509-521``: ``loss.backward();
 optimizer.step()``).  Here each fused forward op (``gw_mlp_forward``, ``gw_project_forward``, ``gw_edge_update_forward``,
 ``gw_node_update_forward``, ``gw_normalized_mse_forward``) is one autograd node whose backward is composed from the
-generic HIP kernels of ``csrc/gw_train.hip`` (fp32-MFMA GEMMs, LayerNorm / ReLU backward, gather and segment-sum duals).
-PyTorch only links the nodes and sums gradients of tensors that are used more than once; no torch arithmetic op touches
-an activation.  Forward calls made under autograd also write the activations the reference's autograd would have saved
-(relu outputs, pre-LayerNorm rows) - SURVEY.md appendix G.
-
-First version: correctness before speed (activations are materialised, nothing is recomputed or fused).
+HIP kernels of ``csrc/gw_train.hip`` (weight-gradient GEMMs in fp32 or on split operands, gather and segment-sum duals) and the
+register-resident input-gradient chain of an MLP (``gw_mlp_ln_chain_backward``: LayerNorm backward, the masked products of the
+Linear / ReLU chain, the layer-0 input gradients, the first Linear's bias gradient and a joining gradient in ONE launch; fp32 and
+bf16x3).  PyTorch only links the nodes and sums gradients of tensors that are used more than once - where both uses meet in one
+node (an edge row as operand and residual of its block; an edge embedding as product and residual: ``ProjectFunction``
+``passthrough``) the sum happens inside that launch; no torch arithmetic op touches an activation.  Forward calls made under
+autograd also write the activations the reference's autograd would have saved (relu outputs, pre-LayerNorm rows) - SURVEY.md
+appendix G.  MLPs off the kernel shapes (narrow heads, wide models) run the same steps as separate launches.
 """
 from __future__ import annotations
 
@@ -49,7 +51,7 @@ def _x3(mlp) -> bool:
 def gemm_tn_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, c_col0: int = 0, colsum: Optional[torch.Tensor] = None,
                 x3: bool = False) -> None:
     """c[:ma, c_col0:c_col0+nb] += a^T @ b   (a [rows, ma], b [rows, nb]);  colsum[:ma] += column sums of a.  ``x3``: products on
-    split operands (include/gw_amd.h: GW_GEMM_TN_BF16X3; 128-multiples only - other shapes run the fp32 kernel)."""
+    split operands (include/gw_amd.h: GW_GEMM_TN_BF16X3; any shape)."""
     rows, ma, nb = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
     _lib.check(_L().gw_gemm_f32(_lib.GEMM_TN_BF16X3 if x3 else _lib.GEMM_TN, ma, nb, rows, a.data_ptr(), int(a.stride(0)), b.data_ptr(), int(b.stride(0)),
                                 c.data_ptr() + 4 * c_col0, int(c.stride(0)), None if colsum is None else colsum.data_ptr(), _st(a)),

@@ -45,8 +45,9 @@ extern "C" {
  * gw_pack_linear_bf16x3 (4 bytes per weight).  Every table this mode reads or writes is fp32 rows (GW_LAYOUT_ROWS_F32): none of
  * the bf16 mode's 16-bit formats (edge tiles, fp16 product rows, bf16 K-order aggregates, segment-aligned tiles) applies.
  * Trains: the forward entry points accept gw_activation_save with these weights (fp32 saves: relu outputs of every Linear,
- * pre-LayerNorm rows), the backward's masked input-gradient products run through gw_project_forward (relu_mask) on transposed
- * split packs and its weight-gradient GEMMs through gw_gemm_f32 with GW_GEMM_TN_BF16X3; only GW_DTYPE_BF16 is inference-only.
+ * pre-LayerNorm rows), the backward's masked input-gradient products run through gw_mlp_ln_chain_backward /
+ * gw_mlp_chain_backward_bf16x3 (gw_project_forward with relu_mask for single products) on transposed split packs and its
+ * weight-gradient GEMMs through gw_gemm_f32 with GW_GEMM_TN_BF16X3; only GW_DTYPE_BF16 is inference-only.
  * Mesh-sized node updates (gw_node_update_forward with at most 12 288 rows, fp32 and bf16x3 weights alike) run on the row-split
  * kernels of csrc/gw_noders.hip - same arguments, bitwise the rows of the 64-column kernels. */
 #define GW_DTYPE_BF16X3 2
@@ -365,9 +366,9 @@ typedef struct gw_activation_save {
 #define GW_GEMM_NN 0 /* C[m][n]  = sum_k A[m][k] * B[k][n]   (input gradients:  dX = dZ . W)                         */
 #define GW_GEMM_TN 1 /* C[m][n] += sum_k A[k][m] * B[k][n]   (weight gradients: dW += dZ^T . X; C must hold the sum) */
 #define GW_GEMM_TN_BF16X3 2 /* (v16) GW_GEMM_TN with split-operand products (both operands as bf16 hi / lo pairs, three bf16 MFMAs per
-                               product, fp32 accumulate: the weight-gradient GEMMs of the mixed-precision training step); runs when
-                               m and n are multiples of 128 and the operands are 16-byte aligned, otherwise the fp32 kernel
-                               computes the same sums */
+                               product, fp32 accumulate: the weight-gradient GEMMs of the mixed-precision training step); any
+                               shape, leading dimension and alignment (v19; before: multiples of 128 only, other shapes on
+                               the fp32 kernel) */
 int gw_gemm_f32(int32_t mode, int64_t m, int32_t n, int64_t k, const float* a, int32_t lda, const float* b, int32_t ldb,
                 float* c, int32_t ldc, float* colsum_a /* TN only, may be NULL: colsum_a[m] += sum_k A[k][m] (bias gradient) */,
                 void* stream);
