@@ -127,9 +127,10 @@ def lib():
     L.gw_mlp_chain_backward_bf16x3.restype = c_int
     L.gw_mlp_chain_backward_bf16x3.argtypes = L.gw_mlp_chain_backward.argtypes
     L.gw_mlp_ln_chain_backward.restype = c_int
-    L.gw_mlp_ln_chain_backward.argtypes = [c_int32, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    L.gw_mlp_ln_chain_backward.argtypes = [c_int32, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p,
-                                           c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int32, c_void_p]
+                                           c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int32, ctypes.c_uint32, c_void_p]
     L.gw_pack_many.restype = c_int
     L.gw_pack_many.argtypes = [c_int32, c_int32, POINTER(GwPackItem), c_int32, POINTER(GwPadItem), c_void_p]
     L.gw_mlp_forward.restype = c_int

@@ -155,12 +155,17 @@ def input_grad(mlp, layer: int, d: torch.Tensor, W: torch.Tensor, lo: int, hi: i
     return out
 
 
-def chain_backward(d: torch.Tensor, chain, fan, ln=None, colsum=None, fan_add=None):
+FAN_ADD_INPUT = "input gradient"  # fan_add entry: the launch's own input gradient row joins that product (as gathered)
+
+
+def chain_backward(d: torch.Tensor, chain, fan, ln=None, colsum=None, fan_add=None, gather=None):
     """gw_mlp_chain_backward[_bf16x3]: ``chain`` = [(packed W^T, relu output, out)], ``fan`` = [(packed W^T block, out)]; all rows
     x 256.  The packed streams carry the dtype (fp32, or int16 words of the split stream).  Extras of gw_mlp_ln_chain_backward:
-    ``ln`` = (pre-norm rows, gamma, dgamma, dbeta, dy): ``d`` is the gradient at the
-    OUTPUT of the MLP's LayerNorm and the launch walks back through the norm first; ``colsum`` [256] += column sums of the last chain
-    gradient; ``fan_add`` = one tensor or None per fan item, added to that product before it is stored."""
+    ``ln`` = (pre-norm rows, gamma, dgamma, dbeta, dy): ``d`` is the gradient at the OUTPUT of the MLP's LayerNorm and the launch
+    walks back through the norm first; ``colsum`` [256] += column sums of the last chain gradient; ``fan_add`` = one tensor, None
+    or FAN_ADD_INPUT per fan item, added to that product before it is stored; ``gather`` = (idx int32 [n], table rows per batch
+    element, add rows or None), with ``ln`` only: row b * n + k of the launch reads ``d[b * table_rows + idx[k]]`` (+ its row of
+    add) - ``d`` is then the table and the gathered rows are never written."""
     import ctypes as C
 
     def arr(ptrs):
@@ -173,18 +178,24 @@ def chain_backward(d: torch.Tensor, chain, fan, ln=None, colsum=None, fan_add=No
     if len({t.dtype for t in streams}) > 1:
         raise RuntimeError("graph_weather_amd: chain_backward: packed streams of different dtypes")
     x3 = bool(streams) and streams[0].dtype != torch.float32  # (no product at all: the C entry refuses)
+    n_rows = int(chain[0][2].shape[0]) if chain else (int(fan[0][1].shape[0]) if fan else 0)
     chain_items = (len(chain), arr([c[0].data_ptr() for c in chain]), arr([c[1].data_ptr() for c in chain]), arr([c[2].data_ptr() for c in chain]))
     fan_items = (len(fan), arr([f[0].data_ptr() for f in fan]), arr([f[1].data_ptr() for f in fan]))
-    adds = [t for t in (fan_add or []) if t is not None]
-    if ln is not None or colsum is not None or adds:
+    fan_add = list(fan_add or [])
+    adds = [t for t in fan_add if isinstance(t, torch.Tensor)]
+    mask = sum(1 << i for i, t in enumerate(fan_add) if t is FAN_ADD_INPUT)
+    if ln is not None or colsum is not None or adds or mask or gather is not None:
         y, gamma, dgamma, dbeta, dy = ln if ln is not None else (None,) * 5
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        if adds and (len(fan_add) != len(fan) or len({int(t.stride(0)) for t in adds}) != 1):
+        if (adds or mask) and (len(fan_add) != len(fan) or len({int(t.stride(0)) for t in adds}) > 1):
             raise RuntimeError("graph_weather_amd: chain_backward: fan_add needs one entry per fan item and one leading dimension")
-        _lib.check(_L().gw_mlp_ln_chain_backward(_lib.DTYPE_BF16X3 if x3 else _lib.DTYPE_F32, int(d.shape[0]), d.data_ptr(), int(d.stride(0)),
+        idx, tab_rows, gadd = gather if gather is not None else (None, 0, None)
+        _lib.check(_L().gw_mlp_ln_chain_backward(_lib.DTYPE_BF16X3 if x3 else _lib.DTYPE_F32, n_rows, d.data_ptr(), int(d.stride(0)),
+                                                 ptr(idx), 0 if idx is None else int(idx.numel()), int(tab_rows), ptr(gadd),
+                                                 0 if gadd is None else int(gadd.stride(0)),
                                                  ptr(y), ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(dy), *chain_items, ptr(colsum), *fan_items,
-                                                 arr([0 if t is None else t.data_ptr() for t in fan_add]) if adds else None,
-                                                 int(adds[0].stride(0)) if adds else 0, _st(d)),
+                                                 arr([t.data_ptr() if isinstance(t, torch.Tensor) else 0 for t in fan_add]) if adds else None,
+                                                 int(adds[0].stride(0)) if adds else 0, mask, _st(d)),
                    "gw_mlp_ln_chain_backward")
         return
     fn = _L().gw_mlp_chain_backward_bf16x3 if x3 else _L().gw_mlp_chain_backward
@@ -194,7 +205,23 @@ def chain_backward(d: torch.Tensor, chain, fan, ln=None, colsum=None, fan_add=No
 # ---------------------------------------------------------------------------------------------------------------------
 # backward of the Linear/ReLU chain shared by all fused ops
 # ---------------------------------------------------------------------------------------------------------------------
-def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
+class GatheredRows:
+    """An incoming gradient that is a gather: row b * n + k = ``table[b * rows_pb + idx[k]]`` (+ row of ``add``) - the gradient
+    of the edge rows of a block, from the gradient of the aggregate (index_select backward of scatter_sum, graph_net_block.py:188)
+    and of e' where the block exposes it.  ``rows()`` materialises it (gw_gather_rows); the fused chain launch reads it in place."""
+
+    def __init__(self, table: torch.Tensor, rows_pb: int, idx: torch.Tensor, batch: int, add: Optional[torch.Tensor]):
+        self.table, self.rows_pb, self.idx, self.batch, self.add = table, rows_pb, idx, batch, add
+        self.n = int(idx.numel())
+        self._rows: Optional[torch.Tensor] = None
+
+    def rows(self) -> torch.Tensor:
+        if self._rows is None:
+            self._rows = gather_rows(self.table, self.rows_pb, self.idx, self.batch, self.n, self.add)
+        return self._rows
+
+
+def _mlp_chain_backward(dout, saved: SavedActivations, weights: Sequence[torch.Tensor], has_norm: bool,
                         gamma: Optional[torch.Tensor], grads: List[Optional[torch.Tensor]], mlp=None, ln_width: int = 0,
                         fan: Sequence[Tuple[int, int]] = (), fan_out: Optional[dict] = None, bias0_by_caller: bool = False,
                         bias0_in_chain: bool = False, fan_add: Optional[dict] = None):
@@ -211,25 +238,32 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
     dz0 less per MLP.  ``bias0_in_chain``: the caller has no such GEMM (every operand pre-multiplied): the fused chain launch
     sums the columns itself and ``fan_out["bias0_done"]`` is set; MLPs off the kernel shapes leave it to the caller's own pass.
     ``fan_add[(lo, hi)]``: rows the caller would add to that input gradient (the same tensor's gradient from another use: a
-    block's residual); the fused launch adds them before the store and lists the block in ``fan_out["added"]``."""
+    block's residual; FAN_ADD_INPUT: ``dout`` itself); the fused launch adds them before the store and lists the block in
+    ``fan_out["added"]``.  ``dout`` may be ``GatheredRows``: the fused launch with the LayerNorm prologue gathers it in place
+    (``dout.rows()`` is then never made: the caller checks ``dout._rows``); every other path materialises it."""
     n_lin = (len(weights) - (2 if has_norm else 0)) // 2
     if n_lin < 2:
         raise RuntimeError("MLP needs at least one hidden layer")
     # every parameter gradient of this MLP is accumulated into (GEMMs with atomics, column sums): ONE zero fill for all of
     # them - views of a single buffer - instead of one launch per parameter; grads[0] (W0) is handed to the caller zeroed
-    zbuf = torch.zeros(sum(int(w.numel()) for w in weights), dtype=torch.float32, device=dout.device)
+    gathered = dout if isinstance(dout, GatheredRows) else None
+    dev = gathered.table.device if gathered is not None else dout.device
+    zbuf = torch.zeros(sum(int(w.numel()) for w in weights), dtype=torch.float32, device=dev)
     zs, off = [], 0
     for w in weights:
         zs.append(zbuf[off:off + int(w.numel())].view(w.shape))
         off += int(w.numel())
     grads[0] = zs[0]
-    dout = dout.contiguous()
-    n_rows = int(dout.shape[0])
+    if gathered is not None:
+        n_rows, width = gathered.batch * gathered.n, int(gathered.table.shape[1])
+    else:
+        dout = dout.contiguous()
+        n_rows, width = int(dout.shape[0]), int(dout.shape[1])
     # Kernel-shaped MLPs (256 wide, at most two Linear layers above layer 0): the whole chain of masked input-gradient products
     # and the requested layer-0 blocks in ONE launch (gw_mlp_chain_backward); the weight-gradient GEMMs read what it stored.
     # The LayerNorm backward in front of the chain is that launch's prologue (gw_mlp_ln_chain_backward).
     pts = None
-    if (mlp is not None and 2 <= n_lin <= 3 and dout.shape[1] == 256 and n_rows > 0
+    if (mlp is not None and 2 <= n_lin <= 3 and width == 256 and n_rows > 0
             and all(saved.hidden[l].shape[1] == 256 and saved.hidden[l].stride(0) == 256 for l in range(n_lin - 1))):
         pts = [_packed_transposed(mlp, l, weights[2 * l], 0, int(weights[2 * l].shape[1])) for l in range(n_lin - 1, 0, -1)]
         # (fp32 streams: bwd_chain_kernel; split streams of the bf16x3 mode: bwd_chainx3_kernel - the same three-MFMA products)
@@ -237,11 +271,15 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
             pts = None
     ln_fused = (pts is not None and has_norm and int(gamma.numel()) == 256 and ln_width in (0, 256)
                 and saved.pre_norm.shape[1] == 256 and saved.pre_norm.stride(0) == 256)
+    in_place = (gathered is not None and ln_fused and gathered.table.is_contiguous() and gathered.idx.dtype == torch.int32
+                and (gathered.add is None or (gathered.add.stride(1) == 1 and gathered.add.stride(0) % 4 == 0)))
+    if gathered is not None and not in_place:
+        dout = gathered.rows()
     if has_norm:
         grads[-2] = zs[-2]
         grads[-1] = zs[-1]
         if ln_fused:
-            d = torch.empty((n_rows, 256), dtype=torch.float32, device=dout.device)  # written by the chain launch
+            d = torch.empty((n_rows, 256), dtype=torch.float32, device=dev)  # written by the chain launch
         else:
             d = layernorm_backward(dout, saved.pre_norm, gamma, grads[-2], grads[-1], ln_width)
     else:
@@ -253,11 +291,15 @@ def _mlp_chain_backward(dout: torch.Tensor, saved: SavedActivations, weights: Se
         outs = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in pts]
         fouts = [torch.empty((n_rows, 256), dtype=torch.float32, device=d.device) for _ in fblk]
         adds = [fan_add.get(blk) if fan_add else None for blk, _ in fblk]
+        if not ln_fused:  # (the launch's input is then the LayerNorm backward's output, not dout: dout joins as rows)
+            adds = [dout if t is FAN_ADD_INPUT else t for t in adds]
         in_chain = bias0_in_chain and fan_out is not None
-        chain_backward(dout if ln_fused else d, [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
+        chain_backward(gathered.table if in_place else (dout if ln_fused else d),
+                       [(pts[i], saved.hidden[n_lin - 2 - i], outs[i]) for i in range(len(pts))],
                        [(ft, t) for (_, ft), t in zip(fblk, fouts)],
                        ln=(saved.pre_norm, gamma, grads[-2], grads[-1], d) if ln_fused else None,
-                       colsum=zs[1] if in_chain else None, fan_add=adds)
+                       colsum=zs[1] if in_chain else None, fan_add=adds,
+                       gather=(gathered.idx, gathered.rows_pb, gathered.add) if in_place else None)
         fused = outs
         for (blk, _), t in zip(fblk, fouts):
             fan_out[blk] = t
@@ -500,7 +542,9 @@ class EdgeUpdateFunction(torch.autograd.Function):
         E = plan.num_edges
         # gradient at e' = LN(..) + e_res: from the aggregate (gather by destination) and, if exposed, from e_out
         add = de_out.contiguous() if (ctx.want_edges and de_out is not None and de_out.numel()) else None
-        dn = gather_rows(dagg.contiguous(), plan.n_dst, plan.dst, B, E, add)
+        dagg = dagg.contiguous()
+        # (a gather: the fused chain launch reads it in place and the [B * E, 256] table exists only if something else needs it)
+        dn = GatheredRows(dagg, plan.n_dst, plan.dst, B, add)
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         has_norm = mlp._norm() is not None
         fan = [tuple(mlp.native_splits()[i]) for i, sp in enumerate(specs) if sp.mode == "raw" and ctx.needs_input_grad[5 + i]]
@@ -512,7 +556,7 @@ class EdgeUpdateFunction(torch.autograd.Function):
         e_blk = tuple(mlp.native_splits()[2])
         dz0, _ = _mlp_chain_backward(dn, ctx.save, params, has_norm, params[-2] if has_norm else None, grads, mlp, mlp.out_dim,
                                      fan=fan, fan_out=fo, bias0_by_caller=True, bias0_in_chain=no_gemm_on_dz0,
-                                     fan_add={e_blk: dn} if same_e else None)
+                                     fan_add={e_blk: FAN_ADD_INPUT} if same_e else None)
         e_joined = same_e and e_blk in fo.get("added", ())
         W0 = params[0]
         gW0 = grads[0]  # zeroed by _mlp_chain_backward
@@ -541,7 +585,17 @@ class EdgeUpdateFunction(torch.autograd.Function):
         grads[0] = gW0
         de_res = None
         if ctx.needs_input_grad[8] and not e_joined:  # (joined: dts[2] already carries dn - e_in and e_res are one tensor)
-            de_res = dn if ctx.e_res_rows_pb > 0 else segment_sum_rows(dn, E, B, 1, E, plan.identity_ptr(), None)
+            if ctx.e_res_rows_pb > 0:
+                de_res = dn.rows()
+            elif dn._rows is None and add is None:
+                # a residual table shared by the batch, and nothing has made the per-sample rows: sum_b dagg[b, dst[e]] is the
+                # gather of the batch sum of the (small) aggregate gradient - not a pass over a [B * E, 256] table
+                ident = getattr(plan, "_ident_dst", None)
+                if ident is None or ident.device != dagg.device:
+                    ident = plan._ident_dst = torch.arange(plan.n_dst + 1, dtype=torch.int32, device=dagg.device)
+                de_res = gather_rows(segment_sum_rows(dagg, plan.n_dst, B, 1, plan.n_dst, ident, None), plan.n_dst, plan.dst, 1, E)
+            else:
+                de_res = segment_sum_rows(dn.rows(), E, B, 1, E, plan.identity_ptr(), None)
         return (None, None, None, None, None, dts[0], dts[1], dts[2], de_res, None, *grads)
 
 

@@ -114,13 +114,19 @@ __device__ __forceinline__ void row16_sum4(f32x4& v) {
 // forward's LayerNorm); the column sums of d gamma = dn * xhat and d beta = dn over the wave's 16 rows go through DPP row sums into
 // red[0..255 | 256..511] (LDS, this wave's 512 floats) - rows past the end of the table (valid == false: copies of the last row)
 // add nothing.  After a workgroup barrier ln_backward_flush adds the four waves' sums to dgamma / dbeta (one atomic per column).
+// drow2 (wave-uniformly NULL or not): a second row added to dn (the gradient of e' that arrives beside the gathered aggregate's).
 __device__ __forceinline__ void ln_backward_rows16(f32x4 (&g)[16], const float* __restrict__ yrow, const float* __restrict__ drow,
-                                                   const float* __restrict__ gamma, bool valid, int q, int j, float* red) {
+                                                   const float* __restrict__ drow2, const float* __restrict__ gamma, bool valid, int q,
+                                                   int j, float* red) {
   f32x4 yv[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     yv[t] = ldg4(yrow + 16 * t + 4 * q);
     g[t] = ldg4(drow + 16 * t + 4 * q);
+  }
+  if (drow2 != nullptr) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) g[t] += ldg4(drow2 + 16 * t + 4 * q);
   }
   float sum = 0.f;
 #pragma unroll

@@ -105,6 +105,12 @@ struct BwdChainArgs {
   const float* add[5];    // fan products: rows added to the product before it is stored (NULL: none), leading dimension add_ld
   int add_ld;
   float* colsum;          // [256] += column sums of the last chain gradient (Linear_0's bias gradient); NULL: not wanted
+  // LN launches may gather their input gradient: row c reads d[(c / d_idx_n) * d_tab_rows_pb + d_idx[c % d_idx_n]] (+ d_add[c])
+  const int* d_idx;       // NULL: row c of d
+  int d_idx_n, d_tab_rows_pb;
+  const float* d_add;     // rows [n_rows, 256 (ld d_add_ld)] added to the gathered rows; NULL: none
+  int d_add_ld;
+  unsigned add_d_mask;    // bit p: product p (a fan product) adds the launch's own input gradient row (as gathered) before the store
 };
 int bwd_chainx3_launch(const BwdChainArgs& a, void* stream);
 // one matrix item of gw_pack_many into the split stream (strides in floats)

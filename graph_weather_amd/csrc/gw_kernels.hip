@@ -688,9 +688,18 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
   int parity = 0;
   issue_chunk((const float*)a.w[0], kChunkSteps * HSTEPF, lds, lane, wave);
   float x[HS];
+  // this row of the launch's input gradient: row c of d, or (LN launches) gathered through d_idx, plus a row of d_add
+  const float* drow = a.d + (size_t)c * (size_t)a.d_ld;
+  const float* drow2 = nullptr;
+  if (LN && a.d_idx != nullptr) {
+    const long long b = c / a.d_idx_n;
+    const int k = (int)(c - b * a.d_idx_n);
+    drow = a.d + ((size_t)b * (size_t)a.d_tab_rows_pb + (size_t)ldgi(a.d_idx + k)) * (size_t)a.d_ld;
+    if (a.d_add != nullptr) drow2 = a.d_add + (size_t)c * (size_t)a.d_add_ld;
+  }
   if constexpr (LN) {
     f32x4 g[16];
-    ln_backward_rows16(g, a.ln_y + (size_t)c * 256, a.d + (size_t)c * (size_t)a.d_ld, a.ln_gamma, valid, q, j, red_all + wave * 512);
+    ln_backward_rows16(g, a.ln_y + (size_t)c * 256, drow, drow2, a.ln_gamma, valid, q, j, red_all + wave * 512);
     float* orow = a.ln_dy + (size_t)c * 256;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -736,6 +745,13 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_chain_kernel(const BwdChainAr
       const float* arow = a.add[p] + (size_t)c * (size_t)a.add_ld;
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[t] += ldg4(arow + 16 * t + 4 * q);
+    } else if (EXTRA && !chain && ((a.add_d_mask >> p) & 1u)) {  // ... the launch's own input gradient (never materialised when gathered)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] += ldg4(drow + 16 * t + 4 * q);
+      if (drow2 != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] += ldg4(drow2 + 16 * t + 4 * q);
+      }
     }
     if (valid) {
       float* orow = a.out[p] + (size_t)c * 256;
@@ -757,7 +773,7 @@ int bwd_chain_launch_as(const BwdChainArgs& a, void* stream) {
   return check_launch("bwd_chain_kernel launch");
 }
 int bwd_chain_launch(const BwdChainArgs& a, void* stream) {
-  bool extra = a.colsum != nullptr;
+  bool extra = a.colsum != nullptr || a.add_d_mask != 0;
   for (int i = 0; i < 5; ++i) extra = extra || a.add[i] != nullptr;
   if (a.ln_y != nullptr) return extra ? bwd_chain_launch_as<true, true>(a, stream) : bwd_chain_launch_as<true, false>(a, stream);
   return extra ? bwd_chain_launch_as<false, true>(a, stream) : bwd_chain_launch_as<false, false>(a, stream);
@@ -1078,17 +1094,23 @@ int gw_mlp_chain_backward(int64_t n_rows, const float* d, int32_t d_ld, int32_t 
   return bwd_chain_launch(a, stream);
 }
 
-int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
-                             float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
+int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const int32_t* dn_idx,
+                             int32_t dn_idx_n, int32_t dn_table_rows_pb, const float* dn_add, int32_t dn_add_ld, const float* y,
+                             const float* gamma, float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
                              const float* const* chain_mask, float* const* chain_out, float* dz_colsum, int32_t n_fan,
                              const void* const* fan_w, float* const* fan_out, const float* const* fan_add, int32_t fan_add_ld,
-                             void* stream) {
+                             uint32_t fan_add_dn_mask, void* stream) {
   const bool ln = y != nullptr;
   if (ln && (!gamma || !dgamma || !dbeta || !dy)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: NULL LayerNorm argument");
   if (weight_dtype != GW_DTYPE_BF16X3 && weight_dtype != GW_DTYPE_F32)
     return fail(GW_E_UNSUPPORTED, "gw_mlp_ln_chain_backward: fp32 or split (GW_DTYPE_BF16X3) streams");
   if (dz_colsum && n_chain < 1) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: dz_colsum needs a chain product");
   if (fan_add && (fan_add_ld < 256 || fan_add_ld % 4 != 0)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: bad fan_add_ld");
+  if ((dn_idx || dn_add) && !ln) return fail(GW_E_UNSUPPORTED, "gw_mlp_ln_chain_backward: a gathered input gradient needs the LayerNorm in front");
+  if (dn_add && !dn_idx) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: dn_add goes with dn_idx");
+  if (dn_idx && (dn_idx_n <= 0 || dn_table_rows_pb <= 0 || n_rows % dn_idx_n != 0 || (dn_add && (dn_add_ld < 256 || dn_add_ld % 4 != 0))))
+    return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: bad gather arguments");
+  if (fan_add_dn_mask >> (n_fan > 0 ? n_fan : 0)) return fail(GW_E_BADARG, "gw_mlp_ln_chain_backward: fan_add_dn_mask names a fan item that does not exist");
   BwdChainArgs a;
   if (int rc = fill_bwd_chain(a, n_rows, dn, dn_ld, n_chain, chain_w, chain_mask, chain_out, n_fan, fan_w, fan_out)) return rc;
   if (n_rows == 0) return GW_OK;
@@ -1099,9 +1121,15 @@ int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* 
     a.ln_dbeta = dbeta;
     a.ln_dy = dy;
   }
+  a.d_idx = dn_idx;
+  a.d_idx_n = dn_idx_n;
+  a.d_tab_rows_pb = dn_table_rows_pb;
+  a.d_add = dn_add;
+  a.d_add_ld = dn_add_ld;
   a.colsum = dz_colsum;
   a.add_ld = fan_add_ld;
   for (int i = 0; fan_add && i < n_fan; ++i) a.add[n_chain + i] = fan_add[i];
+  a.add_d_mask = fan_add_dn_mask << n_chain;
   return weight_dtype == GW_DTYPE_BF16X3 ? bwd_chainx3_launch(a, stream) : bwd_chain_launch(a, stream);
 }
 

@@ -804,10 +804,19 @@ __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainA
   int parity = 0;
   issue_bytes<NW>((const char*)a.w[0], FIRST, 0u, lane, wave);
   bf16x8 bh[1][HKS], bl[1][HKS];
+  // this row of the launch's input gradient: row c of d, or (LN launches) gathered through d_idx, plus a row of d_add
+  const float* drow = a.d + (size_t)c * (size_t)a.d_ld;
+  const float* drow2 = nullptr;
+  if (LN && a.d_idx != nullptr) {
+    const long long b = c / a.d_idx_n;
+    const int k = (int)(c - b * a.d_idx_n);
+    drow = a.d + ((size_t)b * (size_t)a.d_tab_rows_pb + (size_t)ldgi(a.d_idx + k)) * (size_t)a.d_ld;
+    if (a.d_add != nullptr) drow2 = a.d_add + (size_t)c * (size_t)a.d_add_ld;
+  }
   if constexpr (LN) {
     float* red_all = (float*)(ldsx + 2 * buf_bytes(NW));  // [wave][d gamma | d beta][256]
     f32x4 g[HT];  // this lane's 64 columns of its row: 16 t + 4 q + r
-    ln_backward_rows16(g, a.ln_y + (size_t)c * 256, a.d + (size_t)c * (size_t)a.d_ld, a.ln_gamma, valid, q, j, red_all + wave * 512);
+    ln_backward_rows16(g, a.ln_y + (size_t)c * 256, drow, drow2, a.ln_gamma, valid, q, j, red_all + wave * 512);
     float* orow = a.ln_dy + (size_t)c * 256;
 #pragma unroll
     for (int s = 0; s < HKS; ++s) {
@@ -845,6 +854,13 @@ __global__ __launch_bounds__(256, 2) void bwd_chainx3_kernel(const gw::BwdChainA
       const float* arow = a.add[p] + (size_t)c * (size_t)a.add_ld;
 #pragma unroll
       for (int t = 0; t < HT; ++t) acc[0][t] += ldg4(arow + 16 * t + 4 * q);
+    } else if (!chain && ((a.add_d_mask >> p) & 1u)) {  // ... the launch's own input gradient (never materialised when gathered)
+#pragma unroll
+      for (int t = 0; t < HT; ++t) acc[0][t] += ldg4(drow + 16 * t + 4 * q);
+      if (drow2 != nullptr) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[0][t] += ldg4(drow2 + 16 * t + 4 * q);
+      }
     }
     if (valid) {
       float* orow = a.out[p] + (size_t)c * 256;

@@ -244,17 +244,24 @@ int gw_mlp_chain_backward_bf16x3(int64_t n_rows, const float* d, int32_t d_ld, i
  * (width 256, eps 1e-5, biased variance), y the saved pre-norm rows [n_rows, 256]; dy [n_rows, 256] receives the gradient at the
  * norm's input (the last Linear's weight-gradient product reads it) and is the chain's d_0 without being read back;
  * dgamma / dbeta [256] are accumulated (+=).  y == NULL: no LayerNorm, dn is d_0 (gamma, dgamma, dbeta, dy unused).
- * The chain arguments are those of gw_mlp_chain_backward_bf16x3, plus two things autograd does with separate kernels:
+ * With the LayerNorm the input gradient may be GATHERED by the launch (the index_select backward of scatter_sum,
+ * graph_net_block.py:188: every edge row receives its destination's row of the aggregate's gradient): dn_idx [dn_idx_n] (NULL:
+ * row c reads row c of dn) - row c = b * dn_idx_n + k reads dn[b * dn_table_rows_pb + dn_idx[k]] - plus row c of dn_add
+ * [n_rows, 256 (ld dn_add_ld)] (may be NULL: the gradient of e' where the block exposes it); the [n_rows, 256] table of gathered
+ * rows is then never written.
+ * The chain arguments are those of gw_mlp_chain_backward_bf16x3, plus three things autograd does with separate kernels:
  * dz_colsum [256] (may be NULL) += column sums of the last chain gradient - the first Linear's bias gradient
  * (addmm backward's sum over rows); fan_add[s] (array or entries may be NULL; rows [n_rows, 256 (ld fan_add_ld)]) is added
  * to fan_out[s] before it is stored - the gradient of a tensor that is both an operand of the first Linear and the block's
- * residual (EdgeProcessor: graph_net_block.py:131-137) arrives as one row.
+ * residual (EdgeProcessor: graph_net_block.py:131-137) arrives as one row; bit s of fan_add_dn_mask: that joining gradient is
+ * the launch's own input gradient row (dn as gathered).
  * weight_dtype: GW_DTYPE_F32 or GW_DTYPE_BF16X3 - the dtype of the packed streams. */
-int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const float* y, const float* gamma,
-                             float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
+int gw_mlp_ln_chain_backward(int32_t weight_dtype, int64_t n_rows, const float* dn, int32_t dn_ld, const int32_t* dn_idx,
+                             int32_t dn_idx_n, int32_t dn_table_rows_pb, const float* dn_add, int32_t dn_add_ld, const float* y,
+                             const float* gamma, float* dgamma, float* dbeta, float* dy, int32_t n_chain, const void* const* chain_w,
                              const float* const* chain_mask, float* const* chain_out, float* dz_colsum, int32_t n_fan,
                              const void* const* fan_w, float* const* fan_out, const float* const* fan_add, int32_t fan_add_ld,
-                             void* stream);
+                             uint32_t fan_add_dn_mask, void* stream);
 
 /* ---- layer-1 split: cat[x_s, x_d, e] . W1^T == x_s . Ws^T + x_d . Wd^T + e . We^T ------------------------
  * (graph_net_block.py:131-134 concatenates and multiplies; the products over node tables are shared by the ~7

@@ -470,3 +470,53 @@ def test_layernorm_backward_as_the_prologue_of_the_input_gradient_chain(rows, x3
             assert (got.double() - want.double()).abs().max().item() <= tol * (want.abs().max().item() + 1e-12) + (1e-6 if name == "fan1+add" else 0.0), name
         want_cs = 5.0 + outs[1].double().sum(0)
         assert (cs.double() - want_cs).abs().max().item() <= 1e-5 * (want_cs.abs().max().item() + 1.0)
+
+
+@pytest.mark.parametrize("x3", [True, False])
+def test_chain_launch_gathers_its_input_gradient_in_place(x3):
+    """gw_mlp_ln_chain_backward with dn_idx / dn_add: the launch reads row dagg[b * n_dst + dst[k]] + de_out[b * E + k] itself - the
+    same bits as the launch on the materialised gather (gw_gather_rows), for every output, with the input gradient joining a fan
+    product (fan_add_dn_mask) and a ragged last tile; the C entry refuses a gather without the LayerNorm in front."""
+    from graph_weather_amd import _lib, autograd as ag
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(77)
+    B, n_dst, E = 3, 50, 333
+    rows = B * E
+    W2, W1 = (torch.randn(256, 256, generator=g) / 16).to(DEV), (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    W0 = (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    dagg = torch.randn(B * n_dst, 256, generator=g).to(DEV)
+    dst = torch.sort(torch.randint(0, n_dst, (E,), generator=g)).values.to(torch.int32).to(DEV)
+    de_out = torch.randn(rows, 256, generator=g).to(DEV)
+    y = (torch.randn(rows, 256, generator=g) * 2 + 0.3).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV)
+    h1, h0 = torch.randn(rows, 256, generator=g).relu().to(DEV), torch.randn(rows, 256, generator=g).relu().to(DEV)
+    n = int(L.gw_packed_bytes_bf16x3(256, 0, 256)) // 2 if x3 else int(L.gw_packed_floats(256, 0, 256))
+    blocks = [(W2, 0), (W1, 0), (W0, 0)]
+    buf = torch.empty(len(blocks) * n, dtype=torch.int16 if x3 else torch.float32, device=DEV)
+    ops.pack_many(_lib.DTYPE_BF16X3 if x3 else _lib.DTYPE_F32, [(W.data_ptr() + 4 * lo, 1, int(W.shape[1]), 256, 256, buf[i * n:].data_ptr())
+                                                                for i, (W, lo) in enumerate(blocks)], [], st)
+    pk = [buf[i * n:(i + 1) * n] for i in range(len(blocks))]
+    for add in (de_out, None):
+        res = []
+        for in_place in (True, False):
+            dg, db = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+            d = torch.full((rows, 256), float("nan"), device=DEV)
+            outs = [torch.full((rows, 256), float("nan"), device=DEV) for _ in range(2)]
+            fout = torch.full((rows, 256), float("nan"), device=DEV)
+            chain = [(pk[0], h1, outs[0]), (pk[1], h0, outs[1])]
+            if in_place:
+                ag.chain_backward(dagg, chain, [(pk[2], fout)], ln=(y, gamma, dg, db, d), fan_add=[ag.FAN_ADD_INPUT], gather=(dst, n_dst, add))
+            else:
+                dn = ag.gather_rows(dagg, n_dst, dst, B, E, add)
+                ag.chain_backward(dn, chain, [(pk[2], fout)], ln=(y, gamma, dg, db, d), fan_add=[dn])
+            torch.cuda.synchronize()
+            res.append([d, dg, db] + outs + [fout])
+        for a_, b_, name in zip(res[0], res[1], ["d", "dgamma", "dbeta", "d1", "dz0", "fan+dn"]):
+            if name in ("dgamma", "dbeta"):  # (atomics: the order of the workgroups)
+                assert (a_ - b_).abs().max().item() <= 1e-4 * (b_.abs().max().item() + 1e-6), name
+            else:
+                assert torch.equal(a_, b_), name
+    with pytest.raises(RuntimeError):
+        ag.chain_backward(dagg, [(pk[0], h1, torch.empty(rows, 256, device=DEV))], [], gather=(dst, n_dst, None))
