@@ -4,17 +4,21 @@
 #                                                           + gpurun_out/TAG/pmc_CONFIG_dominant.json: the edge-update instantiation with the
 #                                                             largest grid (the decoder edge update) in the flat form bench.pmc_traffic() reads
 #                                                             (copied to profiles/rNN_pmc_CONFIG.json by scripts/gpu_final.sh)
+# PMC_CMD (optional): the bench.py arguments of the profiled run instead of "--config CONFIG --steps 3 --warmup 1 --no-cpu-baseline
+# --no-extra" - e.g. the training step: PMC_CMD="--mode train --precision bf16x3 --steps 2 --warmup 1" scripts/gpu_pmc_cfg.sh TAG train_x3
+# "(bwd_chainx3_kernel|gemm_tn_x3_kernel)<[^>]*>"
 # HBM bytes: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) and WRITE_SIZE, both in KiB; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /
 # 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); LDS array utilisation = SQ_LDS_IDX_ACTIVE / 256 CUs / (GRBM_GUI_ACTIVE / 8).
 TAG=${1:-pmc}; CFG=${2:-c2}; RX=${3:-"(chainx3_kernel|chain_kernel|edge_kernel|chain16_kernel|node_rs3?_kernel|edge16[a-z_0-9]*kernel)<[^>]*>"}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+CMD=${PMC_CMD:-"--config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-extra"}
 cd /tmp
 run_pass () {
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  GW_AUTO_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $R/$OUT/run_${CFG}_$name.log 2>&1
+  GW_AUTO_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$name -o p -- python $R/bench.py $CMD > $R/$OUT/run_${CFG}_$name.log 2>&1
   echo "rc=$?" >> $R/$OUT/run_${CFG}_$name.log
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" /tmp/raw_${CFG}_$name.csv
